@@ -1,0 +1,213 @@
+/*
+ * include/rfx.h -- C ABI of librfx.so: the MI355X (gfx950) replacement for RemixFusion's
+ * mapping hot-path kernels.
+ *
+ * The reference has no C ABI on this path: its kernels are CUDA-C strings JIT-compiled by
+ * PyCUDA and tiny-cuda-nn torch modules.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference tree).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - extern "C", returns int: 0 = RFX_OK, <0 = error (never throws, never aborts).
+ *   - Every `float*` / `const float*` documented as "dev" is a device pointer owned by the
+ *     caller (e.g. torch tensor.data_ptr()); "host" pointers are small parameter arrays read
+ *     before the call returns.  No hidden allocation: scratch comes from an explicit
+ *     workspace whose size the matching *_workspace_bytes() query reports.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous w.r.t. the host and safe to capture into a hipGraph.
+ *   - Scalars are passed in their true types (the reference packs them into fp32 arrays).
+ *   - No global state; distinct streams / volumes may be driven from distinct threads.
+ */
+#ifndef RFX_H
+#define RFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFX_OK               0
+#define RFX_ERR_ARG         -1   /* null pointer / non-positive size / inconsistent shapes */
+#define RFX_ERR_HIP         -2   /* a HIP runtime call failed (see rfx_last_hip_error)      */
+#define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
+#define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
+
+#define RFX_ABI_VERSION 1
+
+typedef void* rfx_stream;
+
+int rfx_abi_version(void);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int rfx_last_hip_error(void);
+
+/* ======================================================================================
+ * Moving TSDF volume (MV).  Layout: three fp32 arrays of dx*dy*dz voxels, z fastest
+ * (idx = z + y*dz + x*dy*dz), tsdf init 1, weight init 0, colour packed B*65536+G*256+R.
+ * ==================================================================================== */
+
+/* V1: replaces kernel `integrate` model/Volume.py:196-336 + host wrapper :713-757.
+ *   K[9] row-major intrinsics (host), c2w[16] row-major camera-to-world (host),
+ *   color_packed/depth: dev [H*W]; old_bnd[6] = x0,x1,y0,y1,z0,z1 (host, used iff reintegrate).
+ *   index_decode: 0 = reproduce the reference's fp32 index decode (incl. its rounding
+ *   artefacts next to slab boundaries when dx*dy*dz > 2^24), 1 = exact integer decode.
+ *   workspace: dev, >= rfx_tsdf_integrate_workspace_bytes(H, W). */
+size_t rfx_tsdf_integrate_workspace_bytes(int H, int W);
+int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
+                       const float origin[3], float voxel, const float K[9], const float c2w[16],
+                       const float* color_packed, const float* depth, int H, int W,
+                       float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                       const float old_bnd[6], int index_decode,
+                       void* workspace, size_t workspace_bytes, rfx_stream stream);
+
+/* host-side colour packing of model/Volume.py:725-728 moved to the device:
+ * rgb255 dev [n,3] (0..255 valued floats) -> packed dev [n] = floor(B*65536+G*256+R). */
+int rfx_pack_color(const float* rgb255, float* packed, int64_t n, rfx_stream stream);
+
+/* V6: replaces `clean_tsdf` model/Volume.py:561-583 (host :656-677): tsdf=1, weight=0, color=0. */
+int rfx_tsdf_fill(float* tsdf, float* weight, float* color, int64_t n, rfx_stream stream);
+
+/* V7: replaces `copy_volume` model/Volume.py:585-610 (host :883-908). */
+int rfx_tsdf_copy(const float* tsdf, const float* weight, const float* color,
+                  float* tsdf_back, float* weight_back, float* color_back, int64_t n, rfx_stream stream);
+
+/* V2: replaces `swap_rot_trans` model/Volume.py:128-194 (host :796-855): gather the new
+ * volume (dims, origin) from the back copy (old_dims, old_origin); (1,0,0) outside. */
+int rfx_tsdf_shift(float* tsdf, float* weight, float* color, int dx, int dy, int dz, const float origin[3],
+                   const float* old_tsdf, const float* old_weight, const float* old_color,
+                   int odx, int ody, int odz, const float old_origin[3], float voxel,
+                   int index_decode, rfx_stream stream);
+
+/* V3: replaces `tri_intepolate` model/Volume.py:337-458 (host :760-794).
+ * pts dev [n,3] world coords; out5 dev [n,5] = (tsdf, r, g, b, tsdf at low corner). */
+int rfx_tsdf_trilerp(const float* tsdf, const float* weight, const float* color, int dx, int dy, int dz,
+                     const float origin[3], float voxel, const float* pts, int64_t n, float* out5,
+                     rfx_stream stream);
+
+/* V4: replaces `filter_tsdf` model/Volume.py:462-487 (host :857-881). */
+int rfx_tsdf_filter(float* tsdf, float* weight, float* color, int64_t n, float weight_threshold,
+                    rfx_stream stream);
+
+/* V5: replaces `get_truncated_pc` model/Volume.py:489-559 (host :622-653).
+ * pc7 dev [pc_num,7] (caller zero-fills), count dev uint32[1] (caller zero-fills). Slot = idx % pc_num;
+ * when several voxels share a slot the highest voxel index wins (deterministic, unlike the
+ * reference's race). */
+int rfx_tsdf_truncated_pc(const float* tsdf, const float* color, int dx, int dy, int dz,
+                          const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
+                          float* pc7, uint32_t* count, int index_decode, rfx_stream stream);
+
+/* ======================================================================================
+ * Global explicit volume (GBV/GBW): trgb dev [R^3,4] interleaved (tsdf,r,g,b), x fastest;
+ * w dev [R^3].  Same memory the dense-grid lookup (rfx_field_*) reads.
+ * ==================================================================================== */
+
+/* G1: replaces `integrate` mp_slam/mapper.py:37-158 (host :823-872).  c2w is a DEVICE pointer
+ * (the reference passes Holder(pose)); box[6] = x0,x1,y0,y1,z0,z1 (host); rgb01 dev [H,W,3]. */
+int rfx_gbv_integrate(float* trgb, float* w, int res, const float box[6], const float K[9],
+                      const float* c2w_dev, const float* rgb01, const float* depth, int H, int W,
+                      float trunc, float obs_weight, rfx_stream stream);
+
+/* G2: replaces `clean_tsdf` mp_slam/mapper.py:161-183 (host :267-282): t=1, rgb=0. */
+int rfx_gbv_clear(float* trgb, int64_t n_voxels, rfx_stream stream);
+
+/* ======================================================================================
+ * Residual neural field.  Replaces tinycudann.Encoding (HashGrid: model/encodings.py:33-51;
+ * OneBlob: :65-76; dense Grid: model/scene_rep.py:60-93) and the torch MLP
+ * (model/decoder.py:116-146) for the queries of model/scene_rep.py:212-349.
+ * ==================================================================================== */
+
+#define RFX_MAX_LEVELS 16
+
+typedef struct rfx_grid_desc {          /* one multi-resolution grid (tiny-cuda-nn layout) */
+    int32_t  n_levels;                  /* <= RFX_MAX_LEVELS                                 */
+    int32_t  n_feat;                    /* features per entry: 2 (hash), 4 (GBV), 1 (GBW)    */
+    float    scale[RFX_MAX_LEVELS];     /* exp2(l*log2(pls))*base - 1                        */
+    uint32_t res[RFX_MAX_LEVELS];       /* ceil(scale)+1                                     */
+    uint32_t size[RFX_MAX_LEVELS];      /* entries in level                                  */
+    uint32_t offset[RFX_MAX_LEVELS];    /* first entry of level                              */
+    uint32_t hashed[RFX_MAX_LEVELS];    /* 1 = spatial hash, 0 = dense index                 */
+} rfx_grid_desc;
+
+typedef struct rfx_field_desc {
+    rfx_grid_desc hash;                 /* embed_res_fn: 16 levels x 2 features              */
+    const float*  hash_table;           /* dev, hash.offset[L-1]+size[L-1] entries * 2       */
+    const float*  gbv;                  /* dev [R^3*4]                                       */
+    int32_t       gbv_res;              /* R (globalV.base_resolution)                       */
+    const float*  w1;                   /* dev [32,81] torch Linear.weight layout [out,in]   */
+    const float*  w2;                   /* dev [16,32]                                       */
+    const float*  w3;                   /* dev [32,66]                                       */
+    const float*  w4;                   /* dev [3,32]                                        */
+    float         tsdf_scale;           /* training.c_trunc / training.trunc is applied as
+                                           (x*c_trunc)/trunc; both factors are passed:      */
+    float         c_trunc;
+    float         trunc;
+    float         clamp_hi;             /* mapping.clamp when clamp mode is on, else 1       */
+    int32_t       clamp_mode;           /* JointEncoding.clamp (scene_rep.py:332-337)        */
+    int32_t       pos_fp16;             /* 1 = round OneBlob outputs to fp16 (tcnn default)  */
+} rfx_field_desc;
+
+/* E1 alone (query_sdf_res(embed=True), mp_slam/slam.py:209): x01 dev [n,3] -> feat dev [n, L*F]. */
+int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
+                            float* feat, rfx_stream stream);
+/* backward of the above: dfeat dev [n, L*F] -> atomically accumulated into dtable (dev, same
+ * shape as table, caller zero-fills) and, if dx01 != NULL, dx01 dev [n,3] (overwritten). */
+int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
+                             const float* dfeat, float* dtable, float* dx01, rfx_stream stream);
+
+/* E2 alone: tcnn OneBlob, x01 dev [n,3] -> dev [n, 3*n_bins]. */
+int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, float* out, rfx_stream stream);
+
+/* Q1 fused: x01 -> raw4 = (rgb + ex_rgb, sdf + tsdf) (model/scene_rep.py:314-349): E1+E2+E3,
+ * tsdf rescale/clamp, MFMA MLP, residual add.  raw4 dev [n,4]. */
+int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream);
+
+/* Backward of Q1.  draw4 dev [n,4].  Accumulates (atomically) into d_hash (dev, hash table
+ * shape) and dw1..dw4 (dev, weight shapes) -- caller zero-fills or keeps accumulating like
+ * torch .grad; dx01 (dev [n,3], may be NULL) is overwritten. */
+int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                       float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
+                       rfx_stream stream);
+
+/* Q2 point queries (model/scene_rep.py:212-310).  out dev [n] or [n,3] as documented. */
+int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream);          /* query_sdf_res      */
+int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, float* rgb3, rfx_stream stream);       /* query_color_residual */
+
+/* ======================================================================================
+ * Ray sampling + volume rendering (model/scene_rep.py:107-127,156-179,407-456).
+ * ==================================================================================== */
+typedef struct rfx_sampler_desc {
+    float   near, far, range_d;         /* cam.near, cam.far, training.range_d               */
+    int32_t n_range_d, n_samples_d;     /* training.n_range_d, training.n_samples_d          */
+    float   perturb;                    /* training.perturb (>0 = stratified jitter)         */
+} rfx_sampler_desc;
+
+/* S1: target_d dev [n]; u01 dev [n,S] uniform draws (NULL or perturb<=0 -> no jitter);
+ * z_vals dev [n,S], S = n_range_d + n_samples_d, sorted ascending. */
+int rfx_sample_z(const rfx_sampler_desc* s, const float* target_d, const float* u01, int64_t n_rays,
+                 float* z_vals, rfx_stream stream);
+
+/* pts01 = ((o + d*z) - bb_min) / (bb_max - bb_min): rays_o/rays_d dev [n,3], bbox[6] =
+ * x0,x1,y0,y1,z0,z1 host; x01 dev [n,S,3] (model/scene_rep.py:443,:388). */
+int rfx_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays, int S,
+                   const float bbox[6], float* x01, rfx_stream stream);
+
+/* R1 forward: raw4 dev [n,S,4], z dev [n,S] -> rgb dev [n,3], depth dev [n]; weights dev [n,S]
+ * (normalised, saved for backward, may be NULL). */
+int rfx_composite_forward(const float* raw4, const float* z_vals, int64_t n_rays, int S, float trunc,
+                          float sc_factor, float* rgb, float* depth, float* weights, rfx_stream stream);
+/* R1 backward: d_rgb dev [n,3], d_depth dev [n] -> d_raw4 dev [n,S,4] (overwritten). */
+int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_rays, int S, float trunc,
+                           float sc_factor, const float* d_rgb, const float* d_depth, float* d_raw4,
+                           rfx_stream stream);
+
+/* Fused eval render (SLAM.render_single, mp_slam/slam.py:290-344): S1 (no jitter) + points +
+ * Q1 + R1 in one launch; nothing but rgb/depth touches HBM. */
+int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const float* rays_o,
+                    const float* rays_d, const float* target_d, int64_t n_rays, const float bbox[6],
+                    float sc_factor, float* rgb, float* depth, rfx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of librfx.so (include/rfx.h).  There is no CPU fallback: if the library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librfx.so")
+RFX_MAX_LEVELS = 16
+
+
+class RfxError(RuntimeError):
+    pass
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_feat", C.c_int32),
+                ("scale", C.c_float * RFX_MAX_LEVELS), ("res", C.c_uint32 * RFX_MAX_LEVELS),
+                ("size", C.c_uint32 * RFX_MAX_LEVELS), ("offset", C.c_uint32 * RFX_MAX_LEVELS),
+                ("hashed", C.c_uint32 * RFX_MAX_LEVELS)]
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [("hash", GridDesc), ("hash_table", C.c_void_p), ("gbv", C.c_void_p), ("gbv_res", C.c_int32),
+                ("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("w4", C.c_void_p),
+                ("tsdf_scale", C.c_float), ("c_trunc", C.c_float), ("trunc", C.c_float),
+                ("clamp_hi", C.c_float), ("clamp_mode", C.c_int32), ("pos_fp16", C.c_int32)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("near", C.c_float), ("far", C.c_float), ("range_d", C.c_float),
+                ("n_range_d", C.c_int32), ("n_samples_d", C.c_int32), ("perturb", C.c_float)]
+
+
+_P = C.c_void_p
+_F3 = C.c_float * 3
+_F6 = C.c_float * 6
+_F9 = C.c_float * 9
+_F16 = C.c_float * 16
+_i, _f, _l, _sz = C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/rfx.h declares (tests check this).
+PROTOTYPES = {
+    "rfx_abi_version": (_i, []),
+    "rfx_last_hip_error": (_i, []),
+    "rfx_tsdf_integrate_workspace_bytes": (_sz, [_i, _i]),
+    "rfx_tsdf_integrate": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
+                                _i, _P, _sz, _P]),
+    "rfx_pack_color": (_i, [_P, _P, _l, _P]),
+    "rfx_tsdf_fill": (_i, [_P, _P, _P, _l, _P]),
+    "rfx_tsdf_copy": (_i, [_P, _P, _P, _P, _P, _P, _l, _P]),
+    "rfx_tsdf_shift": (_i, [_P, _P, _P, _i, _i, _i, _F3, _P, _P, _P, _i, _i, _i, _F3, _f, _i, _P]),
+    "rfx_tsdf_trilerp": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _P, _l, _P, _P]),
+    "rfx_tsdf_filter": (_i, [_P, _P, _P, _l, _f, _P]),
+    "rfx_tsdf_truncated_pc": (_i, [_P, _P, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _i, _P]),
+    "rfx_gbv_integrate": (_i, [_P, _P, _i, _F6, _F9, _P, _P, _P, _i, _i, _f, _f, _P]),
+    "rfx_gbv_clear": (_i, [_P, _l, _P]),
+    "rfx_grid_encode_forward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P]),
+    "rfx_grid_encode_backward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _P, _P]),
+    "rfx_oneblob_forward": (_i, [_P, _l, _i, _i, _P, _P]),
+    "rfx_field_forward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
+    "rfx_field_backward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rfx_field_query_sdf": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
+    "rfx_field_query_color": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
+    "rfx_sample_z": (_i, [C.POINTER(SamplerDesc), _P, _P, _l, _P, _P]),
+    "rfx_ray_points": (_i, [_P, _P, _P, _l, _i, _F6, _P, _P]),
+    "rfx_composite_forward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
+    "rfx_composite_backward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
+    "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _l, _F6, _f, _P, _P, _P]),
+}
+
+_ERR = {-1: "RFX_ERR_ARG", -2: "RFX_ERR_HIP", -3: "RFX_ERR_UNSUPPORTED", -4: "RFX_ERR_WORKSPACE"}
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen librfx.so and bind every prototype.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RfxError(f"{LIB_PATH} not found: build it with `python -m remixfusion_amd.build` "
+                       "(hipcc --offload-arch=gfx950). remixfusion_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rfx_abi_version() != 1:
+        raise RfxError("librfx.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        extra = f" (hipError {load().rfx_last_hip_error()})" if status == -2 else ""
+        raise RfxError(f"{what} failed: {_ERR.get(status, status)}{extra}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """device pointer of a contiguous fp32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RfxError("librfx kernels need device (cuda/HIP) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise RfxError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def farr(ctype, values: Sequence[float]):
+    return ctype(*[float(v) for v in values])

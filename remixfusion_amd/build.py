@@ -1,0 +1,61 @@
+"""Build librfx.so (the HIP C-ABI library) in-tree with hipcc for gfx950.
+
+``python -m remixfusion_amd.build`` or ``remixfusion_amd.build.build_library()``.
+The library is compiled with -ffp-contract=off so that only explicit fmaf() calls fuse
+(bit-parity with the oracle), and with IEEE-correct fp32 division / sqrt.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librfx.so")
+SOURCES = ["rfx_tsdf.hip", "rfx_field.hip", "rfx_render.hip"]
+HEADERS = ["rfx_common.h", "rfx_field_device.h", os.path.join("..", "..", "include", "rfx.h")]
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: librfx.so cannot be built (no CPU fallback exists)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra: List[str] | None = None) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not _stale():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + (extra or []) + ["-o", LIB + ".tmp"] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building librfx.so")
+    if verbose and res.stderr:
+        sys.stderr.write(res.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))
