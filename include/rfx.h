@@ -162,12 +162,15 @@ int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, f
  * tsdf rescale/clamp, MFMA MLP, residual add.  raw4 dev [n,4]. */
 int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream);
 
-/* Backward of Q1.  draw4 dev [n,4].  Accumulates (atomically) into d_hash (dev, hash table
- * shape) and dw1..dw4 (dev, weight shapes) -- caller zero-fills or keeps accumulating like
- * torch .grad; dx01 (dev [n,3], may be NULL) is overwritten. */
+/* Backward of Q1.  draw4 dev [n,4].  Accumulates into d_hash (dev, hash table shape, float
+ * atomics) and dw1..dw4 (dev, weight shapes, deterministic two-stage sum) -- like torch .grad the
+ * caller zero-fills or keeps accumulating; any of them may be NULL.  dx01 (dev [n,3], may be
+ * NULL) is overwritten with dL/dx01 (through hash grid, OneBlob and the GBV lookup).
+ * workspace: dev, 16-byte aligned, >= rfx_field_backward_workspace_bytes(n). */
+size_t rfx_field_backward_workspace_bytes(int64_t n);
 int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                        float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
-                       rfx_stream stream);
+                       void* workspace, size_t workspace_bytes, rfx_stream stream);
 
 /* Q2 point queries (model/scene_rep.py:212-310).  out dev [n] or [n,3] as documented. */
 int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream);          /* query_sdf_res      */
@@ -187,10 +190,13 @@ typedef struct rfx_sampler_desc {
 int rfx_sample_z(const rfx_sampler_desc* s, const float* target_d, const float* u01, int64_t n_rays,
                  float* z_vals, rfx_stream stream);
 
-/* pts01 = ((o + d*z) - bb_min) / (bb_max - bb_min): rays_o/rays_d dev [n,3], bbox[6] =
- * x0,x1,y0,y1,z0,z1 host; x01 dev [n,S,3] (model/scene_rep.py:443,:388). */
+/* x01 = ((o + d*z) - bb_min) / (bb_max - bb_min) (model/scene_rep.py:443,:388): rays_o/rays_d dev
+ * [n,3], bbox[6] = x0,x1,y0,y1,z0,z1 (host, double).  bbox_f64 != 0 evaluates the normalisation
+ * in float64 and rounds to fp32 -- what torch's type promotion does in the reference whenever
+ * mapping.bound contains a non-integer (the bound tensor is then float64); 0 = all fp32.
+ * x01 dev [n,S,3]. */
 int rfx_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays, int S,
-                   const float bbox[6], float* x01, rfx_stream stream);
+                   const double bbox[6], int bbox_f64, float* x01, rfx_stream stream);
 
 /* R1 forward: raw4 dev [n,S,4], z dev [n,S] -> rgb dev [n,3], depth dev [n]; weights dev [n,S]
  * (normalised, saved for backward, may be NULL). */
@@ -201,11 +207,12 @@ int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_ray
                            float sc_factor, const float* d_rgb, const float* d_depth, float* d_raw4,
                            rfx_stream stream);
 
-/* Fused eval render (SLAM.render_single, mp_slam/slam.py:290-344): S1 (no jitter) + points +
- * Q1 + R1 in one launch; nothing but rgb/depth touches HBM. */
+/* Fused render (SLAM.render_single, mp_slam/slam.py:290-344): S1 + points + Q1 + R1 in one launch,
+ * one wave per ray; nothing but rays, rgb and depth touches HBM.  u01 dev [n,S] (NULL = no jitter). */
 int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const float* rays_o,
-                    const float* rays_d, const float* target_d, int64_t n_rays, const float bbox[6],
-                    float sc_factor, float* rgb, float* depth, rfx_stream stream);
+                    const float* rays_d, const float* target_d, const float* u01, int64_t n_rays,
+                    const double bbox[6], int bbox_f64, float sc_factor, float* rgb, float* depth,
+                    rfx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -330,7 +330,7 @@ def mapping_losses(rgb_map, depth_map, raw, z_vals, target_rgb, target_d, *, dep
     """model/scene_rep.py:493-527."""
     td = target_d.squeeze(-1)
     valid = (td > 0.0) * (td < depth_trunc)
-    rgb_w = valid.clone().unsqueeze(-1).to(rgb_map.dtype)
+    rgb_w = valid.clone().unsqueeze(-1)          # bool, like the reference: the assignment below casts to bool
     rgb_w[rgb_w == 0] = rgb_missing
     rgb_loss = F.mse_loss(rgb_map * rgb_w, target_rgb * rgb_w)
     depth_loss = F.mse_loss(depth_map[valid], td[valid])

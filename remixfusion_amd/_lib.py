@@ -41,6 +41,7 @@ _F3 = C.c_float * 3
 _F6 = C.c_float * 6
 _F9 = C.c_float * 9
 _F16 = C.c_float * 16
+_D6 = C.c_double * 6
 _i, _f, _l, _sz = C.c_int, C.c_float, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes).  Must list every symbol include/rfx.h declares (tests check this).
@@ -63,14 +64,15 @@ PROTOTYPES = {
     "rfx_grid_encode_backward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _P, _P]),
     "rfx_oneblob_forward": (_i, [_P, _l, _i, _i, _P, _P]),
     "rfx_field_forward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
-    "rfx_field_backward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rfx_field_backward_workspace_bytes": (_sz, [_l]),
+    "rfx_field_backward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rfx_field_query_sdf": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_field_query_color": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_sample_z": (_i, [C.POINTER(SamplerDesc), _P, _P, _l, _P, _P]),
-    "rfx_ray_points": (_i, [_P, _P, _P, _l, _i, _F6, _P, _P]),
+    "rfx_ray_points": (_i, [_P, _P, _P, _l, _i, _D6, _i, _P, _P]),
     "rfx_composite_forward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
     "rfx_composite_backward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
-    "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _l, _F6, _f, _P, _P, _P]),
+    "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),
 }
 
 _ERR = {-1: "RFX_ERR_ARG", -2: "RFX_ERR_HIP", -3: "RFX_ERR_UNSUPPORTED", -4: "RFX_ERR_WORKSPACE"}

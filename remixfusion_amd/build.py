@@ -16,12 +16,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librfx.so")
 SOURCES = ["rfx_tsdf.hip", "rfx_field.hip", "rfx_render.hip"]
-HEADERS = ["rfx_common.h", "rfx_field_device.h", os.path.join("..", "..", "include", "rfx.h")]
+HEADERS = ["rfx_common.h", "rfx_field_device.h", "rfx_field_mlp.h", os.path.join("..", "..", "include", "rfx.h")]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function",
+    "-Wall", "-Wno-unused-function", "-DHASH_GROUP=4", "-DFWD_WAVES=3", "-DBWD_WAVES=2",
 ]
 
 

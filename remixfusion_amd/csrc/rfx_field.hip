@@ -1,11 +1,635 @@
-// placeholder: filled in by the field milestone
-#include "rfx_common.h"
-extern "C" {
-int rfx_grid_encode_forward(const rfx_grid_desc*, const float*, const float*, int64_t, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_grid_encode_backward(const rfx_grid_desc*, const float*, const float*, int64_t, const float*, float*, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_oneblob_forward(const float*, int64_t, int, int, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_field_forward(const rfx_field_desc*, const float*, int64_t, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_field_backward(const rfx_field_desc*, const float*, int64_t, const float*, float*, float*, float*, float*, float*, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_field_query_sdf(const rfx_field_desc*, const float*, int64_t, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
-int rfx_field_query_color(const rfx_field_desc*, const float*, int64_t, float*, rfx_stream) { return RFX_ERR_UNSUPPORTED; }
+// rfx_field.hip -- residual neural field on gfx950: multires hash grid + OneBlob + dense GBV lookup
+// + the two bias-free MLPs (81->32->16, 66->32->3), forward and backward.
+//
+// Replaces tinycudann.Encoding (HashGrid / OneBlob / dense Grid) and the torch nn.Linear MLP of the
+// reference for JointEncoding.query_color_sdf & friends (model/scene_rep.py:212-349,
+// model/encodings.py:33-76, model/decoder.py:116-146).
+//
+// Design (MI355X):
+//  * one lane = one sample point, one wave = 64 points.  Encodings are computed per lane in
+//    registers (gathers from the L2/Infinity-Cache resident tables), never written to HBM.
+//  * the MLP runs on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32) in the *transposed*
+//    form  H^T[out x pts] = W[out x in] . X^T[in x pts] : weights are the A operand (staged once
+//    per block in LDS, already in operand order), points are the B operand.  A lane's features
+//    become B operands with one v_permlane32_swap per feature pair, and the 32x32 accumulator of
+//    one layer *is* the B operand of the next layer (its K order is folded into the staged
+//    weights), so activations never leave registers.
+//  * backward = recompute forward, chain the same trick for dX, stage the per-point rows needed
+//    for the weight gradients in a workspace, then (a) a streaming MFMA kernel reduces
+//    dW = dY^T X over points with deterministic two-stage partial sums and (b) a per-point kernel
+//    scatters the hash-grid gradients (float atomics) and evaluates d/dx of the encodings.
+#include "rfx_field_mlp.h"
+#include <algorithm>
+
+namespace rfx {
+
+// ---------------------------------------------------------------- Q1 forward kernel
+__global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
+                                                            float* __restrict__ raw4) {
+    __shared__ float wl[FWD_SLOTS * 64];
+    stage_weights(f, wl, FWD_SLOTS);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const int64_t p = base + lane;
+        float x[3];
+        load_point(x01, p, n, x);
+        Enc e;
+        encode_point(f, x, e);
+        Mlp m;
+        mlp_forward_123<false>(f, x, wl, lane, e, m);
+        float raw[4];
+        mlp_forward_4(wl, lane, e, m, raw);
+        if (p < n) reinterpret_cast<float4*>(raw4)[p] = make_float4(raw[0], raw[1], raw[2], raw[3]);
+    }
 }
+
+// Q2: query_sdf_res (always +-1 clamp) / query_color_residual (decoder fed the raw GBV tsdf)
+template <int MODE>   // 0: sdf, 1: colour
+__global__ __launch_bounds__(256, FWD_WAVES) void field_query_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
+                                                          float* __restrict__ out) {
+    __shared__ float wl[FWD_SLOTS * 64];
+    stage_weights(f, wl, FWD_SLOTS);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const int64_t p = base + lane;
+        float x[3];
+        load_point(x01, p, n, x);
+        Enc e;
+        encode_point(f, x, e);
+        if (MODE == 1) e.cin = e.ex[0];          // scene_rep.py:294: ex_Trgb[...,:1] unscaled
+        Mlp m;
+        mlp_forward_123<false>(f, x, wl, lane, e, m);
+        if (MODE == 0) {
+            float a = m.h2[0][0], b = m.h2[1][0];
+            swap32(a, b);
+            if (p < n) out[p] = a + e.tres;
+        } else {
+            float raw[4];
+            mlp_forward_4(wl, lane, e, m, raw);
+            if (p < n) { out[p * 3] = raw[0]; out[p * 3 + 1] = raw[1]; out[p * 3 + 2] = raw[2]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- E1 / E2 standalone
+__global__ __launch_bounds__(256) void grid_encode_forward_kernel(rfx_grid_desc g, const float* __restrict__ table,
+                                                                  const float* __restrict__ x01, int64_t n,
+                                                                  float* __restrict__ feat) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+    const int Fd = g.n_feat, L = g.n_levels;
+    float* o = feat + p * (int64_t)(L * Fd);
+    for (int l = 0; l < L; ++l) {
+        const Level lv = get_level(g, l);
+        if (Fd == 2) {
+            const float2 v = lookup2(table, lv, x);
+            reinterpret_cast<float2*>(o)[l] = v;
+        } else if (Fd == 4) {
+            const float4 v = lookup4(table, lv, x);
+            reinterpret_cast<float4*>(o)[l] = v;
+        } else {
+            o[l] = lookup1(table, lv, x);
+        }
+    }
+}
+
+// dfeat rows have stride `ld` floats (>= L*F) so that the field backward can point it at its workspace.
+__global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc g, const float* __restrict__ table,
+                                                                   const float* __restrict__ x01, int64_t n,
+                                                                   const float* __restrict__ dfeat, int ld,
+                                                                   float* __restrict__ dtable, float* __restrict__ dx01,
+                                                                   int dx_accumulate) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+    const float* gr = dfeat + p * (int64_t)ld;
+    float dx[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < g.n_levels; ++l) {
+        const Level lv = get_level(g, l);
+        const float2 gv = reinterpret_cast<const float2*>(gr)[l];
+        if (dtable && (gv.x != 0.f || gv.y != 0.f)) scatter2(dtable, lv, x, gv.x, gv.y);
+        if (dx01) {
+            const float gg[2] = {gv.x, gv.y};
+            lookup_dx<2>(table, lv, x, gg, dx);
+        }
+    }
+    if (dx01) {
+        if (dx_accumulate) { dx01[p * 3] += dx[0]; dx01[p * 3 + 1] += dx[1]; dx01[p * 3 + 2] += dx[2]; }
+        else { dx01[p * 3] = dx[0]; dx01[p * 3 + 1] = dx[1]; dx01[p * 3 + 2] = dx[2]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __restrict__ x01, int64_t n, int fp16,
+                                                              float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float v[48];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oneblob_dim<16>(x01[p * 3 + d], fp16 != 0, v + 16 * d);
+    float4* o = reinterpret_cast<float4*>(out + p * 48);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// ---------------------------------------------------------------- backward: workspace layout
+// per-point rows (fp32).  X1 = [emb32 | pos48 | cin | 0..]; G = [geo15 | ex_rgb3 | 0..];
+// dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..]
+constexpr int LD_X1 = 96, LD_H = 32, LD_G = 32, LD_DY2 = 16, LD_DX1 = 96;
+constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
+constexpr int DW_BLOCKS = 256;
+
+struct BwdWs {
+    float *x1, *h1, *dh1, *g, *dy2, *h3, *dh3, *dx1, *partial;
+};
+
+__host__ __device__ inline size_t ws_floats_per_point() { return LD_X1 + 3 * LD_H + LD_G + LD_DY2 + LD_H + LD_DX1; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static BwdWs carve(void* ws, int64_t n) {
+    BwdWs w;
+    float* p = reinterpret_cast<float*>(ws);
+    const size_t np = align_up((size_t)n, 64);
+    w.x1 = p; p += np * LD_X1;
+    w.h1 = p; p += np * LD_H;
+    w.dh1 = p; p += np * LD_H;
+    w.g = p; p += np * LD_G;
+    w.dy2 = p; p += np * LD_DY2;
+    w.h3 = p; p += np * LD_H;
+    w.dh3 = p; p += np * LD_H;
+    w.dx1 = p; p += np * LD_DX1;
+    w.partial = p;
+    return w;
+}
+
+// write 4 consecutive floats of the lane's own row
+__device__ __forceinline__ void st4(float* row, int col, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(row + col) = make_float4(a, b, c, d);
+}
+
+// D-layout tile pair (t0,t1) -> own-point rows, written to `dst` rows of stride ld at column col0 + row.
+// After swap32(t0[r], t1[r]): t0[r] = row krow(r,0) of own point, t1[r] = row krow(r,1).
+// Rows come out in groups of four consecutive indices: regs 4q..4q+3 -> rows 8q..8q+3 (t0) / 8q+4..8q+7 (t1).
+__device__ __forceinline__ void store_tiles_as_rows(f32x16 t0, f32x16 t1, float* row, int col0, bool relu, bool valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = t0[r], b = t1[r];
+        swap32(a, b);
+        t0[r] = relu ? fmaxf(a, 0.f) : a;
+        t1[r] = relu ? fmaxf(b, 0.f) : b;
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        st4(row, col0 + 8 * q, t0[4 * q], t0[4 * q + 1], t0[4 * q + 2], t0[4 * q + 3]);
+        st4(row, col0 + 8 * q + 4, t1[4 * q], t1[4 * q + 1], t1[4 * q + 2], t1[4 * q + 3]);
+    }
+}
+
+__device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16& b) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        m |= (a[r] > 0.f ? 1u : 0u) << r;
+        m |= (b[r] > 0.f ? 1u : 0u) << (16 + r);
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------- backward kernel A (MFMA chain)
+__global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
+                                                             const float* __restrict__ draw4, BwdWs ws) {
+    extern __shared__ float wl[];
+    stage_weights(f, wl, ALL_SLOTS);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const int64_t p = base + lane;
+        const bool valid = p < n;
+        float x[3];
+        load_point(x01, p, n, x);
+        float4 dr = valid ? reinterpret_cast<const float4*>(draw4)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+        Enc e;
+        encode_point(f, x, e);
+        // ---- stage X1 (emb part inside the forward; pos/cin after the forward has used them)
+        float* x1row = ws.x1 + p * LD_X1;
+        Mlp m;
+        mlp_forward_123<true>(f, x, wl, lane, e, m, x1row, valid);
+        // pos is in tile-operand form: swap back to own-point rows for staging
+#pragma unroll
+        for (int s = 0; s < 24; ++s) swap32(e.pos[2 * s], e.pos[2 * s + 1]);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st4(x1row, 32 + 4 * i, e.pos[4 * i], e.pos[4 * i + 1], e.pos[4 * i + 2], e.pos[4 * i + 3]);
+            st4(x1row, 80, e.cin, 0.f, 0.f, 0.f);
+            st4(x1row, 84, 0.f, 0.f, 0.f, 0.f); st4(x1row, 88, 0.f, 0.f, 0.f, 0.f); st4(x1row, 92, 0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned mask1 = positive_mask(m.h1[0], m.h1[1]);
+        const unsigned mask3 = positive_mask(m.h3[0], m.h3[1]);
+        store_tiles_as_rows(m.h1[0], m.h1[1], ws.h1 + p * LD_H, 0, true, valid);
+        store_tiles_as_rows(m.h3[0], m.h3[1], ws.h3 + p * LD_H, 0, true, valid);
+        {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
+            float o[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float a = m.h2[0][r], b = m.h2[1][r];
+                swap32(a, b);
+                o[krow(r, 0)] = a; o[krow(r, 1)] = b;
+            }
+            if (valid) {
+                float* grow = ws.g + p * LD_G;
+                st4(grow, 0, o[1], o[2], o[3], o[4]); st4(grow, 4, o[5], o[6], o[7], o[8]);
+                st4(grow, 8, o[9], o[10], o[11], o[12]); st4(grow, 12, o[13], o[14], o[15], e.ex[1]);
+                st4(grow, 16, e.ex[2], e.ex[3], 0.f, 0.f); st4(grow, 20, 0.f, 0.f, 0.f, 0.f);
+                st4(grow, 24, 0.f, 0.f, 0.f, 0.f); st4(grow, 28, 0.f, 0.f, 0.f, 0.f);
+            }
+        }
+
+        // ---- dH3pre = relu'(h3) . (W4^T dY4)
+        f32x16 d3[2] = {zero16(), zero16()};
+        {
+            float a = dr.x, b = dr.y;
+            swap32(a, b);
+            float w = wl[(OFFB4 + 0) * 64 + lane];
+            d3[0] = mfma32(w, a, d3[0]); d3[1] = mfma32(w, b, d3[1]);
+            a = dr.z; b = 0.f;
+            swap32(a, b);
+            w = wl[(OFFB4 + 1) * 64 + lane];
+            d3[0] = mfma32(w, a, d3[0]); d3[1] = mfma32(w, b, d3[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d3[0][r] = ((mask3 >> r) & 1u) ? d3[0][r] : 0.f;
+            d3[1][r] = ((mask3 >> (16 + r)) & 1u) ? d3[1][r] : 0.f;
+        }
+        store_tiles_as_rows(d3[0], d3[1], ws.dh3 + p * LD_H, 0, false, valid);
+
+        // ---- dX3 = W3^T dH3pre, M-tile 1 first (rows 32..63: d_pos[32..47], d_geo[0..14], d_ex_r)
+        f32x16 gx1[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float w = wl[(OFFB3 + 16 + r) * 64 + lane];
+            gx1[0] = mfma32(w, d3[0][r], gx1[0]); gx1[1] = mfma32(w, d3[1][r], gx1[1]);
+        }
+        // ---- dH1pre = relu'(h1) . (W2^T dY2), dY2 = (d_sdf, d_geo)
+        f32x16 d1[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float w = wl[(OFFB2 + s) * 64 + lane];
+            d1[0] = mfma32(w, gx1[0][8 + s], d1[0]); d1[1] = mfma32(w, gx1[1][8 + s], d1[1]);
+        }
+        {
+            float a = dr.w, b = 0.f;
+            swap32(a, b);
+            const float w = wl[(OFFB2 + 8) * 64 + lane];
+            d1[0] = mfma32(w, a, d1[0]); d1[1] = mfma32(w, b, d1[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d1[0][r] = ((mask1 >> r) & 1u) ? d1[0][r] : 0.f;
+            d1[1][r] = ((mask1 >> (16 + r)) & 1u) ? d1[1][r] : 0.f;
+        }
+        store_tiles_as_rows(d1[0], d1[1], ws.dh1 + p * LD_H, 0, false, valid);
+        // own-point rows of gx1: rows q=0..15 -> d_pos[32..47] (colour path), q=16..30 -> d_geo, q=31 -> d_ex_r
+        float gq[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = gx1[0][r], b = gx1[1][r];
+            swap32(a, b);
+            gq[krow(r, 0)] = a; gq[krow(r, 1)] = b;
+        }
+        if (valid) {
+            float* yrow = ws.dy2 + p * LD_DY2;
+            st4(yrow, 0, dr.w, gq[16], gq[17], gq[18]); st4(yrow, 4, gq[19], gq[20], gq[21], gq[22]);
+            st4(yrow, 8, gq[23], gq[24], gq[25], gq[26]); st4(yrow, 12, gq[27], gq[28], gq[29], gq[30]);
+        }
+        float* dxrow = ws.dx1 + p * LD_DX1;
+        // ---- dX1 = W1^T dH1pre: M-tile 0 = d_emb
+        {
+            f32x16 t[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float w = wl[(OFFB1 + r) * 64 + lane];
+                t[0] = mfma32(w, d1[0][r], t[0]); t[1] = mfma32(w, d1[1][r], t[1]);
+            }
+            store_tiles_as_rows(t[0], t[1], dxrow, 0, false, valid);
+        }
+        // ---- d_pos[0..31] = dX1 M-tile 1 + dX3 M-tile 0
+        {
+            f32x16 t[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float w1s = wl[(OFFB1 + 16 + r) * 64 + lane];
+                t[0] = mfma32(w1s, d1[0][r], t[0]); t[1] = mfma32(w1s, d1[1][r], t[1]);
+                const float w3s = wl[(OFFB3 + r) * 64 + lane];
+                t[0] = mfma32(w3s, d3[0][r], t[0]); t[1] = mfma32(w3s, d3[1][r], t[1]);
+            }
+            store_tiles_as_rows(t[0], t[1], dxrow, 32, false, valid);
+        }
+        // ---- dX1 M-tile 2: rows 64..79 = d_pos[32..47] (+ colour path gq[0..15]), row 80 = d_cin
+        //      dX3 M-tile 2: rows 64,65 = d_ex_g, d_ex_b
+        {
+            f32x16 t[2] = {zero16(), zero16()}, c[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float w1s = wl[(OFFB1 + 32 + r) * 64 + lane];
+                t[0] = mfma32(w1s, d1[0][r], t[0]); t[1] = mfma32(w1s, d1[1][r], t[1]);
+                const float w3s = wl[(OFFB3 + 32 + r) * 64 + lane];
+                c[0] = mfma32(w3s, d3[0][r], c[0]); c[1] = mfma32(w3s, d3[1][r], c[1]);
+            }
+            float tq[32], cq[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = t[0][r], b = t[1][r];
+                swap32(a, b);
+                tq[krow(r, 0)] = a; tq[krow(r, 1)] = b;
+            }
+            {
+                float a = c[0][0], b = c[1][0];
+                swap32(a, b);
+                cq[0] = a;                      // row 0 of M-tile 2 = X3 index 64 = ex_g
+                a = c[0][1]; b = c[1][1];
+                swap32(a, b);
+                cq[1] = a;                      // X3 index 65 = ex_b
+            }
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    st4(dxrow, 64 + 4 * i, tq[4 * i] + gq[4 * i], tq[4 * i + 1] + gq[4 * i + 1], tq[4 * i + 2] + gq[4 * i + 2],
+                        tq[4 * i + 3] + gq[4 * i + 3]);
+                // [80] d_cin, [81..83] d_ex_rgb from the colour net (the residual-add part is added by the dx kernel)
+                st4(dxrow, 80, tq[16], gq[31], cq[0], cq[1]);
+                st4(dxrow, 84, 0.f, 0.f, 0.f, 0.f); st4(dxrow, 88, 0.f, 0.f, 0.f, 0.f); st4(dxrow, 92, 0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward kernel D: dW = dY^T X over points
+// A[i=out][k=pt] = dY[pt][out], B[k=pt][j=in] = X[pt][in]: both are coalesced row reads of the
+// staged [pt][.] arrays, so operands stream straight from memory into MFMA registers.
+__device__ __forceinline__ float ldrow(const float* base, int64_t pt, int ld, int col, int ncol, int64_t n) {
+    return (pt < n && col < ncol) ? base[pt * ld + col] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void field_dw_partial_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
+                                                               float* __restrict__ partial) {
+    __shared__ float red[4][DW_TOTAL / 4 + 64];   // not used for reduction across waves; see below
+    (void)red;
+    const int lane = threadIdx.x & 63, lo = lane & 31, h = lane >> 5;
+    const int wv = threadIdx.x >> 6;
+    // points are dealt to (block, wave) in contiguous slabs of 2*STEP points
+    f32x16 a1[3], a3[3], a2, a4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a1[j] = zero16(); a3[j] = zero16(); }
+    a2 = zero16(); a4 = zero16();
+    const int64_t n_pairs = (n + 1) / 2;
+    const int64_t n_w = (int64_t)gridDim.x * 4;
+    const int64_t per = (n_pairs + n_w - 1) / n_w;
+    const int64_t w_id = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t s0 = w_id * per, s1 = std::min<int64_t>(n_pairs, s0 + per);
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t pt = 2 * s + h;
+        const float dh1 = ldrow(ws.dh1, pt, LD_H, lo, 32, n);
+        const float dh3 = ldrow(ws.dh3, pt, LD_H, lo, 32, n);
+        const float dy2 = ldrow(ws.dy2, pt, LD_DY2, lo, 16, n);
+        const float dy4 = ldrow(draw4, pt, 4, lo, 3, n);
+        const float x1a = ldrow(ws.x1, pt, LD_X1, lo, 96, n);
+        const float x1b = ldrow(ws.x1, pt, LD_X1, 32 + lo, 96, n);
+        const float x1c = ldrow(ws.x1, pt, LD_X1, 64 + lo, 96, n);
+        const float gg = ldrow(ws.g, pt, LD_G, lo, 32, n);
+        const float h1 = ldrow(ws.h1, pt, LD_H, lo, 32, n);
+        const float h3 = ldrow(ws.h3, pt, LD_H, lo, 32, n);
+        a1[0] = mfma32(dh1, x1a, a1[0]); a1[1] = mfma32(dh1, x1b, a1[1]); a1[2] = mfma32(dh1, x1c, a1[2]);
+        a2 = mfma32(dy2, h1, a2);
+        // X3 = [pos48 | geo15 ex3]: pos = X1 cols 32..79 -> needs cols 32+j; built from x1b/x1c shifted:
+        // N-tile 0 of X3 = X1 cols 32..63 = x1b; N-tile 1 = [X1 cols 64..79 | G cols 0..15]; N-tile 2 = G cols 16..17
+        const float x3b = lo < 16 ? ldrow(ws.x1, pt, LD_X1, 64 + lo, 96, n) : ldrow(ws.g, pt, LD_G, lo - 16, 32, n);
+        const float x3c = ldrow(ws.g, pt, LD_G, 16 + lo, 18, n);
+        a3[0] = mfma32(dh3, x1b, a3[0]); a3[1] = mfma32(dh3, x3b, a3[1]); a3[2] = mfma32(dh3, x3c, a3[2]);
+        a4 = mfma32(dy4, h3, a4);
+        (void)gg;
+    }
+    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  Write this wave's partial.
+    float* out = partial + w_id * DW_TOTAL;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = krow(r, h);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i1 = 32 * j + lo;
+            if (i1 < N_IN1) out[o * N_IN1 + i1] = a1[j][r];
+            if (i1 < N_IN3) out[N_H * N_IN1 + N_OUT2 * N_H + o * N_IN3 + i1] = a3[j][r];
+        }
+        if (o < N_OUT2) out[N_H * N_IN1 + o * N_H + lo] = a2[r];
+        if (o < N_OUT4) out[N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + o * N_H + lo] = a4[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void field_dw_reduce_kernel(const float* __restrict__ partial, int n_partials,
+                                                              float* __restrict__ dw1, float* __restrict__ dw2,
+                                                              float* __restrict__ dw3, float* __restrict__ dw4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DW_TOTAL) return;
+    float s = 0.f;
+    for (int k = 0; k < n_partials; ++k) s += partial[(size_t)k * DW_TOTAL + i];
+    const int o1 = N_H * N_IN1, o2 = o1 + N_OUT2 * N_H, o3 = o2 + N_H * N_IN3;
+    if (i < o1) { if (dw1) dw1[i] += s; }
+    else if (i < o2) { if (dw2) dw2[i - o1] += s; }
+    else if (i < o3) { if (dw3) dw3[i - o2] += s; }
+    else { if (dw4) dw4[i - o3] += s; }
+}
+
+// ---------------------------------------------------------------- backward kernel C: dx through OneBlob + GBV
+// adds to dx01 (after the hash part wrote it): needs d_pos[48], d_cin, d_ex_rgb(colour net) from the
+// dX1 rows and draw4 (residual adds: d ex_rgb += draw.rgb, d tres += draw.sdf).
+__global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
+                                                       const float* __restrict__ draw4, const float* __restrict__ dx1,
+                                                       float* __restrict__ dx01) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+    const float* row = dx1 + p * LD_DX1;
+    float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float g[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) g[k] = row[32 + 16 * d + k];
+        dx[d] = oneblob_dim_dx<16>(x[d], g);
+    }
+    const float4 dr = reinterpret_cast<const float4*>(draw4)[p];
+    // tsdf path: t = clamp(ex0*c_trunc/trunc); raw.sdf += t; cin = clamp(t,-1,1) (clamp mode) or t
+    const float4 ex = lookup4(f.gbv, f.gbv_level, x);
+    float t = ex.x * f.c_trunc;
+    t = t / f.trunc;
+    const float d_cin = row[80];
+    float d_t;
+    if (f.clamp_mode) {
+        const bool in_hi = (t >= -f.clamp_hi) && (t <= f.clamp_hi);
+        const float tc = fminf(fmaxf(t, -f.clamp_hi), f.clamp_hi);
+        const bool in_one = (tc >= -1.0f) && (tc <= 1.0f);
+        d_t = in_hi ? (dr.w + (in_one ? d_cin : 0.f)) : 0.f;
+    } else {
+        const bool in_one = (t >= -1.0f) && (t <= 1.0f);
+        d_t = in_one ? (dr.w + d_cin) : 0.f;
+    }
+    const float gex[4] = {d_t * f.c_trunc / f.trunc, row[81] + dr.x, row[82] + dr.y, row[83] + dr.z};
+    lookup_dx<4>(f.gbv, f.gbv_level, x, gex, dx);
+    dx01[p * 3] += dx[0]; dx01[p * 3 + 1] += dx[1]; dx01[p * 3 + 2] += dx[2];
+}
+
+// ---------------------------------------------------------------- host side
+int make_fieldk(const rfx_field_desc* d, FieldK* k) {
+    if (!d || !d->hash_table || !d->gbv || !d->w1 || !d->w2 || !d->w3 || !d->w4) return RFX_ERR_ARG;
+    if (d->hash.n_levels != 16 || d->hash.n_feat != 2) return RFX_ERR_UNSUPPORTED;   // decoder input is 32+48+1
+    if (d->gbv_res <= 1 || !(d->trunc > 0.f)) return RFX_ERR_ARG;
+    k->hash = d->hash;
+    k->table = d->hash_table;
+    k->gbv = d->gbv;
+    // tcnn dense Grid, n_levels=1, per_level_scale=1: scale = base-1, res = base, size = round_up(res^3, 8)
+    k->gbv_level.scale = (float)d->gbv_res - 1.0f;
+    k->gbv_level.res = (unsigned)d->gbv_res;
+    const uint64_t r3 = (uint64_t)d->gbv_res * d->gbv_res * d->gbv_res;
+    if (r3 >= (1ull << 31)) return RFX_ERR_UNSUPPORTED;
+    k->gbv_level.size = (unsigned)((r3 + 7) / 8 * 8);
+    k->gbv_level.offset = 0;
+    k->gbv_level.hashed = 0;
+    k->w1 = d->w1; k->w2 = d->w2; k->w3 = d->w3; k->w4 = d->w4;
+    k->c_trunc = d->c_trunc; k->trunc = d->trunc; k->clamp_hi = d->clamp_hi;
+    k->clamp_mode = d->clamp_mode; k->pos_fp16 = d->pos_fp16;
+    return RFX_OK;
+}
+
+static inline int wave_grid(int64_t n, int max_blocks) {
+    int64_t b = (n + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
+}
+
+}  // namespace rfx
+
+using namespace rfx;
+
+extern "C" {
+
+int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n, float* feat,
+                            rfx_stream stream) {
+    if (!g || !table || !x01 || !feat || n < 0) return RFX_ERR_ARG;
+    if (g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_ARG;
+    if (g->n_feat != 1 && g->n_feat != 2 && g->n_feat != 4) return RFX_ERR_UNSUPPORTED;
+    if (n == 0) return RFX_OK;
+    hipLaunchKernelGGL(grid_encode_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
+                       table, x01, n, feat);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
+                             const float* dfeat, float* dtable, float* dx01, rfx_stream stream) {
+    if (!g || !table || !x01 || !dfeat || n < 0) return RFX_ERR_ARG;
+    if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
+    if (n == 0 || (!dtable && !dx01)) return RFX_OK;
+    hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
+                       table, x01, n, dfeat, g->n_levels * 2, dtable, dx01, 0);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, float* out, rfx_stream stream) {
+    if (!x01 || !out || n < 0) return RFX_ERR_ARG;
+    if (n_bins != 16) return RFX_ERR_UNSUPPORTED;     // pos.n_bins = 16 in every reference config
+    if (n == 0) return RFX_OK;
+    hipLaunchKernelGGL(oneblob_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x01, n,
+                       pos_fp16, out);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream) {
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || !raw4 || n < 0) return RFX_ERR_ARG;
+    if (n == 0) return RFX_OK;
+    hipLaunchKernelGGL(field_forward_kernel, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream) {
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || !sdf || n < 0) return RFX_ERR_ARG;
+    if (n == 0) return RFX_OK;
+    k.clamp_mode = 0;   // query_sdf_res clamps to +-1 regardless of self.clamp (scene_rep.py:233)
+    hipLaunchKernelGGL((field_query_kernel<0>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, sdf);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, float* rgb3, rfx_stream stream) {
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || !rgb3 || n < 0) return RFX_ERR_ARG;
+    if (n == 0) return RFX_OK;
+    hipLaunchKernelGGL((field_query_kernel<1>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, rgb3);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+size_t rfx_field_backward_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    const size_t np = align_up((size_t)n, 64);
+    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * 4 * DW_TOTAL) * sizeof(float);
+}
+
+int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                       float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
+                       void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || !draw4 || n < 0) return RFX_ERR_ARG;
+    if (n == 0) return RFX_OK;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    BwdWs ws = carve(workspace, n);
+    const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
+    static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
+    if (!attr_set) {
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(field_backward_kernel, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, st, k, x01, n, draw4, ws);
+    RFX_LAUNCH_CHECK();
+    if (dw1 || dw2 || dw3 || dw4) {
+        hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
+        RFX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 255) / 256), dim3(256), 0, st, ws.partial, DW_BLOCKS * 4,
+                           dw1, dw2, dw3, dw4);
+        RFX_LAUNCH_CHECK();
+    }
+    if (d_hash || dx01) {
+        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.hash, k.table,
+                           x01, n, ws.dx1, LD_DX1, d_hash, dx01, 0);
+        RFX_LAUNCH_CHECK();
+    }
+    if (dx01) {
+        hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k, x01, n, draw4, ws.dx1, dx01);
+        RFX_LAUNCH_CHECK();
+    }
+    return RFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// rfx_field_device.h -- device building blocks of the residual neural field on gfx950:
+// tiny-cuda-nn-compatible multi-resolution grid lookup (hash / dense), OneBlob, and the
+// fp32-MFMA helpers of the fused MLP.  Conventions: see oracle/field_oracle.py (same contract).
+#pragma once
+#include "rfx_common.h"
+#include <hip/hip_fp16.h>
+
+namespace rfx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------ grid lookup
+struct Level {
+    float scale;
+    unsigned res, size, offset, hashed;
+};
+
+__device__ __forceinline__ Level get_level(const rfx_grid_desc& g, int l) {
+    Level L;
+    L.scale = g.scale[l]; L.res = g.res[l]; L.size = g.size[l]; L.offset = g.offset[l]; L.hashed = g.hashed[l];
+    return L;
+}
+
+// tiny-cuda-nn grid_index<3>: stride walk with the `stride <= hashmap_size` guard, coherent prime
+// hash when the level does not fit, final `% hashmap_size`; everything wraps at 32 bits.
+__device__ __forceinline__ unsigned grid_index(const Level& L, unsigned gx, unsigned gy, unsigned gz) {
+    unsigned idx;
+    if (L.hashed) {
+        idx = gx ^ (gy * 2654435761u) ^ (gz * 805459861u);
+    } else {
+        unsigned stride = 1;
+        idx = 0;
+        if (stride <= L.size) { idx += gx * stride; stride *= L.res; }
+        if (stride <= L.size) { idx += gy * stride; stride *= L.res; }
+        if (stride <= L.size) { idx += gz * stride; stride *= L.res; }
+    }
+    if (idx >= L.size) idx %= L.size;   // in-range dense lookups never take the modulo
+    return idx;
+}
+
+struct Cell {            // per (point, level): base vertex and fractional offsets
+    unsigned g[3];
+    float f[3];
+};
+
+__device__ __forceinline__ Cell locate(const Level& L, const float x[3]) {
+    Cell c;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float pos = fmaf(L.scale, x[d], 0.5f);
+        float fl = floorf(pos);
+        c.g[d] = (unsigned)(int)fl;
+        c.f[d] = pos - fl;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w *= ((corner >> d) & 1) ? c.f[d] : (1.0f - c.f[d]);
+    return w;
+}
+
+__device__ __forceinline__ unsigned corner_index(const Level& L, const Cell& c, int corner) {
+    return grid_index(L, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
+}
+
+// F = 2 lookup (hash grid): returns the two interpolated features of one level.
+__device__ __forceinline__ float2 lookup2(const float* __restrict__ table, const Level& L, const float x[3]) {
+    const Cell c = locate(L, x);
+    const float2* __restrict__ t = reinterpret_cast<const float2*>(table) + L.offset;
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = corner_weight(c, k);
+        acc.x = fmaf(w, v[k].x, acc.x);
+        acc.y = fmaf(w, v[k].y, acc.y);
+    }
+    return acc;
+}
+
+// F = 4 lookup (GBV) and F = 1 (GBW): single dense level.
+__device__ __forceinline__ float4 lookup4(const float* __restrict__ table, const Level& L, const float x[3]) {
+    const Cell c = locate(L, x);
+    const float4* __restrict__ t = reinterpret_cast<const float4*>(table) + L.offset;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = corner_weight(c, k);
+        acc.x = fmaf(w, v[k].x, acc.x); acc.y = fmaf(w, v[k].y, acc.y);
+        acc.z = fmaf(w, v[k].z, acc.z); acc.w = fmaf(w, v[k].w, acc.w);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float lookup1(const float* __restrict__ table, const Level& L, const float x[3]) {
+    const Cell c = locate(L, x);
+    const float* __restrict__ t = table + L.offset;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fmaf(corner_weight(c, k), v[k], acc);
+    return acc;
+}
+
+// d(feature)/dx for one level: sum over the 4 edges along each dim (tcnn kernel_grid_backward_input
+// semantics for Linear interpolation).  g = dL/dfeature (F values); returns dL/dx contribution.
+template <int F>
+__device__ __forceinline__ void lookup_dx(const float* __restrict__ table, const Level& L, const float x[3],
+                                          const float* g, float dx[3]) {
+    const Cell c = locate(L, x);
+    const float* __restrict__ t = table + (size_t)L.offset * F;
+    float dot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned idx = corner_index(L, c, k);
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) s = fmaf(t[(size_t)idx * F + f], g[f], s);
+        dot[k] = s;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float w = ((k >> d) & 1) ? 1.0f : -1.0f;
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (e != d) w *= ((k >> e) & 1) ? c.f[e] : (1.0f - c.f[e]);
+            s = fmaf(w, dot[k], s);
+        }
+        dx[d] = fmaf(L.scale, s, dx[d]);
+    }
+}
+
+// scatter dL/dfeature of one level into the gradient table (F = 2), one float atomic per value.
+__device__ __forceinline__ void scatter2(float* __restrict__ dtable, const Level& L, const float x[3], float g0,
+                                         float g1) {
+    const Cell c = locate(L, x);
+    float* __restrict__ t = dtable + (size_t)L.offset * 2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned idx = corner_index(L, c, k);
+        const float w = corner_weight(c, k);
+        atomicAdd(t + (size_t)idx * 2, w * g0);
+        atomicAdd(t + (size_t)idx * 2 + 1, w * g1);
+    }
+}
+
+// ------------------------------------------------------------------------------ OneBlob
+__device__ __forceinline__ float quartic_cdf(float t, float n) {
+    const float u = t * n;
+    const float u2 = u * u;
+    const float u4 = u2 * u2;
+    return fmaxf(0.0f, fminf(1.0f, (15.0f / 16.0f) * u * (1.0f - (2.0f / 3.0f) * u2 + (1.0f / 5.0f) * u4) + 0.5f));
+}
+// derivative of the (unclamped) cdf polynomial w.r.t. t: 15/16 n (1-u^2)^2 inside |u|<1, else 0
+__device__ __forceinline__ float quartic_pdf(float t, float n) {
+    const float u = t * n;
+    const float q = fmaxf(1.0f - u * u, 0.0f);
+    return (15.0f / 16.0f) * n * q * q;
+}
+
+__device__ __forceinline__ float round_fp16(float v) { return __half2float(__float2half_rn(v)); }
+
+// out[k] for k = 0..NB-1 of one input dim (tcnn one_blob_subwarp_aligned)
+template <int NB>
+__device__ __forceinline__ void oneblob_dim(float x, bool fp16, float* out) {
+    const float n = (float)NB;
+    float Lk[NB + 1];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float lb = (float)k / n;   // exact for power-of-two NB
+        Lk[k] = quartic_cdf(lb - x, n) + quartic_cdf(lb - x - 1.0f, n) + quartic_cdf(lb - x + 1.0f, n);
+    }
+    Lk[NB] = Lk[0] + 1.0f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float v = Lk[k + 1] - Lk[k];
+        out[k] = fp16 ? round_fp16(v) : v;
+    }
+}
+
+// dL/dx through OneBlob for one dim given dL/dout[k] (straight-through across the fp16 rounding)
+template <int NB>
+__device__ __forceinline__ float oneblob_dim_dx(float x, const float* g) {
+    const float n = (float)NB;
+    float dL[NB + 1];   // dLk/dx = -(pdf(..)+pdf(..)+pdf(..))
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float lb = (float)k / n;
+        dL[k] = -(quartic_pdf(lb - x, n) + quartic_pdf(lb - x - 1.0f, n) + quartic_pdf(lb - x + 1.0f, n));
+    }
+    dL[NB] = dL[0];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) s = fmaf(g[k], dL[k + 1] - dL[k], s);
+    return s;
+}
+
+// ------------------------------------------------------------------------------ MFMA helpers
+// v_permlane32_swap: swaps the upper 32 lanes of `a` with the lower 32 lanes of `b`.
+// own-point values (a = feature 2s, b = feature 2s+1 of lane's point) -> (tile0 operand, tile1 operand)
+// where a tile operand holds [k even of points 0..31 | k odd of points 0..31]; the same instruction
+// turns a pair of D-layout registers (tile0, tile1) back into two own-point rows.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row index held by (accumulator register r, lane half h) of a 32x32 D tile
+__host__ __device__ __forceinline__ int krow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+}  // namespace rfx

@@ -1,0 +1,205 @@
+// rfx_field_mlp.h -- the fused encode + MFMA-MLP device path shared by the field kernels
+// (rfx_field.hip) and the fused ray renderer (rfx_render.hip).  See rfx_field.hip for the design.
+#pragma once
+#include "rfx_field_device.h"
+
+namespace rfx {
+
+// ---------------------------------------------------------------- staged weight layout (LDS)
+#ifndef HASH_GROUP
+#define HASH_GROUP 2
+#endif
+#ifndef FWD_WAVES
+#define FWD_WAVES 2
+#endif
+#ifndef BWD_WAVES
+#define BWD_WAVES 2
+#endif
+constexpr int N_EMB = 32, N_POS = 48, N_IN1 = 81, N_H = 32, N_OUT2 = 16, N_IN3 = 66, N_OUT4 = 3;
+constexpr int S1 = 41, S2 = 16, S3 = 34, S4 = 16;
+constexpr int OFF1 = 0, OFF2 = OFF1 + S1, OFF3 = OFF2 + S2, OFF4 = OFF3 + S3, FWD_SLOTS = OFF4 + S4;   // 107
+constexpr int OFFB4 = FWD_SLOTS, OFFB3 = OFFB4 + 2, OFFB2 = OFFB3 + 48, OFFB1 = OFFB2 + 9, ALL_SLOTS = OFFB1 + 48;  // 214
+
+struct FieldK {            // by-value kernel argument
+    rfx_grid_desc hash;
+    const float* table;
+    const float* gbv;
+    Level gbv_level;
+    const float *w1, *w2, *w3, *w4;
+    float c_trunc, trunc, clamp_hi;
+    int clamp_mode, pos_fp16;
+};
+
+// value of staged slot `slot`, lane `l` (see header comment of each layer below)
+__device__ inline float staged_weight(const FieldK& f, int slot, int l) {
+    const int lo = l & 31, h = l >> 5;
+    if (slot < OFF2) {                       // L1: A[hid][k=2s+h] = W1[hid][k]
+        const int k = 2 * (slot - OFF1) + h;
+        return k < N_IN1 ? f.w1[lo * N_IN1 + k] : 0.f;
+    } else if (slot < OFF3) {                // L2: k-slot r = previous accumulator register r
+        const int k = krow(slot - OFF2, h);
+        return lo < N_OUT2 ? f.w2[lo * N_H + k] : 0.f;
+    } else if (slot < OFF4) {                // L3: [pos pairs | h2 regs 0..7 (out o -> geo o-1) | ex_r,ex_g | ex_b,0]
+        const int s = slot - OFF3;
+        int k;
+        if (s < 24) k = 2 * s + h;
+        else if (s < 32) { const int o = krow(s - 24, h); k = o >= 1 ? N_POS + o - 1 : -1; }
+        else if (s == 32) k = 63 + h;
+        else k = h == 0 ? 65 : -1;
+        return k >= 0 ? f.w3[lo * N_IN3 + k] : 0.f;
+    } else if (slot < OFFB4) {               // L4
+        const int k = krow(slot - OFF4, h);
+        return lo < N_OUT4 ? f.w4[lo * N_H + k] : 0.f;
+    } else if (slot < OFFB3) {               // B4: dH3[hid] = sum_o W4[o][hid] dY4[o]; k = o = 2s+h
+        const int o = 2 * (slot - OFFB4) + h;
+        return o < N_OUT4 ? f.w4[o * N_H + lo] : 0.f;
+    } else if (slot < OFFB2) {               // B3: dX3[i] = sum_hid W3[hid][i] dH3[hid]; slot = mt*16 + r
+        const int s = slot - OFFB3, mt = s >> 4, r = s & 15, i = 32 * mt + lo;
+        return i < N_IN3 ? f.w3[krow(r, h) * N_IN3 + i] : 0.f;
+    } else if (slot < OFFB1) {               // B2: dH1[hid] = sum_o W2[o][hid] dY2[o]
+        const int s = slot - OFFB2;
+        if (s < 8) {                         //   k-slot = dX3 M-tile-1 register 8+s: row q -> geo j=q-16 -> o=j+1
+            const int j = krow(8 + s, h) - 16;
+            return j <= 14 ? f.w2[(j + 1) * N_H + lo] : 0.f;
+        }
+        return h == 0 ? f.w2[0 * N_H + lo] : 0.f;   // (d_sdf, 0)
+    } else {                                 // B1: dX1[i] = sum_hid W1[hid][i] dH1[hid]
+        const int s = slot - OFFB1, mt = s >> 4, r = s & 15, i = 32 * mt + lo;
+        return i < N_IN1 ? f.w1[krow(r, h) * N_IN1 + i] : 0.f;
+    }
+}
+
+__device__ inline void stage_weights(const FieldK& f, float* wl, int n_slots) {
+    for (int i = threadIdx.x; i < n_slots * 64; i += blockDim.x) wl[i] = staged_weight(f, i >> 6, i & 63);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- per-point encodings (own-point layout)
+struct Enc {
+    float pos[N_POS];
+    float ex[4];      // GBV (tsdf in c_trunc units, r, g, b)
+    float tres;       // tsdf rescaled/clamped: the residual added to the sdf output
+    float cin;        // tsdf fed to the decoder
+};
+
+__device__ __forceinline__ void encode_point(const FieldK& f, const float x[3], Enc& e) {
+    const float4 g = lookup4(f.gbv, f.gbv_level, x);
+    e.ex[0] = g.x; e.ex[1] = g.y; e.ex[2] = g.z; e.ex[3] = g.w;
+    float t = g.x * f.c_trunc;
+    t = t / f.trunc;
+    if (f.clamp_mode) {
+        t = fminf(fmaxf(t, -f.clamp_hi), f.clamp_hi);
+        e.cin = fminf(fmaxf(t, -1.0f), 1.0f);
+    } else {
+        t = fminf(fmaxf(t, -1.0f), 1.0f);
+        e.cin = t;
+    }
+    e.tres = t;
+    // e.pos is filled by mlp_forward_123 after the hash levels (keeps the gather phase lean)
+}
+
+// ---------------------------------------------------------------- MLP forward on the matrix cores
+struct Mlp {
+    f32x16 h1[2], h2[2], h3[2];
+};
+
+// Hash-grid levels are looked up and fed to the matrix cores level by level (level l = k-step l),
+// so the 32 features are never all live.  STAGE: also write them to x1row (backward staging).
+// consumes e.pos / e.cin / e.ex; leaves e.pos in *tile-operand* form (swapped pairs).
+template <bool STAGE>
+__device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
+                                                int lane, Enc& e, Mlp& m, float* x1row = nullptr,
+                                                bool valid = true) {
+    m.h1[0] = zero16(); m.h1[1] = zero16();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float2 v = lookup2(f.table, get_level(f.hash, s), x);
+        if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v;
+        float a = v.x, b = v.y;
+        swap32(a, b);
+        const float w = wl[(OFF1 + s) * 64 + lane];
+        m.h1[0] = mfma32(w, a, m.h1[0]);
+        m.h1[1] = mfma32(w, b, m.h1[1]);
+        if ((s % HASH_GROUP) == HASH_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oneblob_dim<16>(x[d], f.pos_fp16 != 0, e.pos + 16 * d);
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+        swap32(e.pos[2 * s], e.pos[2 * s + 1]);
+        const float w = wl[(OFF1 + 16 + s) * 64 + lane];
+        m.h1[0] = mfma32(w, e.pos[2 * s], m.h1[0]);
+        m.h1[1] = mfma32(w, e.pos[2 * s + 1], m.h1[1]);
+    }
+    {
+        float a = e.cin, b = 0.f;
+        swap32(a, b);
+        const float w = wl[(OFF1 + 40) * 64 + lane];
+        m.h1[0] = mfma32(w, a, m.h1[0]);
+        m.h1[1] = mfma32(w, b, m.h1[1]);
+    }
+    m.h2[0] = zero16(); m.h2[1] = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float w = wl[(OFF2 + r) * 64 + lane];
+        m.h2[0] = mfma32(w, fmaxf(m.h1[0][r], 0.f), m.h2[0]);
+        m.h2[1] = mfma32(w, fmaxf(m.h1[1][r], 0.f), m.h2[1]);
+    }
+    m.h3[0] = zero16(); m.h3[1] = zero16();
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+        const float w = wl[(OFF3 + s) * 64 + lane];
+        m.h3[0] = mfma32(w, e.pos[2 * s], m.h3[0]);
+        m.h3[1] = mfma32(w, e.pos[2 * s + 1], m.h3[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float w = wl[(OFF3 + 24 + r) * 64 + lane];
+        m.h3[0] = mfma32(w, m.h2[0][r], m.h3[0]);
+        m.h3[1] = mfma32(w, m.h2[1][r], m.h3[1]);
+    }
+    {
+        float a = e.ex[1], b = e.ex[2];
+        swap32(a, b);
+        float w = wl[(OFF3 + 32) * 64 + lane];
+        m.h3[0] = mfma32(w, a, m.h3[0]);
+        m.h3[1] = mfma32(w, b, m.h3[1]);
+        a = e.ex[3]; b = 0.f;
+        swap32(a, b);
+        w = wl[(OFF3 + 33) * 64 + lane];
+        m.h3[0] = mfma32(w, a, m.h3[0]);
+        m.h3[1] = mfma32(w, b, m.h3[1]);
+    }
+}
+
+// layer 4 + residual add -> raw4 of the lane's own point
+__device__ __forceinline__ void mlp_forward_4(const float* __restrict__ wl, int lane, const Enc& e, const Mlp& m,
+                                              float raw[4]) {
+    f32x16 o0 = zero16(), o1 = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float w = wl[(OFF4 + r) * 64 + lane];
+        o0 = mfma32(w, fmaxf(m.h3[0][r], 0.f), o0);
+        o1 = mfma32(w, fmaxf(m.h3[1][r], 0.f), o1);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = o0[c], b = o1[c];
+        swap32(a, b);                 // a = [tile0 lanes<32 | tile1 lanes<32] = own point
+        raw[c] = a + e.ex[c + 1];
+    }
+    float a = m.h2[0][0], b = m.h2[1][0];
+    swap32(a, b);
+    raw[3] = a + e.tres;
+}
+
+__device__ __forceinline__ void load_point(const float* __restrict__ x01, int64_t p, int64_t n, float x[3]) {
+    if (p < n) { x[0] = x01[p * 3]; x[1] = x01[p * 3 + 1]; x[2] = x01[p * 3 + 2]; }
+    else { x[0] = x[1] = x[2] = 0.5f; }
+}
+
+
+// host: build the by-value kernel argument from the public descriptor (defined in rfx_field.hip)
+int make_fieldk(const rfx_field_desc* d, FieldK* k);
+
+}  // namespace rfx

@@ -15,6 +15,7 @@
 // order, fmaf where nvcc -fmad=true contracts, IEEE div/sqrt), so results are bit-identical to
 // oracle/tsdf_oracle.c; the cull only removes voxels that provably fail the reference's tests.
 #include "rfx_common.h"
+#include <algorithm>
 
 namespace rfx {
 
@@ -53,7 +54,14 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(dmax_bits, __float_as_uint(m));
+    // one atomic per block (a single address saturates at ~90 atomics/us on MI355X)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.0f) atomicMax(dmax_bits, __float_as_uint(m));
+    }
 }
 
 // ---------------------------------------------------------------------------- per-voxel math
@@ -586,7 +594,8 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
     unsigned* dmax_bits = reinterpret_cast<unsigned*>(workspace);
     float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + 256);
     RFX_HIP_TRY(hipMemsetAsync(dmax_bits, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(mv_prepass_kernel, dim3(sweep_blocks((int64_t)H * W)), dim3(256), 0, st, depth, dimg,
+    const int prepass_blocks = (int)std::min<int64_t>(256, ((int64_t)H * W + 1023) / 1024);
+    hipLaunchKernelGGL(mv_prepass_kernel, dim3(prepass_blocks), dim3(256), 0, st, depth, dimg,
                        dmax_bits, H, W, K[0], K[4], K[2], K[5]);
     RFX_LAUNCH_CHECK();
     constexpr int TX = 4, TY = 4, U = 2;

@@ -1,0 +1,77 @@
+"""KeyFrameDatabase: per-keyframe ray store + uniform global ray sampling
+(reference model/keyframe.py:5-96).  Rays are (dir3, rgb3, depth1).  Unlike the reference the
+store lives on the mapping device (HBM) so sampling is a device gather, not a CPU gather +
+H2D copy per iteration; Python's ``random`` still draws the indices so a
+seeded run picks the same rays as the reference would."""
+from __future__ import annotations
+
+import random
+
+import torch
+
+
+class KeyFrameDatabase(object):
+    def __init__(self, config, H, W, num_kf, num_rays_to_save, device, num_frame=None) -> None:
+        self.config = config
+        self.keyframes = {}
+        self.device = device
+        self.rays = torch.zeros((num_kf, num_rays_to_save, 7), device=device)
+        self.num_rays_to_save = num_rays_to_save
+        self.frame_ids = None
+        self.H, self.W = H, W
+        self.kf_poses = torch.zeros((num_kf, 4, 4))
+        self.kf_fuse_poses = torch.zeros((num_kf, 4, 4))
+        self.kf_error = torch.zeros((num_kf), device=device)
+        self.kf_error_cnt = torch.zeros((num_kf), device=device)
+        if num_frame is not None:
+            self.all_fuse_pose = torch.zeros((num_frame, 4, 4), device=device)
+
+    def __len__(self):
+        return len(self.frame_ids)
+
+    def get_length(self):
+        return self.__len__()
+
+    def sample_single_keyframe_rays(self, rays, option="random", first=False):
+        """rays [1, H*W, 7] -> [1, num_rays_to_save, 7] (or [num_rays_to_save, 7] for filter_depth)."""
+        rays_valid = None
+        if option == "random":
+            idxs = random.sample(range(0, self.H * self.W), self.num_rays_to_save)
+        elif option == "filter_depth":
+            valid = (rays[..., -1] > 0.0) & (rays[..., -1] <= self.config["cam"]["depth_trunc"])
+            rays_valid = rays[valid, :]
+            if len(rays_valid) > self.num_rays_to_save:
+                idxs = random.sample(range(0, len(rays_valid)), self.num_rays_to_save)
+            else:
+                # too few valid-depth rays: fall back to uniform sampling over the frame.  (The
+                # reference intends this too but its `option == "random"` at :42 is a comparison,
+                # so it would index rays_valid out of range; SURVEY.md appendix D.)
+                idxs = random.sample(range(0, self.H * self.W), self.num_rays_to_save)
+                option = "random"
+        else:
+            raise NotImplementedError()
+        idx_t = torch.as_tensor(idxs, device=rays.device)
+        if option == "random" or first:
+            return rays[:, idx_t]
+        return rays_valid[idx_t, :]
+
+    def attach_ids(self, frame_ids):
+        self.frame_ids = frame_ids if self.frame_ids is None else torch.cat([self.frame_ids, frame_ids], dim=0)
+
+    def add_keyframe(self, batch, filter_depth=False):
+        first = bool(batch["frame_id"] == 0)
+        rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+        rays = rays.reshape(1, -1, rays.shape[-1]).to(self.device)
+        rays = self.sample_single_keyframe_rays(rays, "filter_depth" if filter_depth else "random", first=first)
+        fid = batch["frame_id"]
+        if not isinstance(fid, torch.Tensor):
+            fid = torch.tensor([fid])
+        self.attach_ids(fid.reshape(-1).cpu())
+        self.rays[len(self.frame_ids) - 1] = rays
+
+    def sample_global_rays(self, bs):
+        num_kf = self.__len__()
+        idxs = torch.tensor(random.sample(range(num_kf * self.num_rays_to_save), bs))
+        sample_rays = self.rays[:num_kf].reshape(-1, 7)[idxs.to(self.rays.device)]
+        frame_ids = self.frame_ids[idxs // self.num_rays_to_save]
+        return sample_rays, frame_ids

@@ -1,0 +1,289 @@
+"""GPU parity: librfx field / render kernels (through the C ABI and the Python mirror) vs the torch
+CPU oracle.  fp32 tolerances: forward rel 1e-4; gradients rel 2e-3 (float atomics)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import field_oracle as FO  # noqa: E402
+
+
+def _close(got, ref, rtol, atol, what):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    if not bool((err <= lim).all()):
+        i = int(torch.argmax(err - lim))
+        raise AssertionError(f"{what}: max err {err.max():.3e} (ref scale {ref.abs().max():.3e}); worst "
+                             f"got {got.reshape(-1)[i]:.6e} ref {ref.reshape(-1)[i]:.6e}")
+
+
+def _model(name="office0", hash_scale=0.5, seed=0, gbv_fill=True):
+    """JointEncoding on the GPU with deterministic, non-trivial parameters + the matching oracle params."""
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.scene_rep import JointEncoding
+    cfg = synthetic_config(name)
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    torch.manual_seed(seed)
+    m = JointEncoding(cfg, bb, num_kf=8).cuda()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        m.embed_res_fn.params.copy_(((torch.rand(m.embed_res_fn.params.shape, generator=g) * 2 - 1) * hash_scale).cuda())
+        if gbv_fill:
+            R = cfg["globalV"]["base_resolution"]
+            gv = torch.rand((R ** 3, 4), generator=g)
+            gv[:, 0] = gv[:, 0] * 2.4 - 1.2          # tsdf in c_trunc units, exercises both clamps
+            m.GBV.params.copy_(gv.reshape(-1).cuda())
+            m.GBW.params.copy_(torch.rand(R ** 3, generator=g).cuda())
+    return cfg, m
+
+
+def _oracle_params(cfg, m):
+    w1, w2, w3, w4 = (w.detach().cpu().clone() for w in m.decoder_res.fused_weights())
+    meta = FO.hashgrid_meta_from_config(cfg["grid"]["hash_size"], m.resolution_sdf)
+    return FO.FieldParams(hash_meta=meta, hash_table=m.embed_res_fn.params.detach().cpu().clone(),
+                          gbv=m.GBV.params.detach().cpu().clone(), gbw=m.GBW.params.detach().cpu().clone(),
+                          gbv_res=cfg["globalV"]["base_resolution"], W1=w1, W2=w2, W3=w3, W4=w4,
+                          c_trunc=cfg["training"]["c_trunc"], trunc=cfg["training"]["trunc"],
+                          map_clamp=cfg["mapping"]["clamp"], n_bins=16, pos_fp16=True)
+
+
+def _points(n, seed=0, lo=-0.15, hi=1.15):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((n, 3), generator=g) * (hi - lo) + lo
+    x[:7] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [1.0, 0.0, 0.3], [0.999999, 0.5, 0.0],
+                          [-0.3, 1.4, 0.2], [0.25, 0.75, 1.0]])
+    return x
+
+
+def test_grid_meta_matches_oracle_and_survey_tables():
+    from remixfusion_amd.model.encodings import make_grid_desc
+    for T, R, n_params in ((16, 325, None), (16, 400, None), (19, 450, None), (21, 1750, None)):
+        meta = FO.hashgrid_meta_from_config(T, R)
+        pls = float(np.exp2(np.log2(R / 16) / 15))
+        d, n = make_grid_desc(16, 2, T, 16, pls, True)
+        assert n == meta.offsets[-1]
+        for l in range(16):
+            assert d.res[l] == meta.res[l] and d.size[l] == meta.sizes[l] and d.offset[l] == meta.offsets[l]
+            assert bool(d.hashed[l]) == meta.hashed[l] and abs(d.scale[l] - meta.scales[l]) < 1e-6
+    # office0 R=325 -> 1.64e6 params; scene0000 R=450,T=19 -> 1.02e7
+    assert abs(FO.hashgrid_meta_from_config(16, 325).n_params - 1.64e6) < 2e4
+    assert abs(FO.hashgrid_meta_from_config(19, 450).n_params - 1.02e7) < 2e5
+
+
+def test_hash_and_dense_grid_forward():
+    cfg, m = _model()
+    fp = _oracle_params(cfg, m)
+    x = _points(4099)
+    ref = FO.grid_encode(x, fp.hash_table, fp.hash_meta)
+    got = m.embed_res_fn(x.cuda())
+    _close(got, ref, 1e-5, 1e-6, "hash grid")
+    ref4 = FO.grid_encode(x, fp.gbv, FO.dense_meta(fp.gbv_res, 4))
+    _close(m.GBV(x.cuda()), ref4, 1e-5, 1e-6, "GBV")
+    ref1 = FO.grid_encode(x, fp.gbw, FO.dense_meta(fp.gbv_res, 1))
+    _close(m.GBW(x.cuda()), ref1, 1e-5, 1e-6, "GBW")
+    _close(m.query_w_res(x.cuda().view(-1, 1, 3)).reshape(-1), ref1[:, 0], 1e-5, 1e-6, "query_w_res")
+    _close(m.query_sdf_ex(x.cuda()), ref4[:, 0], 1e-5, 1e-6, "query_sdf_ex")
+    _close(m.query_color_ex(x.cuda()), ref4[:, 1:], 1e-5, 1e-6, "query_color_ex")
+    assert m.embed_res_fn(x[:0].cuda()).shape == (0, 32)       # empty input
+
+
+@pytest.mark.parametrize("name", ["scene0000"])
+def test_hash_grid_forward_large_table(name):
+    cfg, m = _model(name, gbv_fill=False)
+    fp = _oracle_params(cfg, m)
+    x = _points(2000, seed=3)
+    _close(m.embed_res_fn(x.cuda()), FO.grid_encode(x, fp.hash_table, fp.hash_meta), 1e-5, 1e-6, "hash grid T=19")
+
+
+def test_oneblob_forward():
+    from remixfusion_amd.model.encodings import OneBlob
+    x = _points(3000, seed=1, lo=-0.05, hi=1.05)
+    for fp16, tol in ((False, 2e-6), (True, 5e-4)):     # fp16: one half-precision ulp near 1 is 4.9e-4
+        got = OneBlob(16, fp16=fp16)(x.cuda())
+        ref = FO.oneblob_encode(x, 16, pos_fp16=fp16)
+        _close(got, ref, 0, tol, f"oneblob fp16={fp16}")
+        assert abs(float(got.sum(1).mean()) - 3.0) < 1e-2   # each dim's bins integrate to 1
+
+
+@pytest.mark.parametrize("clamp", [False, True])
+def test_field_forward_matches_oracle(clamp):
+    cfg, m = _model()
+    cfg["mapping"]["clamp"] = 1.5
+    fp = _oracle_params(cfg, m)
+    fp.map_clamp = 1.5
+    for n in (1, 63, 64, 65, 1000, 4133):
+        x = _points(max(n, 7), seed=n)[:n]
+        m.clamp = clamp
+        got = m.query_color_sdf(x.cuda())
+        ref = FO.query_color_sdf(fp, x, clamp)
+        _close(got, ref, 1e-4, 2e-5, f"raw4 n={n} clamp={clamp}")
+
+
+def test_point_queries_match_oracle():
+    cfg, m = _model()
+    fp = _oracle_params(cfg, m)
+    x = _points(1500, seed=9)
+    _close(m.query_sdf_res(x.cuda().view(-1, 1, 3)).reshape(-1), FO.query_sdf_res(fp, x), 1e-4, 2e-5, "query_sdf_res")
+    _close(m.query_color_residual(x.cuda()), FO.query_color_residual(fp, x), 1e-4, 2e-5, "query_color_residual")
+    emb = m.query_sdf_res(x.cuda().view(10, 150, 3), embed=True)
+    assert emb.shape == (10, 150, 32)
+    _close(emb.reshape(-1, 32), FO.query_sdf_res(fp, x, embed=True), 1e-5, 1e-6, "embed=True")
+
+
+@pytest.mark.parametrize("clamp", [False, True])
+def test_field_backward_matches_autograd_of_oracle(clamp):
+    cfg, m = _model(hash_scale=0.5)
+    cfg["mapping"]["clamp"] = 1.5
+    fp = _oracle_params(cfg, m)
+    fp.map_clamp = 1.5
+    n = 3001
+    x = _points(n, seed=5, lo=0.02, hi=0.98)
+    g = torch.Generator().manual_seed(11)
+    draw = torch.randn((n, 4), generator=g)
+    # oracle grads
+    xo = x.clone().requires_grad_(True)
+    for t in (fp.hash_table, fp.W1, fp.W2, fp.W3, fp.W4):
+        t.requires_grad_(True)
+    FO.query_color_sdf(fp, xo, clamp).backward(draw)
+    # HIP grads
+    m.clamp = clamp
+    for p in m.parameters():
+        p.grad = None
+    xg = x.cuda().requires_grad_(True)
+    m.query_color_sdf(xg).backward(draw.cuda())
+    w1, w2, w3, w4 = m.decoder_res.fused_weights()
+    for got, ref, nm in ((w1.grad, fp.W1.grad, "dW1"), (w2.grad, fp.W2.grad, "dW2"), (w3.grad, fp.W3.grad, "dW3"),
+                         (w4.grad, fp.W4.grad, "dW4")):
+        _close(got, ref, 2e-3, 2e-3 * float(ref.abs().max()), nm)
+    ref_h = fp.hash_table.grad
+    _close(m.embed_res_fn.params.grad, ref_h, 2e-3, 1e-3 * float(ref_h.abs().max()), "d_hash")
+    assert float((m.embed_res_fn.params.grad != 0).float().mean()) > 0.01
+    _close(xg.grad, xo.grad, 5e-3, 5e-3 * float(xo.grad.abs().mean()), "dx01")
+    assert m.GBV.params.grad is None
+
+
+def test_grid_encode_backward_standalone():
+    cfg, m = _model()
+    fp = _oracle_params(cfg, m)
+    x = _points(2000, seed=2, lo=0.01, hi=0.99)
+    g = torch.Generator().manual_seed(4)
+    dy = torch.randn((2000, 32), generator=g)
+    xo = x.clone().requires_grad_(True)
+    fp.hash_table.requires_grad_(True)
+    FO.grid_encode(xo, fp.hash_table, fp.hash_meta).backward(dy)
+    xg = x.cuda().requires_grad_(True)
+    m.embed_res_fn.params.grad = None
+    m.embed_res_fn(xg).backward(dy.cuda())
+    _close(m.embed_res_fn.params.grad, fp.hash_table.grad, 1e-3, 1e-4 * float(fp.hash_table.grad.abs().max()), "dtable")
+    _close(xg.grad, xo.grad, 2e-3, 2e-3 * float(xo.grad.abs().mean()), "dx")
+
+
+def _rays(n, cfg, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([0.1, -0.6, 0.2]) + 0.05 * torch.randn((n, 3), generator=g)
+    d = torch.randn((n, 3), generator=g) * 0.4
+    d[:, 0] = 1.0
+    td = torch.rand((n, 1), generator=g) * 2.5 + 0.3
+    td[::7] = 0.0                                  # rays without depth -> near..far sampling
+    return o, d, td
+
+
+@pytest.mark.parametrize("name", ["office0", "scene0000"])     # S = 59 and S = 117
+def test_sampler_points_and_compositing(name):
+    cfg, m = _model(name, gbv_fill=False)
+    tr, cam = cfg["training"], cfg["cam"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    n = 257
+    o, d, td = _rays(n, cfg)
+    torch.manual_seed(123)
+    z = m.sample_z_vals(td.cuda(), n, torch.device("cuda"))
+    torch.manual_seed(123)
+    u = torch.rand((n, S), device="cuda").cpu()
+    z_ref = FO.sample_z_vals(td, cam["near"], cam["far"], tr["range_d"], tr["n_range_d"], tr["n_samples_d"], tr["perturb"], u)
+    _close(z, z_ref, 1e-6, 2e-6, "z_vals")
+    # points
+    from remixfusion_amd.model.scene_rep import _RayPointsFn
+    x01 = _RayPointsFn.apply(o.cuda(), d.cuda(), z, m)
+    bb = m.bounding_box
+    pts = o[:, None, :] + d[:, None, :] * z.cpu()[..., None]
+    ref = ((pts.reshape(-1, 3) - bb[:, 0]) / (bb[:, 1] - bb[:, 0])).float()
+    _close(x01, ref, 0, 1e-6, "x01")
+    # compositing forward/backward on crafted raw: includes no-crossing, all-negative, crossing at the end
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand((n, S, 4), generator=g)
+    raw[..., 3] = torch.linspace(1.0, -1.0, S)[None, :] * (0.5 + torch.rand((n, 1), generator=g)) + 0.02 * torch.randn((n, S), generator=g)
+    raw[0, :, 3] = 0.7
+    raw[1, :, 3] = -0.4
+    raw[2, :, 3] = 0.5
+    raw[2, -1, 3] = -0.5
+    raw_g = raw.cuda().requires_grad_(True)
+    rgb, dep = m.raw2outputs(raw_g, z)
+    raw_o = raw.clone().requires_grad_(True)
+    rgb_ref, dep_ref = FO.raw2outputs(raw_o, z.cpu(), tr["trunc"], cfg["data"]["sc_factor"])
+    _close(rgb, rgb_ref, 1e-4, 1e-5, "rgb_map")
+    _close(dep, dep_ref, 1e-4, 1e-5, "depth_map")
+    gr, gd = torch.randn((n, 3), generator=g), torch.randn((n,), generator=g)
+    (rgb * gr.cuda()).sum().add((dep * gd.cuda()).sum()).backward()
+    (rgb_ref * gr).sum().add((dep_ref * gd).sum()).backward()
+    _close(raw_g.grad, raw_o.grad, 2e-3, 1e-4, "d_raw")
+    w = m.sdf2weights(raw[..., 3].cuda(), z)
+    _close(w, FO.sdf2weights(raw[..., 3], z.cpu(), tr["trunc"], cfg["data"]["sc_factor"]), 1e-4, 1e-6, "weights")
+
+
+@pytest.mark.parametrize("name", ["office0", "scene0000"])
+def test_fused_render_matches_oracle(name):
+    cfg, m = _model(name)
+    fp = _oracle_params(cfg, m)
+    tr, cam = cfg["training"], cfg["cam"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    n = 150
+    o, d, td = _rays(n, cfg, seed=3)
+    torch.manual_seed(77)
+    rgb, dep = m.render_fused(o.cuda(), d.cuda(), td.cuda())
+    torch.manual_seed(77)
+    u = torch.rand((n, S), device="cuda").cpu()
+    z = FO.sample_z_vals(td, cam["near"], cam["far"], tr["range_d"], tr["n_range_d"], tr["n_samples_d"], tr["perturb"], u)
+    ref = FO.render_rays(fp, m.bounding_box, o, d, z, clamp=False, sc_factor=cfg["data"]["sc_factor"])
+    _close(rgb, ref["rgb_res_map"], 2e-4, 2e-5, "fused rgb")
+    _close(dep, ref["depth_res_map"], 2e-4, 2e-5, "fused depth")
+
+
+def test_mapping_losses_and_total_gradient_match_oracle():
+    """JointEncoding.mapping() end to end (train mode) vs the oracle, including parameter grads."""
+    cfg, m = _model(hash_scale=0.05)
+    fp = _oracle_params(cfg, m)
+    tr, cam = cfg["training"], cfg["cam"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    n = 300
+    o, d, td = _rays(n, cfg, seed=8)
+    g = torch.Generator().manual_seed(2)
+    tgt = torch.rand((n, 3), generator=g)
+    m.train()
+    torch.manual_seed(5)
+    ret = m.mapping(o.cuda(), d.cuda(), tgt.cuda(), td.cuda())
+    torch.manual_seed(5)
+    u = torch.rand((n, S), device="cuda").cpu()
+    z = FO.sample_z_vals(td, cam["near"], cam["far"], tr["range_d"], tr["n_range_d"], tr["n_samples_d"], tr["perturb"], u)
+    for t in (fp.hash_table, fp.W1, fp.W2, fp.W3, fp.W4):
+        t.requires_grad_(True)
+    rend = FO.render_rays(fp, m.bounding_box, o, d, z, clamp=False, sc_factor=cfg["data"]["sc_factor"])
+    ref = FO.mapping_losses(rend["rgb_res_map"], rend["depth_res_map"], rend["raw"], z, tgt, td,
+                            depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"], trunc=tr["trunc"],
+                            sc_factor=cfg["data"]["sc_factor"])
+    for k in ("rgb_res_loss", "depth_res_loss", "sdf_res_loss", "fs_res_loss"):
+        _close(ret[k], ref[k], 1e-4, 1e-7, k)
+    w = {k: tr[k] for k in ("rgb_weight", "depth_weight", "sdf_weight", "fs_weight")}
+    FO.total_loss(ref, w).backward()
+    for p in m.parameters():
+        p.grad = None
+    FO.total_loss(ret, w).backward()
+    w1 = m.decoder_res.fused_weights()[0]
+    _close(w1.grad, fp.W1.grad, 5e-3, 5e-3 * float(fp.W1.grad.abs().max()), "dL/dW1")
+    _close(m.embed_res_fn.params.grad, fp.hash_table.grad, 5e-3, 2e-3 * float(fp.hash_table.grad.abs().max()), "dL/dhash")
+    m.eval()
+    out = m.mapping(o.cuda(), d.cuda(), tgt.cuda(), td.cuda())
+    assert set(out) == {"rgb_res_map", "depth_res_map", "z_vals", "raw"}

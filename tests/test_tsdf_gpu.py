@@ -140,15 +140,197 @@ def test_integrate_no_valid_depth_is_noop_and_camera_outside():
     _run_pair((40, 40, 30), (-2, -3, -2), 0.1, 0.2, [(K, back, rgb, depth + 4.0)])
 
 
-def test_integrate_matches_nofma_oracle_within_tolerance():
-    """the uncontracted variant of the oracle only moves round-off (SURVEY 8d tolerances)."""
+# ------------------------------------------------------------------ the other MV kernels
+def _rand_vol(dims, seed=0):
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(dims))
+    t = rng.uniform(-1, 1, n).astype(np.float32)
+    w = rng.integers(0, 5, n).astype(np.float32)
+    c = (rng.integers(0, 256, n) * 65536 + rng.integers(0, 256, n) * 256 + rng.integers(0, 256, n)).astype(np.float32)
+    return t, w, c
+
+
+def _cuda(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def test_fill_copy_filter():
+    import torch
     from oracle import tsdf as O
-    K, c2w, rgb, depth, _ = small_frame()
-    dims, origin = (200, 200, 150), (-4, -5, -3)
-    a, b = _oracle_vol(dims), _oracle_vol(dims)
-    O.load(True).mv_integrate(*a, dims, origin, 0.04, K, c2w, O.pack_color(rgb), depth, 0.15)
-    O.load(False).mv_integrate(*b, dims, origin, 0.04, K, c2w, O.pack_color(rgb), depth, 0.15)
-    touched = (a[1] != b[1])
-    assert touched.mean() <= 1e-4
-    same = ~touched
-    assert np.max(np.abs(a[0][same] - b[0][same])) <= 2e-5
+    from remixfusion_amd import _lib as L
+    lib, orc = L.load(), O.load()
+    for n_side in ((13, 7, 5), (64, 64, 33)):
+        t, w, c = _rand_vol(n_side, 1)
+        n = t.size
+        dt, dw, dc = _cuda(t, w, c)
+        bt, bw, bc = (torch.empty_like(dt) for _ in range(3))
+        L.check(lib.rfx_tsdf_copy(L.ptr(dt), L.ptr(dw), L.ptr(dc), L.ptr(bt), L.ptr(bw), L.ptr(bc), n, L.stream_ptr()), "copy")
+        for g, r in zip((bt, bw, bc), (t, w, c)):
+            _assert_bit_equal(g.cpu().numpy(), r, "copy")
+        ft, fw, fc = t.copy(), w.copy(), c.copy()
+        orc.mv_filter(ft, fw, fc, 2.0)
+        L.check(lib.rfx_tsdf_filter(L.ptr(dt), L.ptr(dw), L.ptr(dc), n, 2.0, L.stream_ptr()), "filter")
+        for g, r in zip((dt, dw, dc), (ft, fw, fc)):
+            _assert_bit_equal(g.cpu().numpy(), r, "filter")
+        L.check(lib.rfx_tsdf_fill(L.ptr(dt), L.ptr(dw), L.ptr(dc), n, L.stream_ptr()), "fill")
+        assert (dt == 1).all() and (dw == 0).all() and (dc == 0).all()
+
+
+@pytest.mark.parametrize("shift", [(1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (0.0, 0.0, -1.0), (3.0, -3.0, 1.0), (0.37, 0.0, 0.0)])
+def test_shift_matches_oracle_and_roundtrips(shift):
+    from oracle import tsdf as O
+    from remixfusion_amd import _lib as L
+    lib, orc = L.load(), O.load()
+    dims, voxel = (50, 40, 30), 0.1
+    origin = np.array([-2.0, -2.0, -1.0], np.float32)
+    new_origin = origin + np.asarray(shift, np.float32)
+    src = _rand_vol(dims, 2)
+    ref = [np.empty_like(a) for a in src]
+    orc.mv_shift(ref, src, dims, new_origin, dims, origin, voxel)
+    d_src = _cuda(*src)
+    d_dst = _cuda(*[np.zeros_like(a) for a in src])
+    L.check(lib.rfx_tsdf_shift(*[L.ptr(a) for a in d_dst], *dims, L.farr(L._F3, new_origin),
+                               *[L.ptr(a) for a in d_src], *dims, L.farr(L._F3, origin), voxel, 0, L.stream_ptr()), "shift")
+    for g, r, nm in zip(d_dst, ref, "twc"):
+        _assert_bit_equal(g.cpu().numpy(), r, "shift " + nm)
+    if all(float(s).is_integer() for s in shift):
+        # shift(+s) then shift(-s) restores the overlap region exactly, (1,0,0) elsewhere
+        back = _cuda(*[np.zeros_like(a) for a in src])
+        L.check(lib.rfx_tsdf_shift(*[L.ptr(a) for a in back], *dims, L.farr(L._F3, origin),
+                                   *[L.ptr(a) for a in d_dst], *dims, L.farr(L._F3, new_origin), voxel, 0, L.stream_ptr()), "shift")
+        sv = np.round(np.asarray(shift) / voxel).astype(int)
+        x, y, z = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij")
+        inside = np.ones(dims, bool)
+        for ax, g in zip(range(3), (x, y, z)):
+            inside &= (g - sv[ax] >= 0) & (g - sv[ax] < dims[ax])
+        got = back[0].cpu().numpy().reshape(dims)
+        assert np.array_equal(got[inside], src[0].reshape(dims)[inside])
+        assert (got[~inside] == 1).all()
+
+
+def test_trilerp_matches_oracle():
+    from oracle import tsdf as O
+    from remixfusion_amd import _lib as L
+    import torch
+    lib, orc = L.load(), O.load()
+    dims, voxel = (30, 25, 20), 0.05
+    origin = np.array([-0.7, -0.6, -0.5], np.float32)
+    t, w, c = _rand_vol(dims, 3)
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-0.9, 1.0, (5000, 3)).astype(np.float32)         # includes out-of-volume points
+    pts[:50] = origin + np.floor(rng.uniform(0, 19, (50, 3))) * voxel  # exactly on vertices
+    ref = orc.mv_trilerp(t, w, c, dims, origin, voxel, pts)
+    dt, dw, dc, dp = _cuda(t, w, c, pts)
+    out = torch.empty((pts.shape[0], 5), device="cuda")
+    L.check(lib.rfx_tsdf_trilerp(L.ptr(dt), L.ptr(dw), L.ptr(dc), *dims, L.farr(L._F3, origin), voxel, L.ptr(dp),
+                                 pts.shape[0], L.ptr(out), L.stream_ptr()), "trilerp")
+    _assert_bit_equal(out.cpu().numpy(), ref, "trilerp")
+    # empty input is a no-op
+    L.check(lib.rfx_tsdf_trilerp(L.ptr(dt), L.ptr(dw), L.ptr(dc), *dims, L.farr(L._F3, origin), voxel, L.ptr(dp), 0,
+                                 L.ptr(out), L.stream_ptr()), "trilerp0")
+
+
+def test_truncated_pc_matches_oracle():
+    from oracle import tsdf as O
+    from remixfusion_amd import _lib as L
+    import torch
+    lib, orc = L.load(), O.load()
+    dims, voxel = (40, 30, 20), 0.05
+    origin = np.array([-1.0, -0.7, -0.5], np.float32)
+    t, w, c = _rand_vol(dims, 5)
+    for pc_num in (1000, 24000, 50000):
+        ref, n_ref = orc.mv_truncated_pc(t, c, dims, origin, voxel, 0.05, pc_num, 0.5)
+        dt, dc = _cuda(t, c)
+        pc = torch.zeros((pc_num, 7), device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(lib.rfx_tsdf_truncated_pc(L.ptr(dt), L.ptr(dc), *dims, L.farr(L._F3, origin), voxel, 0.05, pc_num, 0.5,
+                                          L.ptr(pc), cnt.data_ptr(), 0, L.stream_ptr()), "pc")
+        _assert_bit_equal(pc.cpu().numpy(), ref, "pc")
+        assert int(cnt.item()) == n_ref
+
+
+# ------------------------------------------------------------------ GBV
+def test_gbv_integrate_and_clear_bit_exact():
+    from oracle import tsdf as O
+    from remixfusion_amd import _lib as L
+    import torch
+    lib, orc = L.load(), O.load()
+    box = np.array([-3, 3, -4, 2.5, -2, 2.5], np.float32)
+    for R in (48, 200):
+        n = R ** 3
+        trgb = np.zeros((n, 4), np.float32)
+        wv = np.zeros(n, np.float32)
+        orc.gbv_clear(trgb)
+        d_trgb = torch.zeros((n, 4), device="cuda")
+        d_w = torch.zeros(n, device="cuda")
+        L.check(lib.rfx_gbv_clear(L.ptr(d_trgb), n, L.stream_ptr()), "clear")
+        _assert_bit_equal(d_trgb.cpu().numpy(), trgb, "clear")
+        for f in (0, 5, 10):
+            K, c2w, _, depth, rgb01 = small_frame(frame=f)
+            upd = orc.gbv_integrate(trgb, wv, R, box, K, c2w, rgb01, depth, 0.1)
+            assert upd > 1000
+            d_pose, d_rgb, d_dep = _cuda(c2w.reshape(-1), rgb01, depth)
+            L.check(lib.rfx_gbv_integrate(L.ptr(d_trgb), L.ptr(d_w), R, L.farr(L._F6, box), L.farr(L._F9, K.reshape(-1)),
+                                          L.ptr(d_pose), L.ptr(d_rgb), L.ptr(d_dep), depth.shape[0], depth.shape[1],
+                                          0.1, 1.0, L.stream_ptr()), "gbv")
+        _assert_bit_equal(d_w.cpu().numpy(), wv, "gbw")
+        _assert_bit_equal(d_trgb.cpu().numpy(), trgb, "gbv")
+        # de-integration of the last frame (obs_weight = -1) follows the same branch structure
+        orc.gbv_integrate(trgb, wv, R, box, K, c2w, rgb01, depth, 0.1, obs_weight=-1.0)
+        L.check(lib.rfx_gbv_integrate(L.ptr(d_trgb), L.ptr(d_w), R, L.farr(L._F6, box), L.farr(L._F9, K.reshape(-1)),
+                                      L.ptr(d_pose), L.ptr(d_rgb), L.ptr(d_dep), depth.shape[0], depth.shape[1],
+                                      0.1, -1.0, L.stream_ptr()), "gbv-")
+        _assert_bit_equal(d_w.cpu().numpy(), wv, "gbw-")
+        _assert_bit_equal(d_trgb.cpu().numpy(), trgb, "gbv-")
+
+
+def test_moving_volume_class_follows_camera():
+    """moving_volume through its reference-shaped API: integrate, move > t_treshold, swap."""
+    import torch
+    from oracle import tsdf as O
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.Volume import moving_volume
+
+    class T:  # the four anchor fields of model/traj.py:28-31
+        kfx = kfy = kfz = 0.0
+        first = 0
+
+    cfg = synthetic_config("office0")
+    cfg["volume"].update({"voxel_size": 0.05, "trunc": 0.15})
+    K, c2w, rgb255, depth, _ = small_frame()
+    traj = T()
+    mv = moving_volume(cfg, traj, c2w.astype(np.float64))
+    assert tuple(mv.vol_dim) == (160, 160, 120)
+    orc = O.load()
+    ot, ow, oc = _oracle_vol(mv.vol_dim)
+    mv.integrate(rgb255, depth, K, c2w, mv.vol_bnds)
+    orc.mv_integrate(ot, ow, oc, mv.vol_dim, mv.vol_origin, 0.05, K, c2w, O.pack_color(rgb255), depth, 0.15)
+    moved = c2w.copy().astype(np.float64)
+    moved[0, 3] += 1.3                                      # > t_treshold along x
+    flag, old_bnds = mv.check_move_volume_new(1, moved, traj)
+    assert flag and mv.vol_bnds[0, 0] == old_bnds[0, 0] + 1.0
+    nt, nw, nc = _oracle_vol(mv.vol_dim)
+    orc.mv_shift((nt, nw, nc), (ot, ow, oc), mv.vol_dim, mv.vol_origin, mv.vol_dim, old_bnds[:, 0].astype(np.float32), 0.05)
+    gt, gw, gc = mv.get_volume_all()
+    _assert_bit_equal(gt, nt, "mv tsdf")
+    _assert_bit_equal(gw, nw, "mv weight")
+    _assert_bit_equal(gc, nc, "mv colour")
+    res, mask = mv.tri_interpolate(np.array([[0.5, 0.2, 0.1], [100.0, 0, 0]], np.float32))
+    assert res.shape == (2, 5) and mask.all() and res[1, 0] == 1.0
+
+
+@pytest.mark.timeout(900)
+def test_integrate_full_size_800x800x600_bit_exact():
+    """BASELINE config 2 size (3.84e8 voxels @ 1 cm, 640x480): GPU vs C oracle, every voxel."""
+    import torch
+    from oracle import tsdf as O
+    dims, origin, voxel, trunc = (800, 800, 600), (-4, -5, -3), 0.01, 0.05
+    K, c2w, rgb255, depth, _ = small_frame(H=480, W=640, frame=3)
+    v = Vol(dims, origin, voxel, trunc)
+    v.integrate(K, c2w, rgb255, depth)
+    ot, ow, oc = _oracle_vol(dims)
+    u, c = O.load().mv_integrate(ot, ow, oc, dims, origin, voxel, K, c2w, O.pack_color(rgb255), depth, trunc)
+    assert u > 1e6
+    for g, r, nm in ((v.w, ow, "weight"), (v.t, ot, "tsdf"), (v.c, oc, "colour")):
+        _assert_bit_equal(g.cpu().numpy(), r, nm)
