@@ -376,7 +376,8 @@ def render_rays(fp: FieldParams, bbox: torch.Tensor, rays_o, rays_d, z_vals, cla
     """model/scene_rep.py:443-454 given z_vals: pts -> normalise (:388) -> Q1 -> R1."""
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     flat = pts.reshape(-1, 3)
-    x01 = (flat - bbox[:, 0]) / (bbox[:, 1] - bbox[:, 0])
+    # a float64 bound promotes this to float64 (scene_rep.py:388); tinycudann then casts its input to fp32
+    x01 = ((flat - bbox[:, 0]) / (bbox[:, 1] - bbox[:, 0])).to(torch.float32)
     raw = query_color_sdf(fp, x01, clamp).reshape(*pts.shape[:-1], 4)
     rgb, depth = raw2outputs(raw, z_vals, fp.trunc, sc_factor)
     return {"rgb_res_map": rgb, "depth_res_map": depth, "z_vals": z_vals, "raw": raw}

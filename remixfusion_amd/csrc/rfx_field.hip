@@ -521,6 +521,7 @@ extern "C" {
 
 int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n, float* feat,
                             rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     if (!g || !table || !x01 || !feat || n < 0) return RFX_ERR_ARG;
     if (g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_ARG;
     if (g->n_feat != 1 && g->n_feat != 2 && g->n_feat != 4) return RFX_ERR_UNSUPPORTED;
@@ -533,6 +534,7 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
 
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
                              const float* dfeat, float* dtable, float* dx01, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     if (!g || !table || !x01 || !dfeat || n < 0) return RFX_ERR_ARG;
     if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
     if (n == 0 || (!dtable && !dx01)) return RFX_OK;
@@ -543,6 +545,7 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
 }
 
 int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, float* out, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     if (!x01 || !out || n < 0) return RFX_ERR_ARG;
     if (n_bins != 16) return RFX_ERR_UNSUPPORTED;     // pos.n_bins = 16 in every reference config
     if (n == 0) return RFX_OK;
@@ -553,6 +556,7 @@ int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, f
 }
 
 int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
@@ -564,6 +568,7 @@ int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, floa
 }
 
 int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
@@ -576,6 +581,7 @@ int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, fl
 }
 
 int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, float* rgb3, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
@@ -595,6 +601,7 @@ size_t rfx_field_backward_workspace_bytes(int64_t n) {
 int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                        float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
                        void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;

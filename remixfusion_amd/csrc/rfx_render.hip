@@ -315,6 +315,7 @@ extern "C" {
 
 int rfx_sample_z(const rfx_sampler_desc* s, const float* target_d, const float* u01, int64_t n_rays, float* z_vals,
                  rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
     SamplerK k;
     int rc = make_sampler(s, &k);
     if (rc) return rc;
@@ -327,6 +328,7 @@ int rfx_sample_z(const rfx_sampler_desc* s, const float* target_d, const float* 
 
 int rfx_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays, int S,
                    const double bbox[6], int bbox_f64, float* x01, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
     if (!rays_o || !rays_d || !z_vals || !bbox || !x01 || n_rays < 0 || S <= 0) return RFX_ERR_ARG;
     if (n_rays == 0) return RFX_OK;
     const int64_t n = n_rays * S;
@@ -338,6 +340,7 @@ int rfx_ray_points(const float* rays_o, const float* rays_d, const float* z_vals
 
 int rfx_composite_forward(const float* raw4, const float* z_vals, int64_t n_rays, int S, float trunc, float sc_factor,
                           float* rgb, float* depth, float* weights, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
     if (!raw4 || !z_vals || !rgb || !depth || n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
     if (n_rays == 0) return RFX_OK;
@@ -349,6 +352,7 @@ int rfx_composite_forward(const float* raw4, const float* z_vals, int64_t n_rays
 
 int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_rays, int S, float trunc, float sc_factor,
                            const float* d_rgb, const float* d_depth, float* d_raw4, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
     if (!raw4 || !z_vals || !d_rgb || !d_depth || !d_raw4 || n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
     if (n_rays == 0) return RFX_OK;
@@ -362,6 +366,7 @@ int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_ray
 int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const float* rays_o, const float* rays_d,
                     const float* target_d, const float* u01, int64_t n_rays, const double bbox[6], int bbox_f64,
                     float sc_factor, float* rgb, float* depth, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
     FieldK fk;
     int rc = make_fieldk(f, &fk);
     if (rc) return rc;
