@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- RGB-D frames/s of the mapping hot path on synthetic 640x480 streams (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A *step* is one RGB-D frame of the stream through the mapping path: TSDF integrate into the
+moving 1 cm volume every frame, and -- whenever the reference's mapper would wake (every
+map_every = 5 frames) -- keyframe integration into the global volume plus iters (5) map and
+BA_iters (5) pose optimisation steps of the residual field (forward, backward, Adam), exactly
+the reference schedule.  All frames are rendered and resident in HBM before the timed region.
+Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @ 1 cm, GT poses).
+At N>1 every rank maps its own spatial partition of an N-times larger scene (weak scaling) and
+exchanges the boundary planes of the global volume with its neighbours over RCCL.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on
+the launch stream) and `cpu_baseline` (the C / torch CPU oracle timed on this host's cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak
+MLP_FLOP_PER_POINT = 2 * (81 * 32 + 32 * 16 + 66 * 32 + 32 * 3)     # 10 624
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="office0")
+    ap.add_argument("--first-iters", type=int, default=None, help="override mapping.first_iters (default: config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--render-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of individual librfx calls on torch's current stream (= the launch stream)."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    def wrap(self, lib, name):
+        fn = getattr(lib, name)
+        timer = self
+
+        def timed(*a):
+            if not timer.enabled:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            timer.records.setdefault(name, []).append((e0, e1, a))
+            return rc
+
+        setattr(lib, name, timed)
+
+    def summary(self):
+        out = {}
+        for name, evs in self.records.items():
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+            out[name] = (len(ms), float(np.mean(ms)), evs)
+        return out
+
+
+def cpu_baseline(cfg, frame, model_points: int):
+    """Oracle timed on the host: TSDF integrate of one full frame into the full-size volume (C,
+    1 thread) + one optimisation iteration of the field on a point sample (torch CPU, all cores),
+    scaled to the per-frame schedule.  A reported baseline, not a target."""
+    from oracle import field_oracle as FO
+    from oracle import tsdf as OT
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    # --- V1 on the full-size volume (single-thread C)
+    vol = cfg["volume"]
+    dims = tuple(int(round(2 * vol[k]["len"] / vol["voxel_size"])) for k in ("x_config", "y_config", "z_config"))
+    n = int(np.prod(dims))
+    c2w = frame["c2w"].cpu().numpy()
+    center = np.round(c2w[:3, 3])
+    origin = center - np.array([vol["x_config"]["len"], vol["y_config"]["len"], vol["z_config"]["len"]])
+    t, w, c = np.ones(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    cam = cfg["cam"]
+    K = np.array([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], np.float32)
+    cpk = OT.pack_color(frame["rgb255"].cpu().numpy())
+    depth = frame["depth"].cpu().numpy()
+    t0 = time.time()
+    upd, col = OT.load().mv_integrate(t, w, c, dims, origin.astype(np.float32), vol["voxel_size"], K, c2w, cpk, depth, vol["trunc"])
+    t_v1 = time.time() - t0
+    del t, w, c
+    # --- one field iteration (forward + backward) on a sample of the points, torch CPU
+    S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
+    n_pts_iter = model_points
+    sample = 4096
+    meta = FO.hashgrid_meta_from_config(cfg["grid"]["hash_size"], int(max(b[1] - b[0] for b in cfg["mapping"]["bound"]) / cfg["grid"]["voxel_sdf"]))
+    g = torch.Generator().manual_seed(0)
+    R = cfg["globalV"]["base_resolution"]
+    fp = FO.FieldParams(hash_meta=meta, hash_table=(torch.rand(meta.n_params, generator=g) * 2e-4 - 1e-4).requires_grad_(True),
+                        gbv=torch.rand(R ** 3 * 4, generator=g), gbw=torch.rand(R ** 3, generator=g), gbv_res=R,
+                        W1=(torch.randn(32, 81, generator=g) * 0.1).requires_grad_(True),
+                        W2=(torch.randn(16, 32, generator=g) * 0.1).requires_grad_(True),
+                        W3=(torch.randn(32, 66, generator=g) * 0.1).requires_grad_(True),
+                        W4=(torch.randn(3, 32, generator=g) * 0.1).requires_grad_(True),
+                        c_trunc=cfg["training"]["c_trunc"], trunc=cfg["training"]["trunc"])
+    x = torch.rand((sample, 3), generator=g)
+    t0 = time.time()
+    reps = 3
+    for _ in range(reps):
+        raw = FO.query_color_sdf(fp, x)
+        raw.square().sum().backward()
+    t_iter_sample = (time.time() - t0) / reps
+    t_iter = t_iter_sample * n_pts_iter / sample
+    m = cfg["mapping"]
+    iters_per_frame = (m["iters"] + m["BA_iters"]) / m["map_every"]
+    t_frame = t_v1 + iters_per_frame * t_iter
+    return {"value": round(1.0 / t_frame, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"C oracle mv_integrate of 1 frame into {dims[0]}x{dims[1]}x{dims[2]} voxels on 1 core ({t_v1:.2f} s, "
+                      f"{upd} voxels updated) + torch-CPU oracle field fwd+bwd on {sample} of {n_pts_iter} points/iter "
+                      f"on {cores} cores ({t_iter_sample:.2f} s, scaled), {iters_per_frame:g} iters/frame",
+            "v1_seconds": round(t_v1, 3), "field_iter_seconds_scaled": round(t_iter, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        dist = dist_mod
+
+    from remixfusion_amd import _lib
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.dist import make_shard
+    from remixfusion_amd.pipeline import MappingPipeline
+
+    lib = _lib.load()
+    timer = KernelTimer()
+    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward", "rfx_render_rays", "rfx_gbv_integrate",
+                 "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward", "rfx_composite_backward"):
+        timer.wrap(lib, name)
+
+    cfg = synthetic_config(args.config)
+    if args.first_iters is not None:
+        cfg["mapping"]["first_iters"] = args.first_iters
+    n_frames = 1 + args.warmup + args.steps
+    shard = make_shard(cfg, rank, world, dist) if world > 1 else None
+    if shard is not None:
+        cfg = shard.config
+    pipe = MappingPipeline(cfg, device=device, n_frames=n_frames + 8, seed=rank, shard=shard)
+    frames = pipe.prefetch(list(range(n_frames)))
+    pipe.start(frames[0])
+    for i in range(1, 1 + args.warmup):
+        pipe.step(i, frames[i])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(1 + args.warmup, n_frames):
+        pipe.step(i, frames[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- rays/s of the fused full-frame renderer (second headline number)
+    render = None
+    if pipe.model is not None and args.render_frames > 0:
+        pipe.model.train()
+        b = frames[n_frames - 1]
+        ray_d = b["direction"].reshape(-1, 3).to(device)
+        c2w = b["c2w"].to(device)
+        rays_d = torch.sum(ray_d.unsqueeze(1) * c2w[None, :3, :3], -1).reshape(-1, 3).contiguous()
+        rays_o = c2w[:3, -1].repeat(rays_d.shape[0], 1).contiguous()
+        td = b["depth"].reshape(-1, 1).to(device)
+        pipe.model.render_fused(rays_o, rays_d, td)
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for _ in range(args.render_frames):
+            pipe.model.render_fused(rays_o, rays_d, td)
+        torch.cuda.synchronize()
+        render = rays_d.shape[0] * args.render_frames / (time.perf_counter() - t1)
+        timer.enabled = False
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (by summed device time over the timed region)
+    summ = timer.summary()
+    cam, tr = cfg["cam"], cfg["training"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    per_kernel = {k: {"calls": c, "avg_ms": round(ms, 4)} for k, (c, ms, _) in summ.items()}
+    step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
+    dominant = max(step_kernels, key=lambda k: step_kernels[k][0] * step_kernels[k][1]) if step_kernels else None
+    roofline = None
+    extra_rooflines = {}
+
+    def mfma_roofline(name, flop_per_point, point_arg_index):
+        cnt, ms, evs = summ[name]
+        pts = float(np.mean([e[2][point_arg_index] for e in evs]))
+        ach = flop_per_point * pts / (ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "points_per_launch": int(pts),
+                "avg_ms": round(ms, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+
+    if "rfx_field_forward" in summ:
+        extra_rooflines["field_forward"] = mfma_roofline("rfx_field_forward", MLP_FLOP_PER_POINT, 2)
+    if "rfx_field_backward" in summ:
+        extra_rooflines["field_backward"] = mfma_roofline("rfx_field_backward", 2 * MLP_FLOP_PER_POINT, 2)
+    if "rfx_render_rays" in summ:
+        cnt, ms, evs = summ["rfx_render_rays"]
+        pts = float(evs[0][2][6]) * S
+        ach = MLP_FLOP_PER_POINT * pts / (ms * 1e-3) / 1e12
+        extra_rooflines["render_rays"] = {"kernel": "rfx_render_rays", "bound": "mfma", "achieved": round(ach, 3),
+                                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                          "points_per_launch": int(pts), "avg_ms": round(ms, 4)}
+    if "rfx_tsdf_integrate" in summ:
+        # algorithmic bytes: 16 U + 8 C + 8 H W; U, C counted by the CPU oracle on one timed frame
+        cnt, ms, _ = summ["rfx_tsdf_integrate"]
+        uc = None
+        if not args.no_cpu_baseline:
+            try:
+                from oracle import tsdf as OT
+                mv = pipe.mv
+                f = frames[n_frames - 1]
+                n = int(np.prod(mv.vol_dim))
+                tt, ww, cc = np.ones(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+                uc = OT.load().mv_integrate(tt, ww, cc, mv.vol_dim, mv.vol_origin, mv.voxel_size, pipe.K,
+                                            f["c2w"].cpu().numpy(), OT.pack_color(f["rgb255"].cpu().numpy()),
+                                            f["depth"].cpu().numpy(), mv.trunc_margin)
+                del tt, ww, cc
+            except Exception as e:   # the oracle is optional at bench time
+                uc = None
+                print(f"[bench] oracle voxel count unavailable: {e}", file=sys.stderr)
+        if uc is not None:
+            nbytes = 16 * uc[0] + 8 * uc[1] + 8 * cam["H"] * cam["W"]
+            ach = nbytes / (ms * 1e-3) / 1e9
+            extra_rooflines["tsdf_integrate"] = {"kernel": "rfx_tsdf_integrate (prepass + integrate)", "bound": "hbm",
+                                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                                 "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
+                                                 "algorithmic_bytes": int(nbytes), "avg_ms": round(ms, 4)}
+    key = {"rfx_field_forward": "field_forward", "rfx_field_backward": "field_backward",
+           "rfx_tsdf_integrate": "tsdf_integrate"}.get(dominant)
+    roofline = extra_rooflines.get(key) if key else None
+    if roofline is None and extra_rooflines:
+        roofline = next(iter(extra_rooflines.values()))
+
+    base = None
+    if not args.no_cpu_baseline:
+        m = cfg["mapping"]
+        n_rays = m["sample"] + max(m["sample"] // 8, m["min_pixels_cur"])
+        tv_pts = (tr["smooth_pts"] - 1) ** 3
+        base = cpu_baseline(cfg, frames[n_frames - 1], n_rays * S + tv_pts)
+
+    fps = args.steps * world / elapsed
+    out = {
+        "metric": "RGB-D frames/sec mapping (640x480, 1cm TSDF)", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume "
+                               f"{'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
+                               f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
+                               f"{cfg['mapping']['iters']}+{cfg['mapping']['BA_iters']} iters every {cfg['mapping']['map_every']} frames, GT poses",
+                   "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},
+        "render_rays_per_s": round(render, 1) if render else None,
+        "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,
+        "cpu_baseline": base,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

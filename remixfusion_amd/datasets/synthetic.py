@@ -56,6 +56,7 @@ class SyntheticRoom:
         self.num_rays_to_save = int(self.total_pixels * cfg["mapping"]["n_pixels"])
         self.rays_d = get_camera_rays(self.H, self.W, self.fx, self.fy, self.cx, self.cy, device=self.device)
         self.frame_ids = list(range(self.num_frames))
+        self._cache = {}
         self.poses = [self._pose(i) for i in range(self.num_frames)]
         lo, hi = self.room[:, 0], self.room[:, 1]
         ext = hi - lo
@@ -120,7 +121,18 @@ class SyntheticRoom:
         rgb = torch.where((kind > 0)[:, None], sph, wall).clamp(0, 1)
         return rgb.reshape(self.H, self.W, 3), t_hit.reshape(self.H, self.W)
 
+    def prefetch(self, ids):
+        """render frames once and keep them resident on ``device`` (HBM) for later __getitem__ calls."""
+        for i in ids:
+            if i not in self._cache:
+                self._cache[i] = self._make(i)
+
     def __getitem__(self, index: int):
+        if index in self._cache:
+            return dict(self._cache[index])
+        return self._make(index)
+
+    def _make(self, index: int):
         c2w = self.poses[index]
         rgb, depth = self._render(c2w)
         n = self.total_pixels

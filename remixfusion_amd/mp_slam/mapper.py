@@ -1,0 +1,230 @@
+"""Mapper: keyframe integration into the global volume + the map / pose optimisation schedule.
+
+Host-side mirror of the reference ``mp_slam/mapper.py:191-950`` (same class, method names,
+argument meaning).  The two module-level PyCUDA kernels (:36-188) are replaced by
+``rfx_gbv_integrate`` / ``rfx_gbv_clear``; everything the schedule calls on the model is a librfx
+kernel.  ``step()`` is the body of the reference's ``run()`` loop (:884-906) so a single process
+can drive it; ``run()`` keeps the polling form for a separate tracker thread.
+Evaluation / mesh helpers (``calc_2d_metric*``, ``post_process_mesh``, :626-821) are out of scope.
+"""
+from __future__ import annotations
+
+import random
+import time
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import _F6, _F9, check, farr, ptr, stream_ptr
+
+
+class Mapper:
+    def __init__(self, config, SLAM, model) -> None:
+        self.config, self.slam, self.model = config, SLAM, model
+        self.tracking_idx, self.mapping_idx = SLAM.tracking_idx, SLAM.mapping_idx
+        self.mapping_first_frame, self.tracking_stop_flag = SLAM.mapping_first_frame, SLAM.tracking_stop_flag
+        self.keyframe = SLAM.keyframeDatabase
+        self.map_optimizer, self.rba_optimizer = SLAM.map_optimizer, SLAM.rba_optimizer
+        self.device, self.dataset = SLAM.device, SLAM.dataset
+        self.est_c2w_data, self.RO_c2w_data, self.est_c2w_data_rel = SLAM.est_c2w_data, SLAM.RO_c2w_data, SLAM.est_c2w_data_rel
+        self.update_local_MV = SLAM.update_local_MV
+        self.first_BA = True
+        self.shard = None     # set by MappingPipeline when the scene is partitioned across GPUs
+        self.create_global_volume(config["globalV"]["base_resolution"])
+
+    def create_global_volume(self, base_resolution):
+        """reference :213-255."""
+        self.vol_dim = np.array([base_resolution] * 3)
+        self.map_box = self.config["mapping"]["bound"]
+        self.voxel_size = 1.0 / base_resolution
+        self.vol_origin = np.array([b[0] for b in self.map_box])
+        self.box_length = np.array([b[1] - b[0] for b in self.map_box])
+        d = self.dataset
+        self.K = np.array([[d.fx, 0, d.cx], [0, d.fy, d.cy], [0, 0, 1]])
+        self.trunc_margin = self.config["training"]["c_trunc"]
+
+    def save_ckpt(self, save_path):
+        torch.save({"pose": self.est_c2w_data, "pose_rel": self.est_c2w_data_rel, "model": self.model.state_dict()}, save_path)
+
+    # ---- GBV kernels --------------------------------------------------------------------
+    def init_mapvolume(self):
+        """GBV <- (1,0,0,0) (reference :267-282)."""
+        check(_lib.load().rfx_gbv_clear(ptr(self.model.GBV.params), int(np.prod(self.vol_dim)), stream_ptr(self.device)),
+              "rfx_gbv_clear")
+
+    def integrate_kf(self, batch, pose, obs_weight=1.0):
+        """fuse one RGB-D keyframe into GBV/GBW (reference :823-872)."""
+        color_im = batch["rgb"].squeeze().to(self.device).float().contiguous()
+        depth_im = batch["depth"].squeeze().to(self.device).float().contiguous()
+        im_h, im_w = depth_im.shape
+        pose_dev = pose.to(self.device).float().reshape(-1).contiguous()
+        box = [v for b in self.map_box for v in b]
+        check(_lib.load().rfx_gbv_integrate(ptr(self.model.GBV.params), ptr(self.model.GBW.params), int(self.vol_dim[0]),
+                                            farr(_F6, box), farr(_F9, self.K.reshape(-1)), ptr(pose_dev), ptr(color_im),
+                                            ptr(depth_im), im_h, im_w, float(self.trunc_margin), float(obs_weight),
+                                            stream_ptr(self.device)), "rfx_gbv_integrate")
+        if self.shard is not None:
+            self.shard.exchange_halo(self.model.GBV.params, self.model.GBW.params, int(self.vol_dim[0]))
+
+    def update_GBV(self, cur_id):
+        """reset and re-integrate every keyframe with its current pose (reference :523-534)."""
+        with torch.no_grad():
+            self.model.GBV.params[:] = 0.0
+            self.init_mapvolume()
+            self.model.GBW.params[:] = 0.0
+        for i in range(0, cur_id, self.config["mapping"]["keyframe_every"]):
+            self.integrate_kf(self.dataset[i], self.est_c2w_data[i])
+
+    # ---- schedule -----------------------------------------------------------------------
+    def first_frame_mapping(self, batch, n_iters=100):
+        """reference :284-364."""
+        if batch["frame_id"] != 0:
+            raise ValueError("First frame mapping must be the first frame!")
+        c2w = batch["c2w"].to(self.device)
+        self.init_mapvolume()
+        self.integrate_kf(batch, c2w)
+        self.est_c2w_data[0] = c2w
+        self.est_c2w_data_rel[0] = c2w
+        self.model.rba.update_init_pose(0, c2w)
+        self.model.train()
+        H, W, n_s = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
+        direction, rgb, depth = (batch[k].to(self.device) for k in ("direction", "rgb", "depth"))
+        ret = loss = None
+        for _ in range(n_iters):
+            self.map_optimizer.zero_grad()
+            indice = self.slam.select_samples(H, W, n_s).to(self.device)
+            indice_h, indice_w = indice % H, indice // H        # (sic) reference :338
+            rays_d_cam = direction[indice_h, indice_w, :]
+            target_s = rgb[indice_h, indice_w, :]
+            target_d = depth[indice_h, indice_w].unsqueeze(-1)
+            rays_o = c2w[None, :3, -1].repeat(n_s, 1)
+            rays_d = torch.sum(rays_d_cam[..., None, :] * c2w[:3, :3], -1)
+            ret = self.model.mapping(rays_o, rays_d, target_s, target_d)
+            loss = self.slam.get_loss_from_ret(ret)
+            loss.backward()
+            self.map_optimizer.step()
+        self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
+        self.mapping_first_frame[0] = 1
+        return ret, loss
+
+    def _sample_rays(self, current_rays):
+        m = self.config["mapping"]
+        rays, ids = self.keyframe.sample_global_rays(m["sample"])
+        n_cur = max(m["sample"] // len(self.keyframe.frame_ids), m["min_pixels_cur"])
+        idx_cur = random.sample(range(0, self.slam.dataset.H * self.slam.dataset.W), n_cur)
+        cur = current_rays[torch.as_tensor(idx_cur, device=current_rays.device), :]
+        rays = torch.cat([rays.to(self.device), cur], dim=0)
+        ids_all = torch.cat([ids // m["keyframe_every"], -torch.ones((n_cur))]).to(torch.int64).to(self.device)
+        return rays, ids_all
+
+    @staticmethod
+    def _world_rays(rays, ids_all, poses_all):
+        rays_d_cam = rays[..., :3]
+        rays_d = torch.sum(rays_d_cam[..., None, None, :] * poses_all[ids_all, None, :3, :3], -1)
+        rays_o = poses_all[ids_all, None, :3, -1].repeat(1, rays_d.shape[1], 1).reshape(-1, 3)
+        return rays_o, rays_d.reshape(-1, 3), rays[..., 3:6], rays[..., 6:7]
+
+    def global_mapping(self, batch, cur_frame_id):
+        """map update over all keyframes + the current frame (reference :366-423)."""
+        m = self.config["mapping"]
+        poses = torch.stack([self.est_c2w_data[i] for i in range(0, cur_frame_id + 1, m["keyframe_every"])])
+        self.map_optimizer.zero_grad()
+        self.rba_optimizer.zero_grad()
+        current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+        current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
+        with torch.no_grad():
+            last_kf_id = (torch.tensor(cur_frame_id) // m["keyframe_every"]).long().unsqueeze(-1).unsqueeze(-1)
+            poses_all = poses
+            poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze().clone()
+        for i in range(m["iters"]):
+            rays, ids_all = self._sample_rays(current_rays)
+            rays_o, rays_d, target_s, target_d = self._world_rays(rays, ids_all, poses_all)
+            ret = self.model.mapping(rays_o, rays_d, target_s, target_d)
+            loss = self.slam.get_loss_from_ret(ret, smooth=True, iter=i)
+            loss.backward(retain_graph=True)
+            if (i + 1) % m["map_accum_step"] == 0:
+                if (i + 1) > m["map_wait_step"]:
+                    self.map_optimizer.step()
+                self.map_optimizer.zero_grad()
+                self.rba_optimizer.zero_grad()
+
+    def global_pose(self, batch, cur_frame_id):
+        """pose (RBA-MLP) update with the map frozen (reference :425-520)."""
+        m = self.config["mapping"]
+        poses = torch.stack([self.est_c2w_data[i] for i in range(0, cur_frame_id, m["keyframe_every"])])
+        frame_ids_all = torch.tensor(list(range(0, cur_frame_id + 1, m["keyframe_every"])))
+        self.map_optimizer.zero_grad()
+        self.rba_optimizer.zero_grad()
+        current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+        current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
+        all_index = torch.arange(0, poses.shape[0] + 1).unsqueeze(-1)
+        poses_all = self.model.rba(all_index)
+        for i in range(m["BA_iters"]):
+            rays, ids_all = self._sample_rays(current_rays)
+            rays_o, rays_d, target_s, target_d = self._world_rays(rays, ids_all, poses_all)
+            ret = self.model.mapping(rays_o, rays_d, target_s, target_d, clamp=True)
+            loss = self.slam.get_loss_from_ret(ret, fs=True, smooth=True, iter=i)
+            loss.backward(retain_graph=True)
+            if (i + 1) % m["pose_accum_step"] == 0 and m["opt_pose"]:
+                self.rba_optimizer.step()
+                poses_all = self.model.rba(torch.arange(0, poses.shape[0] + 1).unsqueeze(-1))
+                self.map_optimizer.zero_grad()
+                self.rba_optimizer.zero_grad()
+        if len(frame_ids_all) > 1 and m["opt_pose"]:
+            kfupid = torch.arange(len(frame_ids_all) - 1, device=self.device) * m["keyframe_every"]
+            if m["optim_cur"]:
+                self.est_c2w_data[cur_frame_id] = poses_all[-1:].detach().clone()[0]
+            self.est_c2w_data[kfupid] = poses_all[:-1].detach().clone()
+
+    def convert_relative_pose(self, idx=None):
+        """absolute pose per frame: keyframes as stored, others = delta @ keyframe (reference :580-624)."""
+        ke = self.config["mapping"]["keyframe_every"]
+        n = len(self.est_c2w_data) if idx is None else len(self.est_c2w_data[:idx + 1])
+        poses = {}
+        for i in range(n):
+            if i % ke == 0:
+                poses[i] = self.est_c2w_data[i]
+            else:
+                poses[i] = self.est_c2w_data_rel[i] @ self.est_c2w_data[(i // ke) * ke]
+        return poses
+
+    def convert_relative_pose_npy(self, idx=None):
+        """reference :536-577."""
+        d = self.convert_relative_pose(idx)
+        poses = torch.zeros((len(self.dataset), 4, 4), device=self.device)
+        for i, p in d.items():
+            poses[i] = p
+        return poses.detach().cpu().numpy()
+
+    def step(self, current_map_id: int):
+        """one pass of the reference's mapping loop body (:884-906) for frame ``current_map_id``."""
+        ke = self.config["mapping"]["keyframe_every"]
+        if self.first_BA:
+            self.model = self.model.to(self.device)
+            self.first_BA = False
+        batch = self.dataset[current_map_id]
+        batch = {k: (v[None, ...] if isinstance(v, torch.Tensor) else torch.tensor([v])) for k, v in batch.items()}
+        if int(self.mapping_idx[0]) % ke == 0:
+            self.model.rba.update_init_pose(int(current_map_id // ke), self.est_c2w_data[current_map_id])
+            self.integrate_kf(batch, self.est_c2w_data[current_map_id])
+        self.global_mapping(batch, current_map_id)
+        self.global_pose(batch, current_map_id)
+        self.mapping_idx[0] = current_map_id
+        if int(self.mapping_idx[0]) % ke == 0:
+            self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
+
+    def run(self):
+        """polling form of the loop (reference :874-906), for a tracker running in another thread."""
+        m = self.config["mapping"]
+        while self.tracking_idx[0] < len(self.dataset) - 1:
+            while self.tracking_idx[0] <= self.mapping_idx[0] + m["map_every"] and self.tracking_stop_flag[0] == 0:
+                time.sleep(0.01)
+            current_map_id = int(self.mapping_idx[0] + m["keyframe_every"])
+            if current_map_id < len(self.dataset):
+                self.step(current_map_id)
+            if self.tracking_stop_flag[0] != 0:
+                break
+        if m["save_ckpt"]:
+            import os
+            self.save_ckpt(os.path.join(self.config["data"]["output"], self.config["data"]["exp_name"], "checkpoint.pt"))

@@ -1,0 +1,164 @@
+"""SLAM: shared pose tensors, optimizers, loss weighting and the TV smoothness term -- the caller
+contract the Mapper reads (reference mp_slam/slam.py:23-286).  Orchestration only; mesh export,
+pose evaluation and image dumps of the reference (:288-527, open3d / trimesh / matplotlib) are
+out of scope."""
+from __future__ import annotations
+
+import os
+import random
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ..model.keyframe import KeyFrameDatabase
+
+
+class SLAM:
+    def __init__(self, config, dataset, model, device):
+        self.config, self.device, self.dataset, self.model = config, device, dataset, model
+        self.create_bounds()
+        self.create_share_data()
+        self.keyframeDatabase = self.create_kf_database(config)
+        self.create_optimizer()
+        self.vis_dir = os.path.join(config["data"]["output"], config["data"]["exp_name"])
+        self._tv_coords = {}
+
+    # ---- shared state (reference :48-54, :80-90).  One process here, so plain device tensors.
+    def create_share_data(self):
+        self.create_pose_data()
+        self.mapping_first_frame = torch.zeros((1)).int()
+        self.mapping_idx = torch.zeros((1))
+        self.tracking_idx = torch.zeros((1))
+        self.tracking_stop_flag = torch.zeros((1)).int()
+        self.update_local_MV = torch.zeros((1))
+
+    def seed_everything(self, seed):
+        random.seed(seed)
+        os.environ["PYTHONHASHSEED"] = str(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(seed)
+
+    def create_pose_data(self):
+        n = self.dataset.num_frames
+        self.est_c2w_data = torch.zeros((n, 4, 4), device=self.device)
+        self.est_c2w_data_rel = torch.zeros((n, 4, 4), device=self.device)
+        self.RO_c2w_data = torch.zeros((n, 4, 4), device=self.device)
+        self.load_gt_pose()
+
+    def create_bounds(self):
+        self.bounding_box = torch.from_numpy(np.array(self.config["mapping"]["bound"])).to(self.device)
+        self.marching_cube_bound = torch.from_numpy(np.array(self.config["mapping"]["marching_cubes_bound"])).to(self.device)
+
+    def create_kf_database(self, config):
+        num_kf = int(self.dataset.num_frames // config["mapping"]["keyframe_every"] + 1)
+        return KeyFrameDatabase(config, self.dataset.H, self.dataset.W, num_kf, self.dataset.num_rays_to_save,
+                                self.device, len(self.dataset))
+
+    def load_gt_pose(self):
+        self.pose_gt = torch.zeros((self.dataset.num_frames, 4, 4))
+        for i, pose in enumerate(self.dataset.poses):
+            self.pose_gt[i] = pose
+
+    def save_state_dict(self, save_path):
+        torch.save(self.model.state_dict(), save_path)
+
+    def load(self, load_path):
+        self.model.load_state_dict(torch.load(load_path))
+
+    def load_ckpt(self, load_path):
+        """checkpoint layout of Mapper.save_ckpt (reference :128-135)."""
+        d = torch.load(load_path)
+        self.model.load_state_dict(d["model"])
+        self.est_c2w_data = d["pose"]
+        self.est_c2w_data_rel = d["pose_rel"]
+
+    # ---- sampling / losses
+    def select_samples(self, H, W, samples):
+        return torch.tensor(random.sample(range(H * W), int(samples)))
+
+    def get_loss_from_ret(self, ret, rgb=True, sdf=True, depth=True, fs=True, smooth=False, tracking=False, iter=0):
+        """weighted sum of the four mapping losses (+ smooth_weight * TV) (reference :145-190)."""
+        tr = self.config["training"]
+        loss = 0
+        if rgb:
+            loss += tr["rgb_weight"] * ret["rgb_res_loss"]
+        if depth:
+            loss += tr["depth_weight"] * ret["depth_res_loss"]
+        if sdf:
+            loss += tr["sdf_weight"] * ret["sdf_res_loss"]
+        if fs:
+            loss += tr["fs_weight"] * ret["fs_res_loss"]
+        if smooth and tr["smooth_weight"] > 0:
+            loss += tr["smooth_weight"] * self.smoothness(tr["smooth_pts"], tr["smooth_vox"], margin=tr["smooth_margin"])
+        return loss
+
+    def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05, color=False):
+        """Total variation of the raw hash features on a randomly placed lattice (reference :193-217).
+        The integer lattice is cached on the device instead of being rebuilt on the CPU every call."""
+        bb = self.bounding_box
+        volume = bb[:, 1] - bb[:, 0]
+        grid_size = (sample_points - 1) * voxel_size
+        offset_max = bb[:, 1] - bb[:, 0] - grid_size - 2 * margin
+        offset = torch.rand(3).to(offset_max) * offset_max + margin
+        P = sample_points - 1
+        if P not in self._tv_coords:
+            ar = torch.arange(0, P, dtype=torch.long, device=self.device)
+            self._tv_coords[P] = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).float()
+        coords = self._tv_coords[P].to(volume)
+        pts = (coords + torch.rand((1, 1, 1, 3)).to(volume)) * voxel_size + bb[:, 0] + offset
+        pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0]) if self.config["grid"]["tcnn_encoding"] else pts
+        sdf_res = self.model.query_sdf_res(pts_tcnn, embed=True)
+        tv_x = torch.pow(sdf_res[1:, ...] - sdf_res[:-1, ...], 2).sum()
+        tv_y = torch.pow(sdf_res[:, 1:, ...] - sdf_res[:, :-1, ...], 2).sum()
+        tv_z = torch.pow(sdf_res[:, :, 1:, ...] - sdf_res[:, :, :-1, ...], 2).sum()
+        return (tv_x + tv_y + tv_z) / (sample_points ** 3)
+
+    def get_rays_from_batch(self, batch, c2w_est, indices):
+        """reference :219-247."""
+        rays_d_cam = batch["direction"].reshape(-1, 3)[indices].to(self.device)
+        target_s = batch["rgb"].reshape(-1, 3)[indices].to(self.device)
+        target_d = batch["depth"].reshape(-1, 1)[indices].to(self.device)
+        rays_d = torch.sum(rays_d_cam[..., None, :] * c2w_est[:3, :3], -1)
+        rays_o = c2w_est[None, :3, -1].repeat(rays_d.shape[0], 1)
+        return rays_o, rays_d, target_s, target_d, batch["c2w"][0].to(self.device)
+
+    def convert_relative_pose(self):
+        """reference :258-269."""
+        ke = self.config["mapping"]["keyframe_every"]
+        poses = {}
+        for i in range(len(self.est_c2w_data)):
+            if i % ke == 0:
+                poses[i] = self.est_c2w_data[i]
+            else:
+                poses[i] = self.est_c2w_data_rel[i] @ self.est_c2w_data[(i // ke) * ke]
+        return poses
+
+    def create_optimizer(self):
+        """two Adams: map (decoder wd 1e-6, hash eps 1e-15) and pose MLP (reference :271-286)."""
+        m = self.config["mapping"]
+        trainable = [
+            {"params": self.model.decoder_res.parameters(), "weight_decay": 1e-6, "lr": m["lr_decoder"]},
+            {"params": self.model.embed_res_fn.parameters(), "eps": 1e-15, "lr": m["lr_embed_res"]},
+        ]
+        rba = [{"params": self.model.rba.parameters(), "weight_decay": 1e-6, "eps": 1e-15, "lr": m["lr_pose"]}]
+        self.map_optimizer = optim.Adam(trainable, betas=(0.9, 0.99))
+        self.rba_optimizer = optim.Adam(rba, betas=(0.9, 0.99))
+
+    @torch.no_grad()
+    def render_single(self, frame_id, gt_depth, gt_color, cam_pose, ray_d, prefix=None, gap=1):
+        """Full-frame rgb/depth prediction (reference :288-344) through the fused renderer."""
+        gt_color = gt_color.squeeze(0)[::gap, ::gap, :]
+        gt_depth = gt_depth.squeeze(0)[::gap, ::gap]
+        ray_d = ray_d.squeeze()[::gap, ::gap, ...].to(self.device)
+        c2w = cam_pose.squeeze().detach().to(self.device) if isinstance(cam_pose, torch.Tensor) \
+            else torch.from_numpy(cam_pose).to(self.device)
+        target_d = gt_depth.reshape(-1, 1).to(self.device)
+        rays_d = torch.sum(ray_d.reshape(-1, 3).unsqueeze(1) * c2w[None, :3, :3], -1).reshape(-1, 3)
+        rays_o = c2w[:3, -1].repeat(rays_d.shape[0], 1)
+        rgb, depth = self.model.render_fused(rays_o, rays_d, target_d)
+        h, w = gt_depth.shape[0], gt_depth.shape[1]
+        return rgb.reshape(h, w, 3), depth.reshape(h, w)

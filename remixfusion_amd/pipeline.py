@@ -1,0 +1,94 @@
+"""MappingPipeline: single-process driver of the mapping hot path on one GPU (or one volume shard
+per rank): per frame the moving TSDF volume integrates the RGB-D image (V1); every ``map_every``
+frames the Mapper integrates the keyframe into the global volume (G1) and runs ``iters`` map +
+``BA_iters`` pose optimisation steps of the residual field.  Plays the role of run.py's
+RemixFusion + the tracker's post_processing with ground-truth poses (BASELINE config 2:
+"GT poses, tracker off")."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .datasets import get_dataset
+from .model.scene_rep import JointEncoding
+from .model.traj import Trajectory
+from .model.Volume import moving_volume
+from .mp_slam.mapper import Mapper
+from .mp_slam.slam import SLAM
+
+
+class MappingPipeline:
+    def __init__(self, config: Dict, device: str = "cuda:0", n_frames: Optional[int] = None, seed: int = 0,
+                 shard=None):
+        self.config, self.device = config, torch.device(device)
+        self.dataset = get_dataset(config, device=device, n_frames=n_frames)
+        self.tsdf_only = bool(config["synthetic"].get("tsdf_only", False))
+        self.traj = Trajectory()
+        self.K = self.dataset.K()
+        pose0 = self.dataset.poses[0].numpy().astype(np.float64)
+        self.mv = moving_volume(config, self.traj, pose0, device=self.device) if shard is None \
+            else shard.make_volume(config, self.traj, pose0, self.device)
+        self.shard = shard
+        self.slam = self.mapper = self.model = None
+        if not self.tsdf_only:
+            bb = torch.from_numpy(np.array(config["mapping"]["bound"])).to(self.device)
+            num_kf = int(self.dataset.num_frames // config["mapping"]["keyframe_every"] + 1)
+            self.model = JointEncoding(config, bb, num_kf).to(self.device)
+            with torch.no_grad():
+                for name, p in self.model.named_parameters():
+                    if "rba" in name:
+                        torch.nn.init.normal_(p, mean=0, std=0.0001)     # run.py:39-42
+            self.slam = SLAM(config, self.dataset, self.model, self.device)
+            self.slam.seed_everything(seed)
+            self.mapper = Mapper(config, self.slam, self.model)
+            self.mapper.shard = shard
+        self.frames_done = 0
+
+    # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
+    def prefetch(self, ids: List[int]) -> Dict[int, Dict]:
+        self.dataset.prefetch(ids)
+        out = {}
+        for i in ids:
+            b = self.dataset[i]
+            b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
+            out[i] = b
+        return out
+
+    def start(self, batch0: Dict, first_iters: Optional[int] = None):
+        """frame 0: MV integrate + first-frame mapping (run.py:57-60 / ROtracker.py:132)."""
+        self.track_frame(0, batch0)
+        if self.mapper is not None:
+            n = self.config["mapping"]["first_iters"] if first_iters is None else first_iters
+            self.mapper.first_frame_mapping({k: v for k, v in batch0.items() if k != "rgb255"}, n)
+
+    def track_frame(self, i: int, batch: Dict):
+        """tracker side with GT pose: follow the camera with the volume, then integrate
+        (ROtracker.post_processing, model/ROtracker.py:911-945)."""
+        c2w = batch["c2w"]
+        pose_np = c2w.numpy().astype(np.float64) if not c2w.is_cuda else c2w.cpu().numpy().astype(np.float64)
+        if i > 0:
+            self.mv.check_move_volume_new(i, pose_np, self.traj, version=self.config["volume"]["version"])
+        rgb255 = batch.get("rgb255")
+        if rgb255 is None:
+            rgb255 = torch.floor(batch["rgb"] * 255.0 + 0.5)
+        self.mv.integrate(rgb255, batch["depth"], self.K, pose_np, self.mv.vol_bnds)
+        if self.slam is not None:
+            self.slam.est_c2w_data[i] = c2w.to(self.device)
+            ke = self.config["mapping"]["keyframe_every"]
+            if i % ke != 0:     # relative pose to the last keyframe, like the tracker stores it
+                kf = self.slam.est_c2w_data[(i // ke) * ke]
+                self.slam.est_c2w_data_rel[i] = c2w.to(self.device) @ torch.linalg.inv(kf)
+            self.slam.tracking_idx[0] = i
+
+    def step(self, i: int, batch: Dict):
+        """one frame of the stream: V1 always; mapper step when the reference's loop would fire."""
+        self.track_frame(i, batch)
+        if self.mapper is not None:
+            m = self.config["mapping"]
+            cur = int(self.slam.mapping_idx[0] + m["keyframe_every"])
+            # the reference's mapper wakes when tracking_idx > mapping_idx + map_every (mapper.py:879)
+            if i > int(self.slam.mapping_idx[0]) + m["map_every"] and cur < len(self.dataset):
+                self.mapper.step(cur)
+        self.frames_done += 1
