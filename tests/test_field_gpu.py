@@ -287,3 +287,39 @@ def test_mapping_losses_and_total_gradient_match_oracle():
     m.eval()
     out = m.mapping(o.cuda(), d.cuda(), tgt.cuda(), td.cuda())
     assert set(out) == {"rgb_res_map", "depth_res_map", "z_vals", "raw"}
+
+
+@pytest.mark.parametrize("name", ["office0", "scene0000"])
+def test_product_mapping_matches_reference_golden(name):
+    """the HIP path against vectors produced by the reference's own JointEncoding.mapping()
+    (tests/golden/mapping_*.npz, perturb=0): z_vals, raw, rgb/depth maps and the four losses."""
+    import os
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.scene_rep import JointEncoding
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"mapping_{name}.npz"))
+    cfg = synthetic_config(name)
+    cfg["training"]["perturb"] = 0
+    cfg["globalV"]["base_resolution"] = int(g["gbv_res"])
+    cfg["grid"]["hash_size"] = int(g["hash_T"])
+    cfg["grid"]["voxel_sdf"] = int(g["hash_R"])           # > 10: taken as the resolution itself (scene_rep.py:29-30)
+    m = JointEncoding(cfg, torch.from_numpy(np.array(cfg["mapping"]["bound"])), num_kf=4).cuda()
+    with torch.no_grad():
+        m.embed_res_fn.params.copy_(torch.from_numpy(g["table"]).cuda())
+        m.GBV.params.copy_(torch.from_numpy(g["gbv"]).cuda())
+        for p, k in zip(m.decoder_res.fused_weights(), ("W1", "W2", "W3", "W4")):
+            p.copy_(torch.from_numpy(g[k]).cuda())
+    o, d, td, tgt = (torch.from_numpy(g[k]).cuda() for k in ("o", "d", "td", "tgt"))
+    for clamp, tag in ((False, "c0"), (True, "c1")):
+        m.eval()
+        rend = m.mapping(o, d, tgt, td, clamp=clamp)
+        _close(rend["z_vals"], torch.from_numpy(g[f"{tag}_z_vals"]), 0, 2e-6, "z_vals")
+        _close(rend["raw"], torch.from_numpy(g[f"{tag}_raw"]), 1e-4, 2e-5, "raw")
+        _close(rend["rgb_res_map"], torch.from_numpy(g[f"{tag}_rgb_res_map"]), 1e-4, 2e-5, "rgb map")
+        _close(rend["depth_res_map"], torch.from_numpy(g[f"{tag}_depth_res_map"]), 1e-4, 2e-5, "depth map")
+        m.train()
+        ret = m.mapping(o, d, tgt, td, clamp=clamp)
+        for k in ("rgb_res_loss", "depth_res_loss", "sdf_res_loss", "fs_res_loss"):
+            _close(ret[k], torch.from_numpy(g[f"{tag}_{k}"]), 1e-4, 1e-8, k)
+        # fused renderer on the same rays (no jitter)
+        rgb, dep = m.render_fused(o, d, td, jitter=False)
+        _close(rgb, torch.from_numpy(g[f"{tag}_rgb_res_map"]), 2e-4, 2e-5, "fused rgb") if not clamp else None
