@@ -84,7 +84,7 @@ def cpu_baseline(cfg, frame, model_points: int):
     scaled to the per-frame schedule.  A reported baseline, not a target."""
     from oracle import field_oracle as FO
     from oracle import tsdf as OT
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)     # torch-CPU ops of this size stop scaling (and thrash) beyond ~16 threads
     torch.set_num_threads(cores)
     # --- V1 on the full-size volume (single-thread C)
     vol = cfg["volume"]
@@ -105,7 +105,7 @@ def cpu_baseline(cfg, frame, model_points: int):
     # --- one field iteration (forward + backward) on a sample of the points, torch CPU
     S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
     n_pts_iter = model_points
-    sample = 4096
+    sample = 32768
     meta = FO.hashgrid_meta_from_config(cfg["grid"]["hash_size"], int(max(b[1] - b[0] for b in cfg["mapping"]["bound"]) / cfg["grid"]["voxel_sdf"]))
     g = torch.Generator().manual_seed(0)
     R = cfg["globalV"]["base_resolution"]
@@ -117,8 +117,9 @@ def cpu_baseline(cfg, frame, model_points: int):
                         W4=(torch.randn(3, 32, generator=g) * 0.1).requires_grad_(True),
                         c_trunc=cfg["training"]["c_trunc"], trunc=cfg["training"]["trunc"])
     x = torch.rand((sample, 3), generator=g)
+    FO.query_color_sdf(fp, x[:256]).square().sum().backward()     # warm the allocator / thread pool
     t0 = time.time()
-    reps = 3
+    reps = 2
     for _ in range(reps):
         raw = FO.query_color_sdf(fp, x)
         raw.square().sum().backward()
