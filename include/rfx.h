@@ -207,6 +207,28 @@ int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_ray
                            float sc_factor, const float* d_rgb, const float* d_depth, float* d_raw4,
                            rfx_stream stream);
 
+/* L1 fused: the four mapping losses of JointEncoding.mapping (model/scene_rep.py:493-527 with
+ * model/utils.py:170-256) from raw/z and the rendered maps.  sums8 dev double[8] (scratch),
+ * losses4 dev float[4] = (rgb, depth, sdf, fs), coef4 dev float[4] (kept for the backward).
+ * trunc_loss = training.trunc * data.sc_factor; rgb_missing_on = (training.rgb_missing > 0). */
+int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                             const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
+                             float depth_trunc, int rgb_missing_on, double* sums8, float* losses4, float* coef4,
+                             rfx_stream stream);
+/* d_raw4 = d(sum_i gout4[i] * loss_i)/d raw4 including the path through the compositing (R1
+ * backward); g_rgb_map / g_depth_map: optional extra grads on the rendered maps (may be NULL). */
+int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                              const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc,
+                              float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, const float* coef4,
+                              const float* gout4, const float* g_rgb_map, const float* g_depth_map, float* d_raw4,
+                              rfx_stream stream);
+
+/* TV1: total variation of lattice features feat dev [P,P,P,C] (mp_slam/slam.py:211-215):
+ * *sum1 (dev double) = sum of squared forward differences along x, y, z.  Backward writes
+ * dfeat = gscale_dev[0] * scale * d(sum)/d feat. */
+int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream stream);
+int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream);
+
 /* Fused render (SLAM.render_single, mp_slam/slam.py:290-344): S1 + points + Q1 + R1 in one launch,
  * one wave per ray; nothing but rays, rgb and depth touches HBM.  u01 dev [n,S] (NULL = no jitter). */
 int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const float* rays_o,

@@ -72,6 +72,10 @@ PROTOTYPES = {
     "rfx_ray_points": (_i, [_P, _P, _P, _l, _i, _D6, _i, _P, _P]),
     "rfx_composite_forward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
     "rfx_composite_backward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
+    "rfx_mapping_loss_forward": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _i, _P, _P, _P, _P]),
+    "rfx_mapping_loss_backward": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _f, _f, _i, _P, _P, _P, _P, _P, _P]),
+    "rfx_tv_forward": (_i, [_P, _i, _i, _P, _P]),
+    "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
     "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),
 }
 

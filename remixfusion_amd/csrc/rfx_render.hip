@@ -287,6 +287,177 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_rays_kernel(FieldK f, S
     }
 }
 
+// ------------------------------------------------------------------ L1: fused mapping losses
+// sums (double, caller zero-fills): 0 rgb sq-err, 1 depth sq-err (valid rays), 2 #valid rays,
+// 3 free-space sq-err, 4 sdf sq-err, 5 #front samples, 6 #sdf samples (both counted before the
+// valid-depth mask, like get_masks; model/utils.py:170-198, scene_rep.py:493-517).
+struct LossK {
+    float trunc_loss;     // training.trunc * data.sc_factor
+    float depth_trunc;    // cam.depth_trunc
+    int   rgb_missing_on; // training.rgb_missing > 0 (bool cast in the reference, see scene_rep.py:495-498)
+};
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mapping_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
+                                                                   const float* __restrict__ zv, const float* __restrict__ rgb_map,
+                                                                   const float* __restrict__ depth_map,
+                                                                   const float* __restrict__ tgt_rgb, const float* __restrict__ tgt_d,
+                                                                   int64_t n_rays, int S, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * 4) {
+        const float d = tgt_d[ray];
+        const bool valid = (d > 0.0f) && (d < L.depth_trunc);
+        if (lane == 0) {
+            const float rw = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float e = rgb_map[ray * 3 + c] * rw - tgt_rgb[ray * 3 + c] * rw;
+                a_rgb += (double)(e * e);
+            }
+            if (valid) { const float e = depth_map[ray] - d; a_dep += (double)(e * e); a_val += 1.0; }
+        }
+        for (int j = lane; j < S; j += 64) {
+            const float z = zv[ray * S + j], s = raw[ray * S + j].w;
+            const float front = (z < (d - L.trunc_loss)) ? 1.0f : 0.0f;
+            const float back = (z > (d + L.trunc_loss)) ? 1.0f : 0.0f;
+            const float sm = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
+            a_nfs += front; a_nsdf += sm;
+            if (valid) {
+                const float ef = s * front - front;
+                const float es = (z + s * L.trunc_loss) * sm - d * sm;
+                a_fs += (double)(ef * ef); a_sdf += (double)(es * es);
+            }
+        }
+    }
+    a_rgb = wave_sum_d(a_rgb); a_dep = wave_sum_d(a_dep); a_val = wave_sum_d(a_val); a_fs = wave_sum_d(a_fs);
+    a_sdf = wave_sum_d(a_sdf); a_nfs = wave_sum_d(a_nfs); a_nsdf = wave_sum_d(a_nsdf);
+    if (lane == 0) {
+        atomicAdd(sums + 0, a_rgb); atomicAdd(sums + 1, a_dep); atomicAdd(sums + 2, a_val); atomicAdd(sums + 3, a_fs);
+        atomicAdd(sums + 4, a_sdf); atomicAdd(sums + 5, a_nfs); atomicAdd(sums + 6, a_nsdf);
+    }
+}
+
+// losses[4] = (rgb, depth, sdf, fs) ; coef[4] = d loss_i / d (its squared-error sum)
+__global__ void mapping_loss_finalize_kernel(const double* __restrict__ sums, int64_t n_rays, int S, float* __restrict__ losses,
+                                             float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ns = (double)n_rays * (double)S;
+    const double tot = sums[5] + sums[6];
+    const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
+    const float c_rgb = (float)(1.0 / (3.0 * (double)n_rays)), c_dep = (float)(1.0 / sums[2]);
+    const float c_sdf = (float)(1.0 / ns) * sdf_w, c_fs = (float)(1.0 / ns) * fs_w;
+    losses[0] = (float)sums[0] * c_rgb; losses[1] = (float)sums[1] * c_dep;
+    losses[2] = (float)sums[4] * c_sdf; losses[3] = (float)sums[3] * c_fs;
+    coef[0] = c_rgb; coef[1] = c_dep; coef[2] = c_sdf; coef[3] = c_fs;
+}
+
+// d_raw4 = d(sum_i gout_i * loss_i)/d raw  (+ optional external grads on the maps), compositing included.
+__global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, const float4* __restrict__ raw,
+                                                                    const float* __restrict__ zv, const float* __restrict__ rgb_map,
+                                                                    const float* __restrict__ depth_map,
+                                                                    const float* __restrict__ tgt_rgb, const float* __restrict__ tgt_d,
+                                                                    int64_t n_rays, int S, float trunc, float sc,
+                                                                    const float* __restrict__ coef, const float* __restrict__ gout,
+                                                                    const float* __restrict__ g_rgb_map,
+                                                                    const float* __restrict__ g_depth_map, float4* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const float k_rgb = gout[0] * coef[0], k_dep = gout[1] * coef[1], k_sdf = gout[2] * coef[2], k_fs = gout[3] * coef[3];
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * 4) {
+        float s[2], z[2];
+        float4 rv[2];
+        bool ok[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = lane + 64 * c;
+            ok[c] = j < S;
+            rv[c] = ok[c] ? raw[ray * S + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            z[c] = ok[c] ? zv[ray * S + j] : 0.f;
+            s[c] = rv[c].w;
+        }
+        const RayW rw = ray_weights(s, z, ok, S, lane, trunc, sc);
+        const float d = tgt_d[ray];
+        const bool valid = (d > 0.0f) && (d < L.depth_trunc);
+        const float w2 = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g[c] = k_rgb * 2.0f * w2 * (rgb_map[ray * 3 + c] * w2 - tgt_rgb[ray * 3 + c] * w2);
+            if (g_rgb_map) g[c] += g_rgb_map[ray * 3 + c];
+        }
+        float gd = valid ? k_dep * 2.0f * (depth_map[ray] - d) : 0.0f;
+        if (g_depth_map) gd += g_depth_map[ray];
+        float gj[2], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            gj[c] = g[0] * rv[c].x + g[1] * rv[c].y + g[2] * rv[c].z + gd * z[c];
+            dot += rw.w[c] * gj[c];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!ok[c]) continue;
+            float ds = 0.f;
+            if (rw.w[c] != 0.0f) {
+                const float a = s[c] / trunc;
+                const float sp = sigmoidf(a), sm = sigmoidf(-a);
+                ds = (gj[c] - dot) / rw.wsum * (sp * sm * (sm - sp) / trunc);
+            }
+            if (valid) {
+                const float front = (z[c] < (d - L.trunc_loss)) ? 1.0f : 0.0f;
+                const float back = (z[c] > (d + L.trunc_loss)) ? 1.0f : 0.0f;
+                const float smk = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
+                ds += k_fs * 2.0f * (s[c] * front - front) * front;
+                ds += k_sdf * 2.0f * ((z[c] + s[c] * L.trunc_loss) * smk - d * smk) * (L.trunc_loss * smk);
+            }
+            d_raw[ray * S + lane + 64 * c] = make_float4(rw.w[c] * g[0], rw.w[c] * g[1], rw.w[c] * g[2], ds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ TV1: total variation of lattice features
+// feat [P,P,P,C]; sum over the three axes of squared forward differences (mp_slam/slam.py:211-215).
+__global__ __launch_bounds__(256) void tv_forward_kernel(const float* __restrict__ feat, int P, int Cn, double* __restrict__ sum) {
+    const int64_t total = (int64_t)P * P * P * Cn;
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = i / Cn;
+        const int z = (int)(cell % P), y = (int)((cell / P) % P), x = (int)(cell / ((int64_t)P * P));
+        const float v = feat[i];
+        if (x + 1 < P) { const float e = feat[i + (int64_t)P * P * Cn] - v; acc += (double)(e * e); }
+        if (y + 1 < P) { const float e = feat[i + (int64_t)P * Cn] - v; acc += (double)(e * e); }
+        if (z + 1 < P) { const float e = feat[i + Cn] - v; acc += (double)(e * e); }
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+// dfeat = (*gscale) * scale * d(sum)/d feat
+__global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restrict__ feat, int P, int Cn, float scale,
+                                                          const float* __restrict__ gscale, float* __restrict__ dfeat) {
+    const int64_t total = (int64_t)P * P * P * Cn;
+    const float k = 2.0f * scale * gscale[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = i / Cn;
+        const int z = (int)(cell % P), y = (int)((cell / P) % P), x = (int)(cell / ((int64_t)P * P));
+        const float v = feat[i];
+        const int64_t sx = (int64_t)P * P * Cn, sy = (int64_t)P * Cn, sz = Cn;
+        float g = 0.f;
+        if (x + 1 < P) g -= feat[i + sx] - v;
+        if (x > 0) g += v - feat[i - sx];
+        if (y + 1 < P) g -= feat[i + sy] - v;
+        if (y > 0) g += v - feat[i - sy];
+        if (z + 1 < P) g -= feat[i + sz] - v;
+        if (z > 0) g += v - feat[i - sz];
+        dfeat[i] = k * g;
+    }
+}
+
 static int make_sampler(const rfx_sampler_desc* d, SamplerK* k) {
     if (!d) return RFX_ERR_ARG;
     if (d->n_range_d < 1 || d->n_samples_d < 0) return RFX_ERR_ARG;
@@ -377,6 +548,60 @@ int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const fl
     if (n_rays == 0) return RFX_OK;
     hipLaunchKernelGGL(render_rays_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
                        make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                             const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
+                             float depth_trunc, int rgb_missing_on, double* sums8, float* losses4, float* coef4,
+                             rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums8 || !losses4 || !coef4) return RFX_ERR_ARG;
+    if (n_rays < 0 || S <= 0) return RFX_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    RFX_HIP_TRY(hipMemsetAsync(sums8, 0, 8 * sizeof(double), st));
+    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
+    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, st, L,
+                       reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, sums8);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums8, n_rays, S, losses4, coef4);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                              const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc,
+                              float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, const float* coef4,
+                              const float* gout4, const float* g_rgb_map, const float* g_depth_map, float* d_raw4,
+                              rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !coef4 || !gout4 || !d_raw4) return RFX_ERR_ARG;
+    if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
+    if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
+    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
+    hipLaunchKernelGGL(mapping_loss_backward_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
+                       reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
+                       sc_factor, coef4, gout4, g_rgb_map, g_depth_map, reinterpret_cast<float4*>(d_raw4));
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream stream) {
+    if (!feat || !sum1 || P <= 0 || C <= 0) return RFX_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    RFX_HIP_TRY(hipMemsetAsync(sum1, 0, sizeof(double), st));
+    const int64_t total = (int64_t)P * P * P * C;
+    hipLaunchKernelGGL(tv_forward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, st, feat, P, C, sum1);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream) {
+    if (!feat || !gscale_dev || !dfeat || P <= 0 || C <= 0) return RFX_ERR_ARG;
+    const int64_t total = (int64_t)P * P * P * C;
+    hipLaunchKernelGGL(tv_backward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0,
+                       as_stream(stream), feat, P, C, scale, gscale_dev, dfeat);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -115,6 +115,86 @@ class _CompositeFn(torch.autograd.Function):
         return d_raw, None, None, None
 
 
+class _MappingFn(torch.autograd.Function):
+    """The whole train-mode forward of JointEncoding.mapping as ONE autograd node: S1 sampler, points,
+    Q1 field, R1 compositing and the L1 losses are six kernel launches; backward is three.  Returns
+    (rgb_loss, depth_loss, sdf_loss, fs_loss, rgb_map, depth_map)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, target_rgb, target_d, table, w1, w2, w3, w4, model, clamp):
+        lib = _lib.load()
+        cfg = model.config
+        tr = cfg["training"]
+        dev = rays_o.device
+        st = stream_ptr(dev)
+        o, d = rays_o.detach().to(torch.float32).contiguous(), rays_d.detach().to(torch.float32).contiguous()
+        tgt = target_rgb.detach().to(torch.float32).contiguous()
+        td = target_d.detach().reshape(-1).to(torch.float32).contiguous()
+        n = o.shape[0]
+        S = int(tr["n_range_d"]) + int(tr["n_samples_d"])
+        u = torch.rand((n, S), dtype=torch.float32, device=dev) if tr["perturb"] > 0.0 else None
+        z = torch.empty((n, S), dtype=torch.float32, device=dev)
+        sd = model._sampler_desc()
+        check(lib.rfx_sample_z(C.byref(sd), ptr(td), ptr(u), n, ptr(z), st), "rfx_sample_z")
+        x01 = torch.empty((n * S, 3), dtype=torch.float32, device=dev)
+        check(lib.rfx_ray_points(ptr(o), ptr(d), ptr(z), n, S, model._bbox6, model._bbox_f64, ptr(x01), st), "rfx_ray_points")
+        raw = torch.empty((n * S, 4), dtype=torch.float32, device=dev)
+        desc = model._field_desc(clamp)
+        check(lib.rfx_field_forward(C.byref(desc), ptr(x01), n * S, ptr(raw), st), "rfx_field_forward")
+        out = torch.empty((n, 4), dtype=torch.float32, device=dev)      # rgb map [n,3] | depth map [n]
+        rgb_map, depth_map = torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+        trunc, sc = float(tr["trunc"]), float(cfg["data"]["sc_factor"])
+        check(lib.rfx_composite_forward(ptr(raw), ptr(z), n, S, trunc, sc, ptr(rgb_map), ptr(depth_map), None, st),
+              "rfx_composite_forward")
+        sums = torch.empty(8, dtype=torch.float64, device=dev)
+        lc = torch.empty(8, dtype=torch.float32, device=dev)            # losses[4] | coef[4]
+        check(lib.rfx_mapping_loss_forward(ptr(raw), ptr(z), ptr(rgb_map), ptr(depth_map), ptr(tgt), ptr(td), n, S,
+                                           trunc * sc, float(cfg["cam"]["depth_trunc"]), int(tr["rgb_missing"] > 0),
+                                           sums.data_ptr(), lc.data_ptr(), lc.data_ptr() + 16, st), "rfx_mapping_loss_forward")
+        ctx.save_for_backward(o, d, z, x01, raw, rgb_map, depth_map, tgt, td, lc, table, w1, w2, w3, w4)
+        ctx.model, ctx.clamp, ctx.dims = model, clamp, (n, S)
+        ctx.mark_non_differentiable(z)
+        del out
+        return lc[0], lc[1], lc[2], lc[3], rgb_map, depth_map, z, raw.view(n, S, 4)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_sdf, g_fs, g_rgb_map, g_depth_map, _gz, g_raw):
+        lib = _lib.load()
+        o, d, z, x01, raw, rgb_map, depth_map, tgt, td, lc, table, w1, w2, w3, w4 = ctx.saved_tensors
+        model, (n, S) = ctx.model, ctx.dims
+        cfg = model.config
+        tr = cfg["training"]
+        dev = o.device
+        st = stream_ptr(dev)
+        zero = lc.new_zeros(())
+        gout = torch.stack([g if g is not None else zero for g in (g_rgb, g_depth, g_sdf, g_fs)]).to(torch.float32).contiguous()
+        d_raw = torch.empty_like(raw)
+        trunc, sc = float(tr["trunc"]), float(cfg["data"]["sc_factor"])
+        check(lib.rfx_mapping_loss_backward(ptr(raw), ptr(z), ptr(rgb_map), ptr(depth_map), ptr(tgt), ptr(td), n, S, trunc, sc,
+                                            trunc * sc, float(cfg["cam"]["depth_trunc"]), int(tr["rgb_missing"] > 0),
+                                            lc.data_ptr() + 16, ptr(gout),
+                                            ptr(g_rgb_map.contiguous()) if g_rgb_map is not None else None,
+                                            ptr(g_depth_map.contiguous()) if g_depth_map is not None else None, ptr(d_raw), st),
+              "rfx_mapping_loss_backward")
+        if g_raw is not None:
+            d_raw = d_raw + g_raw.reshape(-1, 4)
+        need = ctx.needs_input_grad
+        want_dx = need[0] or need[1]
+        dx = torch.empty_like(x01) if want_dx else None
+        dt = torch.zeros_like(table) if need[4] else None
+        dws = [torch.zeros_like(w) if nd else None for w, nd in zip((w1, w2, w3, w4), need[5:9])]
+        ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
+        desc = model._field_desc(ctx.clamp)
+        check(lib.rfx_field_backward(C.byref(desc), ptr(x01), n * S, ptr(d_raw), ptr(dt), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]),
+                                     ptr(dws[3]), ptr(dx), ptr(ws), ws.numel() * 4, st), "rfx_field_backward")
+        go = gd = None
+        if want_dx:
+            dp = dx.view(n, S, 3) / model._extent32.to(dev)
+            go = dp.sum(1) if need[0] else None
+            gd = (dp * z[..., None]).sum(1) if need[1] else None
+        return go, gd, None, None, dt, dws[0], dws[1], dws[2], dws[3], None, None
+
+
 # ------------------------------------------------------------------------------ the module
 class JointEncoding(nn.Module):
     def __init__(self, config, bound_box, num_kf=None):
@@ -328,9 +408,20 @@ class JointEncoding(nn.Module):
         """One forward of the mapping objective (reference :460-529).  Train mode: dict of the four
         losses (+ rendered rgb/depth); eval mode: the render dict."""
         self.clamp = clamp
-        rend = self.render_rays(rays_o, rays_d, target_d=target_d, tracking=tracking, render_flag=render_flag)
         if not self.training:
-            return rend
+            return self.render_rays(rays_o, rays_d, target_d=target_d, tracking=tracking, render_flag=render_flag)
+        # train mode: one fused autograd node (sampler + points + field + compositing + losses)
+        w1, w2, w3, w4 = self.decoder_res.fused_weights()
+        rgb_l, depth_l, sdf_l, fs_l, rgb_map, depth_map, _z, _raw = _MappingFn.apply(
+            rays_o, rays_d, target_rgb, target_d, self.embed_res_fn.params, w1, w2, w3, w4, self, bool(clamp))
+        return {"rgb_res_loss": rgb_l, "depth_res_loss": depth_l, "sdf_res_loss": sdf_l, "fs_res_loss": fs_l,
+                "rgb_res": rgb_map, "depth_res": depth_map}
+
+    def mapping_unfused(self, rays_o, rays_d, target_rgb, target_d, clamp=False):
+        """the same objective assembled from the individual kernels + torch ops (kept for tests: the
+        fused node must agree with it).  Mirrors the reference's loss block line by line (:493-527)."""
+        self.clamp = clamp
+        rend = self.render_rays(rays_o, rays_d, target_d=target_d)
         cfg = self.config
         td = target_d.squeeze()
         valid_depth_mask = (td > 0.0) * (td < cfg["cam"]["depth_trunc"])

@@ -12,7 +12,41 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
 from ..model.keyframe import KeyFrameDatabase
+
+
+class _SmoothFn(torch.autograd.Function):
+    """TV of the hash features on a lattice as one autograd node: grid lookup + TV reduction forward,
+    TV gradient + hash scatter backward (reference mp_slam/slam.py:209-215)."""
+
+    @staticmethod
+    def forward(ctx, table, pts01, enc, P, denom):
+        lib = _lib.load()
+        x = pts01.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        n = x.shape[0]
+        feat = torch.empty((n, enc.n_output_dims), dtype=torch.float32, device=x.device)
+        st = stream_ptr(x.device)
+        check(lib.rfx_grid_encode_forward(enc.desc, ptr(table), ptr(x), n, ptr(feat), st), "rfx_grid_encode_forward")
+        acc = torch.empty(1, dtype=torch.float64, device=x.device)
+        check(lib.rfx_tv_forward(ptr(feat), P, enc.n_output_dims, acc.data_ptr(), st), "rfx_tv_forward")
+        ctx.save_for_backward(table, x, feat)
+        ctx.enc, ctx.P, ctx.denom = enc, P, denom
+        return (acc[0] / denom).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        table, x, feat = ctx.saved_tensors
+        st = stream_ptr(x.device)
+        dfeat = torch.empty_like(feat)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        check(lib.rfx_tv_backward(ptr(feat), ctx.P, ctx.enc.n_output_dims, 1.0 / ctx.denom, ptr(gs), ptr(dfeat), st), "rfx_tv_backward")
+        dt = torch.zeros_like(table)
+        check(lib.rfx_grid_encode_backward(ctx.enc.desc, ptr(table), ptr(x), x.shape[0], ptr(dfeat), ptr(dt), None, st),
+              "rfx_grid_encode_backward")
+        return dt, None, None, None, None
 
 
 class SLAM:
@@ -111,6 +145,10 @@ class SLAM:
         coords = self._tv_coords[P].to(volume)
         pts = (coords + torch.rand((1, 1, 1, 3)).to(volume)) * voxel_size + bb[:, 0] + offset
         pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0]) if self.config["grid"]["tcnn_encoding"] else pts
+        return _SmoothFn.apply(self.model.embed_res_fn.params, pts_tcnn, self.model.embed_res_fn, P, float(sample_points ** 3))
+
+    def smoothness_unfused(self, pts_tcnn, sample_points):
+        """reference formulation on top of query_sdf_res(embed=True) (kept for tests)."""
         sdf_res = self.model.query_sdf_res(pts_tcnn, embed=True)
         tv_x = torch.pow(sdf_res[1:, ...] - sdf_res[:-1, ...], 2).sum()
         tv_y = torch.pow(sdf_res[:, 1:, ...] - sdf_res[:, :-1, ...], 2).sum()
