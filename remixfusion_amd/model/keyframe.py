@@ -15,6 +15,9 @@ class KeyFrameDatabase(object):
         self.config = config
         self.keyframes = {}
         self.device = device
+        # mapping.device_sampling: draw ray indices with the device RNG (torch.randperm on the GPU)
+        # instead of Python's random.sample on the host (reference behaviour, O(k) python per draw)
+        self.device_sampling = bool(config["mapping"].get("device_sampling", False))
         self.rays = torch.zeros((num_kf, num_rays_to_save, 7), device=device)
         self.num_rays_to_save = num_rays_to_save
         self.frame_ids = None
@@ -32,25 +35,30 @@ class KeyFrameDatabase(object):
     def get_length(self):
         return self.__len__()
 
+    def _choose(self, population: int, k: int, device) -> torch.Tensor:
+        """k distinct indices out of range(population)."""
+        if self.device_sampling:
+            return torch.randperm(population, device=device)[:k]
+        return torch.as_tensor(random.sample(range(0, population), k), device=device)
+
     def sample_single_keyframe_rays(self, rays, option="random", first=False):
         """rays [1, H*W, 7] -> [1, num_rays_to_save, 7] (or [num_rays_to_save, 7] for filter_depth)."""
         rays_valid = None
         if option == "random":
-            idxs = random.sample(range(0, self.H * self.W), self.num_rays_to_save)
+            idx_t = self._choose(self.H * self.W, self.num_rays_to_save, rays.device)
         elif option == "filter_depth":
             valid = (rays[..., -1] > 0.0) & (rays[..., -1] <= self.config["cam"]["depth_trunc"])
             rays_valid = rays[valid, :]
             if len(rays_valid) > self.num_rays_to_save:
-                idxs = random.sample(range(0, len(rays_valid)), self.num_rays_to_save)
+                idx_t = self._choose(len(rays_valid), self.num_rays_to_save, rays.device)
             else:
                 # too few valid-depth rays: fall back to uniform sampling over the frame.  (The
                 # reference intends this too but its `option == "random"` at :42 is a comparison,
                 # so it would index rays_valid out of range; SURVEY.md appendix D.)
-                idxs = random.sample(range(0, self.H * self.W), self.num_rays_to_save)
+                idx_t = self._choose(self.H * self.W, self.num_rays_to_save, rays.device)
                 option = "random"
         else:
             raise NotImplementedError()
-        idx_t = torch.as_tensor(idxs, device=rays.device)
         if option == "random" or first:
             return rays[:, idx_t]
         return rays_valid[idx_t, :]
@@ -71,6 +79,11 @@ class KeyFrameDatabase(object):
 
     def sample_global_rays(self, bs):
         num_kf = self.__len__()
+        if self.device_sampling:
+            idxs = torch.randperm(num_kf * self.num_rays_to_save, device=self.rays.device)[:bs]
+            sample_rays = self.rays[:num_kf].reshape(-1, 7)[idxs]
+            frame_ids = self.frame_ids.to(idxs.device)[idxs // self.num_rays_to_save]
+            return sample_rays, frame_ids
         idxs = torch.tensor(random.sample(range(num_kf * self.num_rays_to_save), bs))
         sample_rays = self.rays[:num_kf].reshape(-1, 7)[idxs.to(self.rays.device)]
         frame_ids = self.frame_ids[idxs // self.num_rays_to_save]

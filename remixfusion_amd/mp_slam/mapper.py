@@ -93,7 +93,8 @@ class Mapper:
         ret = loss = None
         for _ in range(n_iters):
             self.map_optimizer.zero_grad()
-            indice = self.slam.select_samples(H, W, n_s).to(self.device)
+            indice = (torch.randperm(H * W, device=self.device)[:n_s] if self.keyframe.device_sampling
+                      else self.slam.select_samples(H, W, n_s).to(self.device))
             indice_h, indice_w = indice % H, indice // H        # (sic) reference :338
             rays_d_cam = direction[indice_h, indice_w, :]
             target_s = rgb[indice_h, indice_w, :]
@@ -112,10 +113,15 @@ class Mapper:
         m = self.config["mapping"]
         rays, ids = self.keyframe.sample_global_rays(m["sample"])
         n_cur = max(m["sample"] // len(self.keyframe.frame_ids), m["min_pixels_cur"])
-        idx_cur = random.sample(range(0, self.slam.dataset.H * self.slam.dataset.W), n_cur)
-        cur = current_rays[torch.as_tensor(idx_cur, device=current_rays.device), :]
+        hw = self.slam.dataset.H * self.slam.dataset.W
+        if self.keyframe.device_sampling:
+            idx_cur = torch.randperm(hw, device=current_rays.device)[:n_cur]
+        else:
+            idx_cur = torch.as_tensor(random.sample(range(0, hw), n_cur), device=current_rays.device)
+        cur = current_rays[idx_cur, :]
         rays = torch.cat([rays.to(self.device), cur], dim=0)
-        ids_all = torch.cat([ids // m["keyframe_every"], -torch.ones((n_cur))]).to(torch.int64).to(self.device)
+        ids_kf = (ids // m["keyframe_every"]).to(device=self.device, dtype=torch.int64)
+        ids_all = torch.cat([ids_kf, torch.full((n_cur,), -1, dtype=torch.int64, device=self.device)])
         return rays, ids_all
 
     @staticmethod

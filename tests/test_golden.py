@@ -123,6 +123,7 @@ def test_host_helpers_match_reference(tmp_path):
     assert cfg["a"] == {"b": 1, "c": {"d": 20, "e": 3}, "g": 7} and cfg["f"] == 4 and cfg["h"] == [1, 2]
     # keyframe store: same python RNG stream -> same rays as the reference
     rays = get_camera_rays(12, 16, 14.4, 14.0, 7.5, 5.5)
+    c2["mapping"]["device_sampling"] = False          # reference behaviour: python's random stream
     kf = KeyFrameDatabase(c2, 12, 16, 4, 30, "cpu")
     random.seed(1234)
     gen = torch.Generator().manual_seed(1)
