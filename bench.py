@@ -142,13 +142,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    local_rank %= max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        backend = os.environ.get("RFX_DIST_BACKEND", "nccl")     # nccl == RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
     from remixfusion_amd import _lib
@@ -158,8 +163,10 @@ def main():
 
     lib = _lib.load()
     timer = KernelTimer()
-    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward", "rfx_render_rays", "rfx_gbv_integrate",
-                 "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward", "rfx_composite_backward"):
+    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_weights",
+                 "rfx_field_backward_scatter", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
+                 "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
+                 "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):
         timer.wrap(lib, name)
 
     cfg = synthetic_config(args.config)
@@ -190,7 +197,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -239,8 +246,22 @@ def main():
 
     if "rfx_field_forward" in summ:
         extra_rooflines["field_forward"] = mfma_roofline("rfx_field_forward", MLP_FLOP_PER_POINT, 2)
-    if "rfx_field_backward" in summ:
-        extra_rooflines["field_backward"] = mfma_roofline("rfx_field_backward", 2 * MLP_FLOP_PER_POINT, 2)
+    if "rfx_field_backward_chain" in summ:
+        # recompute-forward + dX chain: 2 x forward FLOPs of algorithmic work (dX); dW is the _weights stage
+        extra_rooflines["field_backward_chain"] = mfma_roofline("rfx_field_backward_chain", MLP_FLOP_PER_POINT, 2)
+    if "rfx_field_backward_weights" in summ:
+        extra_rooflines["field_backward_weights"] = mfma_roofline("rfx_field_backward_weights", MLP_FLOP_PER_POINT, 0)
+    if "rfx_field_backward_scatter" in summ:
+        # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered
+        cnt, ms, evs = summ["rfx_field_backward_scatter"]
+        pts = float(np.mean([e[2][2] for e in evs]))
+        nbytes = pts * (12 + 128 + 1024)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        extra_rooflines["field_backward_scatter"] = {"kernel": "grid_encode_backward_kernel (rfx_field_backward_scatter)",
+                                                     "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                                     "points_per_launch": int(pts), "avg_ms": round(ms, 4),
+                                                     "note": "fp32 atomics execute at the memory side: ~1.3 TB/s contiguous, ~0.08 TB/s scattered (MI355X_MICROARCH.md)"}
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]
         pts = float(evs[0][2][6]) * S
@@ -275,7 +296,8 @@ def main():
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                  "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
                                                  "algorithmic_bytes": int(nbytes), "avg_ms": round(ms, 4)}
-    key = {"rfx_field_forward": "field_forward", "rfx_field_backward": "field_backward",
+    key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
+           "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
            "rfx_tsdf_integrate": "tsdf_integrate"}.get(dominant)
     roofline = extra_rooflines.get(key) if key else None
     if roofline is None and extra_rooflines:

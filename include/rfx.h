@@ -172,6 +172,22 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
                        float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
                        void* workspace, size_t workspace_bytes, rfx_stream stream);
 
+/* The four stages rfx_field_backward runs, exposed so a caller can time / overlap them:
+ *   _chain   : recompute forward + dX chain on the matrix cores; stages per-point rows in the workspace
+ *   _weights : dW = dY^T X over points (streaming MFMA, deterministic two-stage sum), accumulates into dw*
+ *   _scatter : hash-grid gradient scatter (wave-segmented float atomics) into d_hash; writes the hash
+ *              part of dx01 when dx01 != NULL
+ *   _dx      : adds the OneBlob / GBV part of dL/dx01
+ * All take the same workspace; _chain must run first. */
+int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                             void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                               void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,
+                               void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_dx(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dx01,
+                          void* workspace, size_t workspace_bytes, rfx_stream stream);
+
 /* Q2 point queries (model/scene_rep.py:212-310).  out dev [n] or [n,3] as documented. */
 int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream);          /* query_sdf_res      */
 int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, float* rgb3, rfx_stream stream);       /* query_color_residual */
@@ -228,6 +244,11 @@ int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const floa
  * dfeat = gscale_dev[0] * scale * d(sum)/d feat. */
 int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream stream);
 int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream);
+
+/* k distinct pseudo-random indices out of range(population), on the device: replaces python's
+ * random.sample in the ray samplers (model/keyframe.py:33,89; mp_slam/mapper.py:396).  out dev int64[k].
+ * Deterministic in (seed, population). */
+int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream);
 
 /* Fused render (SLAM.render_single, mp_slam/slam.py:290-344): S1 + points + Q1 + R1 in one launch,
  * one wave per ray; nothing but rays, rgb and depth touches HBM.  u01 dev [n,S] (NULL = no jitter). */

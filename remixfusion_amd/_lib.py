@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librfx.so")
+LIB_PATH = os.environ.get("RFX_LIB_PATH", os.path.join(_HERE, "librfx.so"))   # override: A/B builds of the library
 RFX_MAX_LEVELS = 16
 
 
@@ -66,6 +66,10 @@ PROTOTYPES = {
     "rfx_field_forward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_field_backward_workspace_bytes": (_sz, [_l]),
     "rfx_field_backward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "rfx_field_backward_chain": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_weights": (_i, [_l, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "rfx_field_backward_scatter": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),
+    "rfx_field_backward_dx": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),
     "rfx_field_query_sdf": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_field_query_color": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_sample_z": (_i, [C.POINTER(SamplerDesc), _P, _P, _l, _P, _P]),
@@ -76,6 +80,7 @@ PROTOTYPES = {
     "rfx_mapping_loss_backward": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _f, _f, _i, _P, _P, _P, _P, _P, _P]),
     "rfx_tv_forward": (_i, [_P, _i, _i, _P, _P]),
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
+    "rfx_random_subset": (_i, [C.c_uint64, _l, _l, _P, _P]),
     "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),
 }
 
@@ -125,3 +130,13 @@ def stream_ptr(device=None) -> int:
 
 def farr(ctype, values: Sequence[float]):
     return ctype(*[float(v) for v in values])
+
+
+def random_subset(population: int, k: int, device) -> torch.Tensor:
+    """k distinct indices of range(population) as a device int64 tensor; the key comes from python's
+    ``random`` so that ``random.seed`` / SLAM.seed_everything make runs repeatable."""
+    import random as _random
+    out = torch.empty(int(k), dtype=torch.int64, device=device)
+    check(load().rfx_random_subset(_random.getrandbits(64), int(population), int(k), out.data_ptr(), stream_ptr(device)),
+          "rfx_random_subset")
+    return out

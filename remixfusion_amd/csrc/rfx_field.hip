@@ -640,18 +640,16 @@ size_t rfx_field_backward_workspace_bytes(int64_t n) {
     return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * 4 * DW_TOTAL) * sizeof(float);
 }
 
-int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
-                       float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
-                       void* workspace, size_t workspace_bytes, rfx_stream stream) {
+// ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
+int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                             void* workspace, size_t workspace_bytes, rfx_stream stream) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
     if (!x01 || !draw4 || n < 0) return RFX_ERR_ARG;
-    if (n == 0) return RFX_OK;
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
-    hipStream_t st = as_stream(stream);
     BwdWs ws = carve(workspace, n);
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
     static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
@@ -660,25 +658,67 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(field_backward_kernel, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, st, k, x01, n, draw4, ws);
+    hipLaunchKernelGGL(field_backward_kernel, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
     RFX_LAUNCH_CHECK();
-    if (dw1 || dw2 || dw3 || dw4) {
-        hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
-        RFX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 31) / 32), dim3(256), 0, st, ws.partial, DW_BLOCKS * 4,
-                           dw1, dw2, dw3, dw4);
-        RFX_LAUNCH_CHECK();
-    }
-    if (d_hash || dx01) {
-        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.hash, k.table,
-                           x01, n, ws.dx1, LD_DX1, d_hash, dx01, 0);
-        RFX_LAUNCH_CHECK();
-    }
-    if (dx01) {
-        hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k, x01, n, draw4, ws.dx1, dx01);
-        RFX_LAUNCH_CHECK();
-    }
     return RFX_OK;
+}
+
+int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                               void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0 || (!dw1 && !dw2 && !dw3 && !dw4)) return RFX_OK;
+    if (!draw4 || n < 0) return RFX_ERR_ARG;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    BwdWs ws = carve(workspace, n);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 31) / 32), dim3(256), 0, st, ws.partial, DW_BLOCKS * 4,
+                       dw1, dw2, dw3, dw4);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,
+                               void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0 || (!d_hash && !dx01)) return RFX_OK;
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || n < 0) return RFX_ERR_ARG;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    BwdWs ws = carve(workspace, n);
+    hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k.hash,
+                       k.table, x01, n, ws.dx1, LD_DX1, d_hash, dx01, 0);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_backward_dx(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dx01,
+                          void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0 || !dx01) return RFX_OK;
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!x01 || !draw4 || n < 0) return RFX_ERR_ARG;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    BwdWs ws = carve(workspace, n);
+    hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k, x01, n, draw4,
+                       ws.dx1, dx01);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                       float* d_hash, float* dw1, float* dw2, float* dw3, float* dw4, float* dx01,
+                       void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
+    int rc = rfx_field_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = rfx_field_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = rfx_field_backward_scatter(f, x01, n, d_hash, dx01, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return rfx_field_backward_dx(f, x01, n, draw4, dx01, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -458,6 +458,36 @@ __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------ distinct random indices
+// Replaces python's random.sample(range(N), k) of the ray samplers (model/keyframe.py:33,89;
+// mp_slam/mapper.py:396): out[i] = pi(i), i < k, where pi is a keyed pseudo-random permutation of
+// [0, N) -- a 4-round Feistel network on the next even power of two, cycle-walked back into range.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void random_subset_kernel(uint64_t seed, int64_t N, int64_t k, int half_bits,
+                                                            int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
+    uint64_t x = (uint64_t)i;
+    do {
+        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const uint32_t key = (uint32_t)(seed >> (16 * round)) ^ (0x9e3779b9u * (round + 1)) ^ (uint32_t)(seed >> 32);
+            const uint32_t f = mix32(r ^ key) & mask;
+            const uint32_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = ((uint64_t)l << half_bits) | r;
+    } while (x >= (uint64_t)N);       // cycle walking: a permutation of [0, 2^(2 half_bits)) restricted to [0, N)
+    out[i] = (int64_t)x;
+}
+
 static int make_sampler(const rfx_sampler_desc* d, SamplerK* k) {
     if (!d) return RFX_ERR_ARG;
     if (d->n_range_d < 1 || d->n_samples_d < 0) return RFX_ERR_ARG;
@@ -602,6 +632,19 @@ int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* g
     const int64_t total = (int64_t)P * P * P * C;
     hipLaunchKernelGGL(tv_backward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0,
                        as_stream(stream), feat, P, C, scale, gscale_dev, dfeat);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream) {
+    if (k == 0) return RFX_OK;
+    if (!out || population <= 0 || k < 0 || k > population) return RFX_ERR_ARG;
+    int bits = 1;
+    while (bits < 63 && (1LL << bits) < population) ++bits;
+    const int half_bits = (bits + 1) / 2;
+    if (half_bits > 31) return RFX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(random_subset_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
+                       population, k, half_bits, out);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

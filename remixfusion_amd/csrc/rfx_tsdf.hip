@@ -17,6 +17,16 @@
 #include "rfx_common.h"
 #include <algorithm>
 
+#ifndef MV_TX
+#define MV_TX 4
+#endif
+#ifndef MV_TY
+#define MV_TY 4
+#endif
+#ifndef MV_U
+#define MV_U 4
+#endif
+
 namespace rfx {
 
 thread_local int g_last_hip_error = 0;
@@ -34,13 +44,14 @@ struct MvParams {
     int   risky_rows;     // rows with y < risky_rows or y >= dy - risky_rows decode literally
     int   literal_all;    // 1: every voxel decodes literally (conditions for the split not met)
     float ratio_eps;      // bound on |cam_norm/(lambda*cam_z) - 1| from pixel rounding
+    int   dimg_colmajor;  // 1: the packed {depth,1/lambda} image is stored [x][y] (see prepass)
 };
 
 // ---------------------------------------------------------------------------- prepass
 __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict__ depth,
                                                          float2* __restrict__ dimg,
                                                          unsigned* __restrict__ dmax_bits, int H, int W,
-                                                         float fx, float fy, float cx, float cy) {
+                                                         float fx, float fy, float cx, float cy, int colmajor) {
     const int n = H * W;
     float m = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -49,7 +60,10 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
         float vx = (((float)px) - cx) / fx;
         float vy = (((float)py) - cy) / fy;
         float lambda = sqrtf(madd(vx, vx, vy * vy) + 1.0f);
-        dimg[i] = make_float2(d, 1.0f / lambda);
+        // A voxel row (world z) projects to a near-straight pixel walk.  Storing the image with the
+        // walk direction contiguous turns the per-lane gather of a 64-voxel chunk from 64 cache
+        // lines into ~12: column-major when the walk is mostly along image y.
+        dimg[colmajor ? px * H + py : i] = make_float2(d, 1.0f / lambda);
         if (d > m) m = d;   // NaN never wins
     }
 #pragma unroll
@@ -93,6 +107,7 @@ template <int U>
 struct Lanes {
     float cx[U], cy[U], cz[U];
     int   pix[U];
+    int   dix[U];
     bool  ok[U];
     int64_t idx[U];
 };
@@ -114,12 +129,21 @@ __device__ __forceinline__ void integrate_lanes(const MvParams& P, Lanes<U>& L,
         ok = ok && px >= 0 && px < P.W && py >= 0 && py < P.H;
         L.ok[u] = ok;
         L.pix[u] = ok ? py * P.W + px : 0;
+        L.dix[u] = ok ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) dl[u] = L.ok[u] ? dimg[L.pix[u]] : make_float2(0.0f, 0.0f);
+    for (int u = 0; u < U; ++u) dl[u] = L.ok[u] ? dimg[L.dix[u]] : make_float2(0.0f, 0.0f);
 
     float sdf[U], cur[U], wold[U], oc[U], ncl[U];
     bool band[U];
+#if defined(MV_DEBUG_STAGE) && MV_DEBUG_STAGE == 2
+    {
+        float acc = 0.f;
+        for (int u = 0; u < U; ++u) acc += dl[u].x + dl[u].y;
+        if (acc == 12345.678f) tsdf[0] = acc;
+        return;
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         float d = dl[u].x;
@@ -219,8 +243,9 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
                 bool empty = !(dmax > 0.0f);
                 auto clip = [&](float a, float b) {   // keep z with a + b z >= -eps
                     a += eps;
-                    if (b > 0.0f)      lo = fmaxf(lo, -a / b);
-                    else if (b < 0.0f) hi = fminf(hi, -a / b);
+                    const float q = -a * __builtin_amdgcn_rcpf(b);   // ~1 ulp: absorbed by eps and the +-1 voxel margin
+                    if (b > 0.0f)      lo = fmaxf(lo, q);
+                    else if (b < 0.0f) hi = fminf(hi, q);
                     else if (a < 0.0f) empty = true;
                 };
                 clip(Az, Bz);                                                            // cam_z > 0
@@ -240,52 +265,71 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
         }
     }
 
-    unsigned long long active = __ballot(z1 > z0);
-    while (active) {
-        const int r = __ffsll((long long)active) - 1;
-        active &= active - 1;
-        const int rz0 = __shfl(z0, r), rz1 = __shfl(z1, r);
-        const int rx = x0 + r / TY, ry = y0 + r % TY;
-        const bool risky = P.literal_all || ry < P.risky_rows || ry >= P.dy - P.risky_rows;
-        const int64_t row_base = ((int64_t)rx * P.dy + ry) * P.dz;
-        if (!risky) {
-            const RowConst rc = make_row(P, (float)rx, (float)ry);
-            for (int zb = rz0; zb < rz1; zb += 64 * U) {
-                Lanes<U> L;
+    // ---- exactly-decoded rows: flatten (row, 64-voxel chunk) work items over the tile and keep U of
+    //      them in flight, so one wave overlaps the dependent load chains of several rows.
+#if defined(MV_DEBUG_STAGE) && MV_DEBUG_STAGE == 1
+    if (z1 == 12345678) tsdf[0] = 0.f;   // keep the cull alive
+    return;
+#endif
+    const int rx_l = x0 + lane / TY, ry_l = y0 + lane % TY;
+    const bool risky_l = lane < ROWS && (P.literal_all || ry_l < P.risky_rows || ry_l >= P.dy - P.risky_rows);
+    const int nchunk = (!risky_l && z1 > z0) ? (z1 - z0 + 63) >> 6 : 0;
+    int incl = nchunk;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int z = zb + u * 64 + lane;
-                    bool ok = z < rz1;
-                    const float pz = madd((float)z, P.voxel, P.origin[2]);
-                    if (P.reintegrate == 1) ok = ok && !outside_old(P, rc.px, rc.py, pz);
-                    const float tz = pz - P.c2w[11];
-                    L.cx[u] = madd(P.c2w[8], tz, rc.ax);
-                    L.cy[u] = madd(P.c2w[9], tz, rc.ay);
-                    L.cz[u] = madd(P.c2w[10], tz, rc.az);
-                    L.ok[u] = ok;
-                    L.idx[u] = row_base + z;
-                }
-                integrate_lanes<U>(P, L, dimg, cpk, tsdf, weight, color);
-            }
-        } else {
-            for (int zb = 0; zb < P.dz; zb += 64) {
-                Lanes<1> L;
-                const int z = zb + lane;
-                bool ok = z < P.dz;
-                const int idx = (int)(row_base + z);
-                float vx, vy, vz;
-                decode_literal(ok ? idx : 0, P.dy, P.dz, vx, vy, vz);
-                const RowConst rc = make_row(P, vx, vy);
-                const float pz = madd(vz, P.voxel, P.origin[2]);
-                if (P.reintegrate == 1) ok = ok && !outside_old(P, rc.px, rc.py, pz);
-                const float tz = pz - P.c2w[11];
-                L.cx[0] = madd(P.c2w[8], tz, rc.ax);
-                L.cy[0] = madd(P.c2w[9], tz, rc.ay);
-                L.cz[0] = madd(P.c2w[10], tz, rc.az);
-                L.ok[0] = ok;
-                L.idx[0] = idx;
-                integrate_lanes<1>(P, L, dimg, cpk, tsdf, weight, color);
-            }
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int excl = incl - nchunk;
+    const int total = __shfl(incl, 63);
+    for (int base = 0; base < total; base += U) {
+        Lanes<U> L;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = base + u;
+            int r = __popcll(__ballot(incl <= q));          // row whose chunk range contains q
+            const bool live = q < total;
+            r = live ? r : 0;
+            const int rz0 = __shfl(z0, r), rz1 = __shfl(z1, r), rex = __shfl(excl, r);
+            const int rx = x0 + r / TY, ry = y0 + r % TY;
+            const RowConst rc = make_row(P, (float)rx, (float)ry);
+            const int z = rz0 + ((q - rex) << 6) + lane;
+            bool ok = live && z < rz1;
+            const float pz = madd((float)z, P.voxel, P.origin[2]);
+            if (P.reintegrate == 1) ok = ok && !outside_old(P, rc.px, rc.py, pz);
+            const float tz = pz - P.c2w[11];
+            L.cx[u] = madd(P.c2w[8], tz, rc.ax);
+            L.cy[u] = madd(P.c2w[9], tz, rc.ay);
+            L.cz[u] = madd(P.c2w[10], tz, rc.az);
+            L.ok[u] = ok;
+            L.idx[u] = ((int64_t)rx * P.dy + ry) * P.dz + z;
+        }
+        integrate_lanes<U>(P, L, dimg, cpk, tsdf, weight, color);
+    }
+    // ---- rows that decode literally (reference fp32 index decode may alias): whole row, per-voxel decode
+    unsigned long long risky_rows_mask = __ballot(risky_l && z1 > z0);
+    while (risky_rows_mask) {
+        const int r = __ffsll((long long)risky_rows_mask) - 1;
+        risky_rows_mask &= risky_rows_mask - 1;
+        const int rx = x0 + r / TY, ry = y0 + r % TY;
+        const int64_t row_base = ((int64_t)rx * P.dy + ry) * P.dz;
+        for (int zb = 0; zb < P.dz; zb += 64) {
+            Lanes<1> L;
+            const int z = zb + lane;
+            bool ok = z < P.dz;
+            const int idx = (int)(row_base + z);
+            float vx, vy, vz;
+            decode_literal(ok ? idx : 0, P.dy, P.dz, vx, vy, vz);
+            const RowConst rc = make_row(P, vx, vy);
+            const float pz = madd(vz, P.voxel, P.origin[2]);
+            if (P.reintegrate == 1) ok = ok && !outside_old(P, rc.px, rc.py, pz);
+            const float tz = pz - P.c2w[11];
+            L.cx[0] = madd(P.c2w[8], tz, rc.ax);
+            L.cy[0] = madd(P.c2w[9], tz, rc.ay);
+            L.cz[0] = madd(P.c2w[10], tz, rc.az);
+            L.ok[0] = ok;
+            L.idx[0] = idx;
+            integrate_lanes<1>(P, L, dimg, cpk, tsdf, weight, color);
         }
     }
 }
@@ -590,15 +634,17 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
         P.ratio_eps = fminf(0.5f, (mvx + hx) * hx + (mvy + hy) * hy + 1e-5f);
     }
 
+    // world z-axis in camera coordinates = third row of R; its image-space direction picks the layout
+    P.dimg_colmajor = (fabsf(K[4] * c2w[9]) >= fabsf(K[0] * c2w[8])) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     unsigned* dmax_bits = reinterpret_cast<unsigned*>(workspace);
     float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + 256);
     RFX_HIP_TRY(hipMemsetAsync(dmax_bits, 0, sizeof(unsigned), st));
     const int prepass_blocks = (int)std::min<int64_t>(256, ((int64_t)H * W + 1023) / 1024);
     hipLaunchKernelGGL(mv_prepass_kernel, dim3(prepass_blocks), dim3(256), 0, st, depth, dimg,
-                       dmax_bits, H, W, K[0], K[4], K[2], K[5]);
+                       dmax_bits, H, W, K[0], K[4], K[2], K[5], P.dimg_colmajor);
     RFX_LAUNCH_CHECK();
-    constexpr int TX = 4, TY = 4, U = 2;
+    constexpr int TX = MV_TX, TY = MV_TY, U = MV_U;
     const int64_t tiles = (int64_t)((dx + TX - 1) / TX) * ((dy + TY - 1) / TY);
     const int blocks = (int)((tiles + 3) / 4);
     hipLaunchKernelGGL((mv_integrate_kernel<TX, TY, U>), dim3(blocks), dim3(256), 0, st, P, dimg, dmax_bits,

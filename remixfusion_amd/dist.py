@@ -82,6 +82,13 @@ def exchange_planes(dist, rank: int, left: Optional[int], right: Optional[int], 
             v[:, :, ix, :] = buf[:n4].view(R, R, 4)
             w[:, :, ix, :] = buf[n4:].view(R, R, 1)
 
+    # gloo (CPU rehearsal of the multi-GPU path) cannot move device tensors: stage through the host
+    host_staged = gbv.is_cuda and dist.get_backend() == "gloo"
+    if host_staged:
+        _pack = pack
+
+        def pack(ix: int) -> torch.Tensor:       # noqa: F811
+            return _pack(ix).cpu()
     ops, recvs = [], []
     if right is not None:
         send_r = pack(R - 2)
@@ -96,7 +103,7 @@ def exchange_planes(dist, rank: int, left: Optional[int], right: Optional[int], 
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     for buf, ix in recvs:
-        unpack(buf, ix)
+        unpack(buf.to(gbv.device) if host_staged else buf, ix)
 
 
 def make_shard(cfg: Dict, rank: int, world: int, dist=None) -> ScenePartition:

@@ -9,13 +9,15 @@ import random
 
 import torch
 
+from .. import _lib
+
 
 class KeyFrameDatabase(object):
     def __init__(self, config, H, W, num_kf, num_rays_to_save, device, num_frame=None) -> None:
         self.config = config
         self.keyframes = {}
         self.device = device
-        # mapping.device_sampling: draw ray indices with the device RNG (torch.randperm on the GPU)
+        # mapping.device_sampling: draw ray indices on the device (rfx_random_subset)
         # instead of Python's random.sample on the host (reference behaviour, O(k) python per draw)
         self.device_sampling = bool(config["mapping"].get("device_sampling", False))
         self.rays = torch.zeros((num_kf, num_rays_to_save, 7), device=device)
@@ -38,7 +40,7 @@ class KeyFrameDatabase(object):
     def _choose(self, population: int, k: int, device) -> torch.Tensor:
         """k distinct indices out of range(population)."""
         if self.device_sampling:
-            return torch.randperm(population, device=device)[:k]
+            return _lib.random_subset(population, k, device)
         return torch.as_tensor(random.sample(range(0, population), k), device=device)
 
     def sample_single_keyframe_rays(self, rays, option="random", first=False):
@@ -65,6 +67,7 @@ class KeyFrameDatabase(object):
 
     def attach_ids(self, frame_ids):
         self.frame_ids = frame_ids if self.frame_ids is None else torch.cat([self.frame_ids, frame_ids], dim=0)
+        self.frame_ids_dev = self.frame_ids.to(self.device)      # device twin: no H2D copy per sampling call
 
     def add_keyframe(self, batch, filter_depth=False):
         first = bool(batch["frame_id"] == 0)
@@ -80,9 +83,9 @@ class KeyFrameDatabase(object):
     def sample_global_rays(self, bs):
         num_kf = self.__len__()
         if self.device_sampling:
-            idxs = torch.randperm(num_kf * self.num_rays_to_save, device=self.rays.device)[:bs]
+            idxs = _lib.random_subset(num_kf * self.num_rays_to_save, bs, self.rays.device)
             sample_rays = self.rays[:num_kf].reshape(-1, 7)[idxs]
-            frame_ids = self.frame_ids.to(idxs.device)[idxs // self.num_rays_to_save]
+            frame_ids = self.frame_ids_dev[idxs // self.num_rays_to_save]
             return sample_rays, frame_ids
         idxs = torch.tensor(random.sample(range(num_kf * self.num_rays_to_save), bs))
         sample_rays = self.rays[:num_kf].reshape(-1, 7)[idxs.to(self.rays.device)]

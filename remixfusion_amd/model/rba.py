@@ -8,38 +8,55 @@ import torch
 import torch.nn as nn
 
 
+_LEVI = None
+
+
+def _skew(v: torch.Tensor) -> torch.Tensor:
+    """[N,3] -> [N,3,3] cross-product matrices with one matmul against the Levi-Civita tensor."""
+    global _LEVI
+    if _LEVI is None or _LEVI.device != v.device or _LEVI.dtype != v.dtype:
+        e = torch.zeros(3, 3, 3, dtype=v.dtype)
+        e[0, 1, 2] = e[1, 2, 0] = e[2, 0, 1] = -1.0      # skew(v)[i,j] = -eps_ijk v_k
+        e[0, 2, 1] = e[2, 1, 0] = e[1, 0, 2] = 1.0
+        _LEVI = e.to(v.device)
+    return torch.matmul(v, _LEVI.reshape(9, 3).t()).reshape(-1, 3, 3)
+
+
 def angle_axis_to_rotation_matrix(aa: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """Rodrigues with a first-order branch below theta^2 = eps. aa [N,3] -> [N,3,3]."""
-    theta2 = (aa * aa).sum(-1)
+    """Rodrigues R = cos(t) I + sin(t) [w]x + (1-cos(t)) w w^T with w = aa/(t+eps), and the first-order
+    branch I + [aa]x below t^2 = eps (kornia 0.6.12 semantics), in a dozen tensor ops.  aa [N,3]."""
+    theta2 = (aa * aa).sum(-1, keepdim=True)
     theta = torch.sqrt(theta2)
-    w = aa / (theta[:, None] + eps)
-    wx, wy, wz = w[:, 0], w[:, 1], w[:, 2]
-    c, s = torch.cos(theta), torch.sin(theta)
-    k = 1.0 - c
-    R = torch.stack([c + wx * wx * k, wx * wy * k - wz * s, wy * s + wx * wz * k,
-                     wz * s + wx * wy * k, c + wy * wy * k, -wx * s + wy * wz * k,
-                     -wy * s + wx * wz * k, wx * s + wy * wz * k, c + wz * wz * k], -1).view(-1, 3, 3)
-    rx, ry, rz = aa[:, 0], aa[:, 1], aa[:, 2]
-    one = torch.ones_like(rx)
-    T = torch.stack([one, -rz, ry, rz, one, -rx, -ry, rx, one], -1).view(-1, 3, 3)
-    return torch.where((theta2 > eps)[:, None, None], R, T)
+    w = aa / (theta + eps)
+    c, s = torch.cos(theta)[..., None], torch.sin(theta)[..., None]
+    eye = torch.eye(3, dtype=aa.dtype, device=aa.device)
+    R = c * eye + s * _skew(w) + (1.0 - c) * (w[:, :, None] * w[:, None, :])
+    T = eye + _skew(aa)
+    return torch.where((theta2 > eps)[..., None], R, T)
 
 
 def rotation_matrix_to_angle_axis(R: torch.Tensor) -> torch.Tensor:
-    """[N,3,3] -> [N,3] via the quaternion (w>=0 branch selection), like kornia's composition."""
+    """[N,3,3] -> [N,3].  Same map as kornia's (matrix -> quaternion -> angle-axis) but evaluated from
+    the antisymmetric part, which stays accurate for small rotations; the quaternion/diagonal form is
+    only used next to pi where sin(theta) vanishes."""
     m = R
-    tr = m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]
-    qw = torch.sqrt(torch.clamp(1.0 + tr, min=1e-12)) / 2.0
-    qx = torch.sqrt(torch.clamp(1.0 + m[:, 0, 0] - m[:, 1, 1] - m[:, 2, 2], min=1e-12)) / 2.0
-    qy = torch.sqrt(torch.clamp(1.0 - m[:, 0, 0] + m[:, 1, 1] - m[:, 2, 2], min=1e-12)) / 2.0
-    qz = torch.sqrt(torch.clamp(1.0 - m[:, 0, 0] - m[:, 1, 1] + m[:, 2, 2], min=1e-12)) / 2.0
-    qx = torch.copysign(qx, m[:, 2, 1] - m[:, 1, 2])
-    qy = torch.copysign(qy, m[:, 0, 2] - m[:, 2, 0])
-    qz = torch.copysign(qz, m[:, 1, 0] - m[:, 0, 1])
-    sin_half = torch.sqrt(qx * qx + qy * qy + qz * qz)
-    angle = 2.0 * torch.atan2(sin_half, qw)
-    scale = torch.where(sin_half > 1e-8, angle / sin_half.clamp_min(1e-12), torch.full_like(angle, 2.0))
-    return torch.stack([qx * scale, qy * scale, qz * scale], -1)
+    v = 0.5 * torch.stack([m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1]], -1)
+    s = v.norm(dim=-1)
+    c = 0.5 * (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1.0)
+    theta = torch.atan2(s, c)
+    small = s < 1e-4
+    scale = torch.where(small, 1.0 + theta * theta / 6.0, theta / s.clamp_min(1e-12))
+    aa = v * scale[:, None]
+    near_pi = small & (c < 0)
+    if bool(near_pi.any()):
+        d = torch.stack([m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]], -1)
+        axis = torch.sqrt(torch.clamp((d + 1.0) / 2.0, min=0.0))          # |w_i| from R = 2 w w^T - I at theta = pi
+        k = axis.argmax(-1)
+        sign = torch.sign(torch.gather(m, 1, k[:, None, None].expand(-1, 1, 3)).squeeze(1) + 1e-20)   # row k fixes the signs
+        axis = axis * sign
+        axis = axis / axis.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        aa = torch.where(near_pi[:, None], axis * theta[:, None], aa)
+    return aa
 
 
 def make_c2w(r, t):
@@ -86,8 +103,9 @@ class RBA(nn.Module):
         if not isinstance(cam_id, torch.Tensor):
             if cam_id == 0:
                 return self.init_c2w[0]
-            cam_id = torch.tensor([[cam_id]])
-        cam_id = cam_id.to(self.init_c2w.device)
+            cam_id = torch.tensor([[cam_id]], device=self.init_c2w.device)
+        if cam_id.device != self.init_c2w.device:
+            cam_id = cam_id.to(self.init_c2w.device)
         x = (cam_id.type_as(self.init_c2w) / self.num_cams) * 2 - 1
         idx = cam_id.reshape(-1)
         init_r, init_t = self.init_r[idx], self.init_t[idx]

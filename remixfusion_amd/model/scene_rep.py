@@ -29,6 +29,16 @@ from .utils import batchify, compute_loss, get_sdf_loss
 
 
 # ------------------------------------------------------------------------------ autograd glue
+def _field_backward_staged(lib, desc, x, n, draw, dt, dws, dx, ws, st):
+    """the four stages of rfx_field_backward as separate calls (identical kernels; separately timeable)."""
+    wb = ws.numel() * 4
+    check(lib.rfx_field_backward_chain(C.byref(desc), ptr(x), n, ptr(draw), ptr(ws), wb, st), "rfx_field_backward_chain")
+    check(lib.rfx_field_backward_weights(n, ptr(draw), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]), ptr(dws[3]), ptr(ws), wb, st),
+          "rfx_field_backward_weights")
+    check(lib.rfx_field_backward_scatter(C.byref(desc), ptr(x), n, ptr(dt), ptr(dx), ptr(ws), wb, st), "rfx_field_backward_scatter")
+    check(lib.rfx_field_backward_dx(C.byref(desc), ptr(x), n, ptr(draw), ptr(dx), ptr(ws), wb, st), "rfx_field_backward_dx")
+
+
 class _FieldFn(torch.autograd.Function):
     """raw4 = Q1(x01) (scene_rep.py:314-349) with grads for hash table, MLP weights and x01."""
 
@@ -56,9 +66,7 @@ class _FieldFn(torch.autograd.Function):
         dws = [torch.zeros_like(w) if nd else None for w, nd in zip((w1, w2, w3, w4), need[2:6])]
         ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n), x.device)
         desc = model._field_desc(ctx.clamp)
-        check(lib.rfx_field_backward(C.byref(desc), ptr(x), n, ptr(draw.contiguous()), ptr(dt), ptr(dws[0]), ptr(dws[1]),
-                                     ptr(dws[2]), ptr(dws[3]), ptr(dx), ptr(ws), ws.numel() * 4, stream_ptr(x.device)),
-              "rfx_field_backward")
+        _field_backward_staged(lib, desc, x, n, draw.contiguous(), dt, dws, dx, ws, stream_ptr(x.device))
         return dx, dt, dws[0], dws[1], dws[2], dws[3], None, None
 
 
@@ -81,7 +89,7 @@ class _RayPointsFn(torch.autograd.Function):
     def backward(ctx, dx01):
         (z,) = ctx.saved_tensors
         n, S = z.shape
-        dp = dx01.view(n, S, 3) / ctx.model._extent32.to(dx01.device)
+        dp = dx01.view(n, S, 3) / ctx.model._extent_on(dx01.device)
         go = dp.sum(1) if ctx.needs_input_grad[0] else None
         gd = (dp * z[..., None]).sum(1) if ctx.needs_input_grad[1] else None
         return go, gd, None, None
@@ -185,11 +193,10 @@ class _MappingFn(torch.autograd.Function):
         dws = [torch.zeros_like(w) if nd else None for w, nd in zip((w1, w2, w3, w4), need[5:9])]
         ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
         desc = model._field_desc(ctx.clamp)
-        check(lib.rfx_field_backward(C.byref(desc), ptr(x01), n * S, ptr(d_raw), ptr(dt), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]),
-                                     ptr(dws[3]), ptr(dx), ptr(ws), ws.numel() * 4, st), "rfx_field_backward")
+        _field_backward_staged(lib, desc, x01, n * S, d_raw, dt, dws, dx, ws, st)
         go = gd = None
         if want_dx:
-            dp = dx.view(n, S, 3) / model._extent32.to(dev)
+            dp = dx.view(n, S, 3) / model._extent_on(dev)
             go = dp.sum(1) if need[0] else None
             gd = (dp * z[..., None]).sum(1) if need[1] else None
         return go, gd, None, None, dt, dws[0], dws[1], dws[2], dws[3], None, None
@@ -218,6 +225,14 @@ class JointEncoding(nn.Module):
         self._bbox_f64 = 1 if bb.dtype == torch.float64 else 0
         self._bbox6 = farr(_D6, bb.to(torch.float64).reshape(-1).tolist())
         self._extent32 = (bb[:, 1] - bb[:, 0]).to(torch.float32)
+        self._extent_dev = {}
+
+    def _extent_on(self, device) -> torch.Tensor:
+        """bound extent as an fp32 tensor on ``device`` (cached: an H2D copy here would sync every backward)."""
+        key = str(device)
+        if key not in self._extent_dev:
+            self._extent_dev[key] = self._extent32.to(device)
+        return self._extent_dev[key]
 
     def get_resolution(self):
         """reference :24-37."""

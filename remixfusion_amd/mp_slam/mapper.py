@@ -19,6 +19,30 @@ from .. import _lib
 from .._lib import _F6, _F9, check, farr, ptr, stream_ptr
 
 
+class _WorldRaysFn(torch.autograd.Function):
+    """rays_o = t[ids], rays_d = R[ids] @ d_cam (reference mapper.py:407-409); the backward adds the
+    per-ray gradients per pose with index_add_ instead of autograd's sort-based index_put."""
+
+    @staticmethod
+    def forward(ctx, poses_all, ids, d_cam):
+        K = poses_all.shape[0]
+        ids = torch.remainder(ids, K)                       # -1 = the current frame = last pose
+        P = poses_all[ids]
+        ctx.save_for_backward(ids, d_cam, P)
+        ctx.K = K
+        return P[:, :3, 3].contiguous(), torch.einsum("nij,nj->ni", P[:, :3, :3], d_cam)
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        ids, d_cam, P = ctx.saved_tensors
+        g = torch.zeros((ids.shape[0], 4, 4), dtype=g_d.dtype, device=g_d.device)
+        g[:, :3, :3] = g_d[:, :, None] * d_cam[:, None, :]
+        g[:, :3, 3] = g_o
+        gp = torch.zeros((ctx.K, 4, 4), dtype=g_d.dtype, device=g_d.device)
+        gp.index_add_(0, ids, g)
+        return gp, None, None
+
+
 class Mapper:
     def __init__(self, config, SLAM, model) -> None:
         self.config, self.slam, self.model = config, SLAM, model
@@ -93,7 +117,7 @@ class Mapper:
         ret = loss = None
         for _ in range(n_iters):
             self.map_optimizer.zero_grad()
-            indice = (torch.randperm(H * W, device=self.device)[:n_s] if self.keyframe.device_sampling
+            indice = (_lib.random_subset(H * W, n_s, self.device) if self.keyframe.device_sampling
                       else self.slam.select_samples(H, W, n_s).to(self.device))
             indice_h, indice_w = indice % H, indice // H        # (sic) reference :338
             rays_d_cam = direction[indice_h, indice_w, :]
@@ -115,7 +139,7 @@ class Mapper:
         n_cur = max(m["sample"] // len(self.keyframe.frame_ids), m["min_pixels_cur"])
         hw = self.slam.dataset.H * self.slam.dataset.W
         if self.keyframe.device_sampling:
-            idx_cur = torch.randperm(hw, device=current_rays.device)[:n_cur]
+            idx_cur = _lib.random_subset(hw, n_cur, current_rays.device)
         else:
             idx_cur = torch.as_tensor(random.sample(range(0, hw), n_cur), device=current_rays.device)
         cur = current_rays[idx_cur, :]
@@ -126,21 +150,19 @@ class Mapper:
 
     @staticmethod
     def _world_rays(rays, ids_all, poses_all):
-        rays_d_cam = rays[..., :3]
-        rays_d = torch.sum(rays_d_cam[..., None, None, :] * poses_all[ids_all, None, :3, :3], -1)
-        rays_o = poses_all[ids_all, None, :3, -1].repeat(1, rays_d.shape[1], 1).reshape(-1, 3)
-        return rays_o, rays_d.reshape(-1, 3), rays[..., 3:6], rays[..., 6:7]
+        rays_o, rays_d = _WorldRaysFn.apply(poses_all, ids_all, rays[..., :3].contiguous())
+        return rays_o, rays_d, rays[..., 3:6], rays[..., 6:7]
 
     def global_mapping(self, batch, cur_frame_id):
         """map update over all keyframes + the current frame (reference :366-423)."""
         m = self.config["mapping"]
-        poses = torch.stack([self.est_c2w_data[i] for i in range(0, cur_frame_id + 1, m["keyframe_every"])])
+        poses = self.est_c2w_data[0:cur_frame_id + 1:m["keyframe_every"]].clone()
         self.map_optimizer.zero_grad()
         self.rba_optimizer.zero_grad()
         current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
         with torch.no_grad():
-            last_kf_id = (torch.tensor(cur_frame_id) // m["keyframe_every"]).long().unsqueeze(-1).unsqueeze(-1)
+            last_kf_id = torch.full((1, 1), cur_frame_id // m["keyframe_every"], dtype=torch.int64, device=self.device)
             poses_all = poses
             poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze().clone()
         for i in range(m["iters"]):
@@ -158,13 +180,13 @@ class Mapper:
     def global_pose(self, batch, cur_frame_id):
         """pose (RBA-MLP) update with the map frozen (reference :425-520)."""
         m = self.config["mapping"]
-        poses = torch.stack([self.est_c2w_data[i] for i in range(0, cur_frame_id, m["keyframe_every"])])
-        frame_ids_all = torch.tensor(list(range(0, cur_frame_id + 1, m["keyframe_every"])))
+        poses = self.est_c2w_data[0:cur_frame_id:m["keyframe_every"]].clone()
+        frame_ids_all = list(range(0, cur_frame_id + 1, m["keyframe_every"]))
         self.map_optimizer.zero_grad()
         self.rba_optimizer.zero_grad()
         current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
-        all_index = torch.arange(0, poses.shape[0] + 1).unsqueeze(-1)
+        all_index = torch.arange(0, poses.shape[0] + 1, device=self.device).unsqueeze(-1)
         poses_all = self.model.rba(all_index)
         for i in range(m["BA_iters"]):
             rays, ids_all = self._sample_rays(current_rays)
@@ -174,7 +196,7 @@ class Mapper:
             loss.backward(retain_graph=True)
             if (i + 1) % m["pose_accum_step"] == 0 and m["opt_pose"]:
                 self.rba_optimizer.step()
-                poses_all = self.model.rba(torch.arange(0, poses.shape[0] + 1).unsqueeze(-1))
+                poses_all = self.model.rba(all_index)
                 self.map_optimizer.zero_grad()
                 self.rba_optimizer.zero_grad()
         if len(frame_ids_all) > 1 and m["opt_pose"]:

@@ -79,7 +79,8 @@ class MappingPipeline:
             ke = self.config["mapping"]["keyframe_every"]
             if i % ke != 0:     # relative pose to the last keyframe, like the tracker stores it
                 kf = self.slam.est_c2w_data[(i // ke) * ke]
-                self.slam.est_c2w_data_rel[i] = c2w.to(self.device) @ torch.linalg.inv(kf)
+                # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop
+                self.slam.est_c2w_data_rel[i] = c2w.to(self.device) @ torch.linalg.inv_ex(kf).inverse
             self.slam.tracking_idx[0] = i
 
     def step(self, i: int, batch: Dict):
