@@ -22,20 +22,25 @@ __device__ __forceinline__ Level get_level(const rfx_grid_desc& g, int l) {
     return L;
 }
 
-// tiny-cuda-nn grid_index<3>: stride walk with the `stride <= hashmap_size` guard, coherent prime
-// hash when the level does not fit, final `% hashmap_size`; everything wraps at 32 bits.
+// rare path: a dense-level vertex outside the table (points outside the unit cube) wraps modulo the
+// level size; kept out of line so the ~40-instruction u32 modulo is not replicated at every corner.
+__device__ __noinline__ unsigned wrap_index(unsigned idx, unsigned size) { return idx % size; }
+
+// tiny-cuda-nn grid_index<3>.  Its stride walk (`for dim: if stride <= size: index += g*stride`) only
+// ever stops early on levels that end up hashed, so: hashed level -> coherent prime hash, size is a
+// power of two -> mask; dense level -> full x + y*res + z*res^2, wrapped modulo size when out of range.
+// Everything wraps at 32 bits.
 __device__ __forceinline__ unsigned grid_index(const Level& L, unsigned gx, unsigned gy, unsigned gz) {
     unsigned idx;
     if (L.hashed) {
-        idx = gx ^ (gy * 2654435761u) ^ (gz * 805459861u);
+        idx = (gx ^ (gy * 2654435761u) ^ (gz * 805459861u)) & (L.size - 1u);
     } else {
-        unsigned stride = 1;
-        idx = 0;
-        if (stride <= L.size) { idx += gx * stride; stride *= L.res; }
-        if (stride <= L.size) { idx += gy * stride; stride *= L.res; }
-        if (stride <= L.size) { idx += gz * stride; stride *= L.res; }
+        idx = gx + (gy + gz * L.res) * L.res;
+        if (idx >= L.size) idx = wrap_index(idx, L.size);
     }
-    if (idx >= L.size) idx %= L.size;   // in-range dense lookups never take the modulo
+#if defined(FIELD_DBG) && FIELD_DBG == 1
+    idx &= 7;                            // timing experiment: all lanes hit the same line
+#endif
     return idx;
 }
 
@@ -174,15 +179,24 @@ __device__ __forceinline__ float quartic_pdf(float t, float n) {
 
 __device__ __forceinline__ float round_fp16(float v) { return __half2float(__float2half_rn(v)); }
 
-// out[k] for k = 0..NB-1 of one input dim (tcnn one_blob_subwarp_aligned)
+// out[k] for k = 0..NB-1 of one input dim (tcnn one_blob_subwarp_aligned):
+//   out[k] = L(k+1) - L(k),  L(k) = cdf(t) + cdf(t-1) + cdf(t+1),  t = k/NB - x,  L(NB) := L(0) + 1.
+// The kernel radius (1/NB) is far below the copy spacing (1), so at most one of the three copies is
+// unsaturated and the other two are exactly 0 or 1:  L(k) = cdf(t - round(t)) + (1 + round(t)).
+// One polynomial per boundary instead of three (differs from the literal sum by <= 1 ulp of L).
 template <int NB>
 __device__ __forceinline__ void oneblob_dim(float x, bool fp16, float* out) {
+#if defined(FIELD_DBG) && FIELD_DBG == 2
+    for (int k = 0; k < NB; ++k) out[k] = x * (float)k;   // timing experiment: no cdf evaluation
+    return;
+#endif
     const float n = (float)NB;
     float Lk[NB + 1];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const float lb = (float)k / n;   // exact for power-of-two NB
-        Lk[k] = quartic_cdf(lb - x, n) + quartic_cdf(lb - x - 1.0f, n) + quartic_cdf(lb - x + 1.0f, n);
+        const float t = (float)k / n - x;   // k/NB exact for power-of-two NB
+        const float r = (t > 0.5f) ? 1.0f : ((t < -0.5f) ? -1.0f : 0.0f);
+        Lk[k] = quartic_cdf(t - r, n) + (1.0f + r);
     }
     Lk[NB] = Lk[0] + 1.0f;
 #pragma unroll

@@ -47,9 +47,11 @@ __device__ inline float staged_weight(const FieldK& f, int slot, int l) {
         else if (s == 32) k = 63 + h;
         else k = h == 0 ? 65 : -1;
         return k >= 0 ? f.w3[lo * N_IN3 + k] : 0.f;
-    } else if (slot < OFFB4) {               // L4
-        const int k = krow(slot - OFF4, h);
-        return lo < N_OUT4 ? f.w4[lo * N_H + k] : 0.f;
+    } else if (slot < OFFB4) {               // L4 runs on the VALU (3 of 32 rows would be used on the MFMA):
+        const int i = (slot - OFF4) * 64 + l;    //   flat [c][r][h] table: W4[c][krow(r,h)]
+        if (i >= N_OUT4 * 16 * 2) return 0.f;
+        const int c = i / 32, r = (i % 32) / 2, hh = i % 2;
+        return f.w4[c * N_H + krow(r, hh)];
     } else if (slot < OFFB3) {               // B4: dH3[hid] = sum_o W4[o][hid] dY4[o]; k = o = 2s+h
         const int o = 2 * (slot - OFFB4) + h;
         return o < N_OUT4 ? f.w4[o * N_H + lo] : 0.f;
@@ -111,7 +113,9 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
                                                 int lane, Enc& e, Mlp& m, float* x1row = nullptr,
                                                 bool valid = true) {
     m.h1[0] = zero16(); m.h1[1] = zero16();
-#pragma unroll
+    // a real loop (2 levels per trip): level constants are fetched per trip instead of keeping all
+    // 16 x 5 of them live in SGPRs, and the code stays small enough for the instruction cache
+#pragma unroll 2
     for (int s = 0; s < 16; ++s) {
         const float2 v = lookup2(f.table, get_level(f.hash, s), x);
         if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v;
@@ -120,7 +124,6 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         const float w = wl[(OFF1 + s) * 64 + lane];
         m.h1[0] = mfma32(w, a, m.h1[0]);
         m.h1[1] = mfma32(w, b, m.h1[1]);
-        if ((s % HASH_GROUP) == HASH_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) oneblob_dim<16>(x[d], f.pos_fp16 != 0, e.pos + 16 * d);
@@ -172,21 +175,29 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
     }
 }
 
-// layer 4 + residual add -> raw4 of the lane's own point
+// layer 4 + residual add -> raw4 of the lane's own point.  rgb = W4 relu(h3): each lane holds 16 of the
+// 32 hidden units of its tile's point (D layout), so it forms a partial dot product; one
+// v_permlane32_swap per channel brings the two halves of every point together.
 __device__ __forceinline__ void mlp_forward_4(const float* __restrict__ wl, int lane, const Enc& e, const Mlp& m,
                                               float raw[4]) {
-    f32x16 o0 = zero16(), o1 = zero16();
+    const float* __restrict__ w4 = wl + OFF4 * 64;
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float w = wl[(OFF4 + r) * 64 + lane];
-        o0 = mfma32(w, fmaxf(m.h3[0][r], 0.f), o0);
-        o1 = mfma32(w, fmaxf(m.h3[1][r], 0.f), o1);
+        const float a0 = fmaxf(m.h3[0][r], 0.f), a1 = fmaxf(m.h3[1][r], 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float w = w4[(c * 16 + r) * 2 + h];
+            p0[c] = fmaf(a0, w, p0[c]);
+            p1[c] = fmaf(a1, w, p1[c]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float a = o0[c], b = o1[c];
-        swap32(a, b);                 // a = [tile0 lanes<32 | tile1 lanes<32] = own point
-        raw[c] = a + e.ex[c + 1];
+        float a = p0[c], b = p1[c];
+        swap32(a, b);                 // a = lower-half partials of the own point, b = upper-half partials
+        raw[c] = (a + b) + e.ex[c + 1];
     }
     float a = m.h2[0][0], b = m.h2[1][0];
     swap32(a, b);
