@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
 // dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..]
 constexpr int LD_X1 = 96, LD_H = 32, LD_G = 32, LD_DY2 = 16, LD_DX1 = 96;
 constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
-constexpr int DW_BLOCKS = 128;
+constexpr int DW_BLOCKS = 512;
 
 struct BwdWs {
     float *x1, *h1, *dh1, *g, *dy2, *h3, *dh3, *dx1, *partial;
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256) void field_dw_partial_kernel(BwdWs ws, const f
     const int64_t per = (n_pairs + n_w - 1) / n_w;
     const int64_t w_id = (int64_t)blockIdx.x * 4 + wv;
     const int64_t s0 = w_id * per, s1 = std::min<int64_t>(n_pairs, s0 + per);
+#pragma unroll 4
     for (int64_t s = s0; s < s1; ++s) {
         const int64_t pt = 2 * s + h;
         const float dh1 = ldrow(ws.dh1, pt, LD_H, lo, 32, n);

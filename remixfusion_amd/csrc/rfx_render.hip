@@ -303,6 +303,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// sum `v` over the block's 4 waves; result valid in thread 0.  red: 4 doubles of LDS per value.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
 __global__ __launch_bounds__(256) void mapping_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
                                                                    const float* __restrict__ zv, const float* __restrict__ rgb_map,
                                                                    const float* __restrict__ depth_map,
@@ -335,9 +345,12 @@ __global__ __launch_bounds__(256) void mapping_loss_forward_kernel(LossK L, cons
             }
         }
     }
-    a_rgb = wave_sum_d(a_rgb); a_dep = wave_sum_d(a_dep); a_val = wave_sum_d(a_val); a_fs = wave_sum_d(a_fs);
-    a_sdf = wave_sum_d(a_sdf); a_nfs = wave_sum_d(a_nfs); a_nsdf = wave_sum_d(a_nsdf);
-    if (lane == 0) {
+    // one atomic per block and value: a single address only sustains ~90 atomics/us
+    __shared__ double red[4];
+    a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
+    a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
+    a_nsdf = block_sum_d(a_nsdf, red);
+    if (threadIdx.x == 0) {
         atomicAdd(sums + 0, a_rgb); atomicAdd(sums + 1, a_dep); atomicAdd(sums + 2, a_val); atomicAdd(sums + 3, a_fs);
         atomicAdd(sums + 4, a_sdf); atomicAdd(sums + 5, a_nfs); atomicAdd(sums + 6, a_nsdf);
     }
@@ -433,8 +446,9 @@ __global__ __launch_bounds__(256) void tv_forward_kernel(const float* __restrict
         if (y + 1 < P) { const float e = feat[i + (int64_t)P * Cn] - v; acc += (double)(e * e); }
         if (z + 1 < P) { const float e = feat[i + Cn] - v; acc += (double)(e * e); }
     }
-    acc = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+    __shared__ double red[4];
+    acc = block_sum_d(acc, red);
+    if (threadIdx.x == 0) atomicAdd(sum, acc);
 }
 
 // dfeat = (*gscale) * scale * d(sum)/d feat
@@ -592,7 +606,7 @@ int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float
     hipStream_t st = as_stream(stream);
     RFX_HIP_TRY(hipMemsetAsync(sums8, 0, 8 * sizeof(double), st));
     LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
-    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, st, L,
+    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(std::min(ray_grid(n_rays), 128)), dim3(256), 0, st, L,
                        reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, sums8);
     RFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums8, n_rays, S, losses4, coef4);
@@ -622,7 +636,7 @@ int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream str
     hipStream_t st = as_stream(stream);
     RFX_HIP_TRY(hipMemsetAsync(sum1, 0, sizeof(double), st));
     const int64_t total = (int64_t)P * P * P * C;
-    hipLaunchKernelGGL(tv_forward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, st, feat, P, C, sum1);
+    hipLaunchKernelGGL(tv_forward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 256)), dim3(256), 0, st, feat, P, C, sum1);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
