@@ -299,6 +299,18 @@ def main():
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                  "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
                                                  "algorithmic_bytes": int(nbytes), "avg_ms": round(ms, 4)}
+    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+    # summarised by tools/summarize_pmc.py into profiles/r1_pmc_traffic.json); raw counter bytes.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        for rk, kn in (("field_backward_scatter", "rfx::grid_encode_backward_kernel"), ("field_forward", "rfx::field_forward_kernel"),
+                       ("field_backward_chain", "rfx::field_backward_kernel"), ("field_backward_weights", "rfx::field_dw_partial_kernel"),
+                       ("render_rays", "rfx::render_rays_kernel"), ("tsdf_integrate", "void rfx::mv_integrate_kernel<4, 4, 4>")):
+            if rk in extra_rooflines and kn in pmc:
+                extra_rooflines[rk]["traffic"] = int(pmc[kn]["hbm_bytes_raw"])
+                extra_rooflines[rk]["traffic_source"] = "profiles/r1_pmc_traffic.json (FETCH_SIZE+WRITE_SIZE, raw)"
+    except Exception:
+        pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
            "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
            "rfx_tsdf_integrate": "tsdf_integrate"}.get(dominant)
