@@ -306,6 +306,7 @@ def main():
         for rk, kn in (("field_backward_scatter", "rfx::grid_encode_backward_kernel"), ("field_forward", "rfx::field_forward_kernel"),
                        ("field_backward_chain", "rfx::field_backward_kernel"), ("field_backward_weights", "rfx::field_dw_partial_kernel"),
                        ("render_rays", "rfx::render_rays_kernel"), ("tsdf_integrate", "void rfx::mv_integrate_kernel<4, 4, 4>")):
+            kn = next((k for k in pmc if k.startswith(kn.split("<")[0])), kn)
             if rk in extra_rooflines and kn in pmc:
                 extra_rooflines[rk]["traffic"] = int(pmc[kn]["hbm_bytes_raw"])
                 extra_rooflines[rk]["traffic_source"] = "profiles/r1_pmc_traffic.json (FETCH_SIZE+WRITE_SIZE, raw)"

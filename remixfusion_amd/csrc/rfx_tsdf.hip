@@ -18,7 +18,7 @@
 #include <algorithm>
 
 #ifndef MV_TX
-#define MV_TX 4
+#define MV_TX 2
 #endif
 #ifndef MV_TY
 #define MV_TY 4
@@ -45,6 +45,9 @@ struct MvParams {
     int   literal_all;    // 1: every voxel decodes literally (conditions for the split not met)
     float ratio_eps;      // bound on |cam_norm/(lambda*cam_z) - 1| from pixel rounding
     int   dimg_colmajor;  // 1: the packed {depth,1/lambda} image is stored [x][y] (see prepass)
+    // up to three disjoint windows of (x,y) tiles: [0] the frustum footprint (host AABB), [1],[2] the
+    // first / last tile rows in y, which hold the literally-decoded boundary rows and are always walked
+    int   win_x0[3], win_y0[3], win_wx[3], win_wy[3];
 };
 
 // ---------------------------------------------------------------------------- prepass
@@ -210,11 +213,15 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
     static_assert(ROWS <= 64, "tile must fit one wave");
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int tiles_y = (P.dy + TY - 1) / TY;
-    const int tiles_x = (P.dx + TX - 1) / TX;
-    if (wave >= tiles_x * tiles_y) return;
-    const int x0 = (wave / tiles_y) * TX;
-    const int y0 = (wave % tiles_y) * TY;
+    int t = wave, wi = 0;
+    for (; wi < 3; ++wi) {
+        const int cnt = P.win_wx[wi] * P.win_wy[wi];
+        if (t < cnt) break;
+        t -= cnt;
+    }
+    if (wi == 3) return;
+    const int x0 = (P.win_x0[wi] + t / P.win_wy[wi]) * TX;
+    const int y0 = (P.win_y0[wi] + t % P.win_wy[wi]) * TY;
 
     // ---- per-row conservative z interval (lane r < ROWS owns row r of the tile)
     int z0 = 0, z1 = 0;
@@ -645,7 +652,42 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
                        dmax_bits, H, W, K[0], K[4], K[2], K[5], P.dimg_colmajor);
     RFX_LAUNCH_CHECK();
     constexpr int TX = MV_TX, TY = MV_TY, U = MV_U;
-    const int64_t tiles = (int64_t)((dx + TX - 1) / TX) * ((dy + TY - 1) / TY);
+    // Window of tiles the view frustum can touch: the frustum is convex, so its (x,y) footprint lies in
+    // the bounding box of the apex and the four corner rays pushed past the far side of the volume.
+    // Rows that decode literally may alias to other cells, so the window is only used when none do.
+    int tx0 = 0, ty0 = 0, tx1 = (dx + TX - 1) / TX, ty1 = (dy + TY - 1) / TY;
+    if (!P.literal_all) {
+        const float ext = voxel * sqrtf((float)dx * dx + (float)dy * dy + (float)dz * dz);
+        const float far = 2.0f * ext + 2.0f * (fabsf(c2w[3] - origin[0]) + fabsf(c2w[7] - origin[1]) + fabsf(c2w[11] - origin[2]));
+        float lo[2] = {c2w[3], c2w[7]}, hi[2] = {c2w[3], c2w[7]};
+        for (int cidx = 0; cidx < 4; ++cidx) {
+            const float u = (cidx & 1) ? (float)W + 1.0f : -2.0f, v = (cidx & 2) ? (float)H + 1.0f : -2.0f;
+            const float rx = (u - K[2]) / K[0], ry = (v - K[5]) / K[4];
+            for (int a = 0; a < 2; ++a) {
+                const float wv = c2w[4 * a + 3] + far * (c2w[4 * a + 0] * rx + c2w[4 * a + 1] * ry + c2w[4 * a + 2]);
+                lo[a] = fminf(lo[a], wv); hi[a] = fmaxf(hi[a], wv);
+            }
+        }
+        const float pad = 2.0f * voxel;
+        const int vx0 = (int)floorf((lo[0] - pad - P.origin[0]) / voxel), vx1 = (int)ceilf((hi[0] + pad - P.origin[0]) / voxel);
+        const int vy0 = (int)floorf((lo[1] - pad - P.origin[1]) / voxel), vy1 = (int)ceilf((hi[1] + pad - P.origin[1]) / voxel);
+        tx0 = std::max(0, std::min(tx1, vx0 / TX)); ty0 = std::max(0, std::min(ty1, vy0 / TY));
+        tx1 = std::max(tx0, std::min(tx1, vx1 / TX + 1)); ty1 = std::max(ty0, std::min(ty1, vy1 / TY + 1));
+    }
+    const int all_tx = (dx + TX - 1) / TX, all_ty = (dy + TY - 1) / TY;
+    for (int i = 0; i < 3; ++i) { P.win_x0[i] = P.win_y0[i] = P.win_wx[i] = P.win_wy[i] = 0; }
+    if (P.risky_rows > 0 && !P.literal_all) {
+        // boundary strips (all x): tile rows [0, s) and [all_ty - s, all_ty); the main window is clipped to what is left
+        const int s_rows = std::min((P.risky_rows + TY - 1) / TY, all_ty / 2);
+        P.win_x0[1] = 0; P.win_y0[1] = 0; P.win_wx[1] = all_tx; P.win_wy[1] = s_rows;
+        P.win_x0[2] = 0; P.win_y0[2] = all_ty - s_rows; P.win_wx[2] = all_tx; P.win_wy[2] = s_rows;
+        ty0 = std::max(ty0, s_rows); ty1 = std::min(ty1, all_ty - s_rows);
+        if (ty1 < ty0) ty1 = ty0;
+    }
+    P.win_x0[0] = tx0; P.win_y0[0] = ty0; P.win_wx[0] = tx1 - tx0; P.win_wy[0] = ty1 - ty0;
+    int64_t tiles = 0;
+    for (int i = 0; i < 3; ++i) tiles += (int64_t)P.win_wx[i] * P.win_wy[i];
+    if (tiles == 0) return RFX_OK;
     const int blocks = (int)((tiles + 3) / 4);
     hipLaunchKernelGGL((mv_integrate_kernel<TX, TY, U>), dim3(blocks), dim3(256), 0, st, P, dimg, dmax_bits,
                        color_packed, tsdf, weight, color);

@@ -137,13 +137,15 @@ class SLAM:
         volume = bb[:, 1] - bb[:, 0]
         grid_size = (sample_points - 1) * voxel_size
         offset_max = bb[:, 1] - bb[:, 0] - grid_size - 2 * margin
-        offset = torch.rand(3, device=offset_max.device, dtype=offset_max.dtype) * offset_max + margin
+        # torch.rand is fp32 and then cast like the reference's `.to(offset_max)` / `.to(volume)`: with an
+        # all-integer mapping.bound `volume` is int64 and the lattice jitter truncates to 0 (reference quirk)
+        offset = torch.rand(3, device=offset_max.device).to(offset_max.dtype) * offset_max + margin
         P = sample_points - 1
         if P not in self._tv_coords:
             ar = torch.arange(0, P, dtype=torch.long, device=self.device)
             self._tv_coords[P] = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).float()
         coords = self._tv_coords[P].to(volume)
-        pts = (coords + torch.rand((1, 1, 1, 3), device=volume.device, dtype=volume.dtype)) * voxel_size + bb[:, 0] + offset
+        pts = (coords + torch.rand((1, 1, 1, 3), device=volume.device).to(volume.dtype)) * voxel_size + bb[:, 0] + offset
         pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0]) if self.config["grid"]["tcnn_encoding"] else pts
         return _SmoothFn.apply(self.model.embed_res_fn.params, pts_tcnn, self.model.embed_res_fn, P, float(sample_points ** 3))
 

@@ -367,10 +367,10 @@ def test_fused_mapping_node_equals_unfused_path_and_tv_node():
     bb = slam.bounding_box
     P = tr["smooth_pts"] - 1
     offset_max = bb[:, 1] - bb[:, 0] - P * tr["smooth_vox"] - 2 * tr["smooth_margin"]
-    offset = torch.rand(3, device="cuda", dtype=offset_max.dtype) * offset_max + tr["smooth_margin"]
+    offset = torch.rand(3, device="cuda").to(offset_max.dtype) * offset_max + tr["smooth_margin"]
     ar = torch.arange(0, P, device="cuda")
     coords = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).to(bb)
-    pts = (coords + torch.rand((1, 1, 1, 3), device="cuda", dtype=bb.dtype)) * tr["smooth_vox"] + bb[:, 0] + offset
+    pts = (coords + torch.rand((1, 1, 1, 3), device="cuda").to(bb.dtype)) * tr["smooth_vox"] + bb[:, 0] + offset
     pts01 = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0])
     m.embed_res_fn.params.grad = None
     tv_ref = slam.smoothness_unfused(pts01, tr["smooth_pts"])

@@ -21,7 +21,9 @@ for i in range(1, nf):
     pipe.step(i, frames[i])
 torch.cuda.synchronize()
 dt = time.time() - t0
-print(f"{nf - 1} frames in {dt:.3f}s -> {(nf - 1) / dt:.1f} fps; mapping_idx {int(pipe.slam.mapping_idx[0])}")
+print(f"{nf - 1} frames in {dt:.3f}s -> {(nf - 1) / dt:.1f} fps; mapping_idx {int(pipe.slam.mapping_idx[0]) if pipe.slam else None}")
+if pipe.slam is None:
+    print("tsdf-only: updated voxels", int((pipe.mv.weight_vol_gpu > 0).sum())); sys.exit(0)
 m = pipe.model
 m.train()
 with torch.no_grad():
