@@ -381,3 +381,36 @@ def test_fused_mapping_node_equals_unfused_path_and_tv_node():
     fp = _oracle_params(cfg, m)
     feat = FO.grid_encode(pts01.reshape(-1, 3).float().cpu(), fp.hash_table, fp.hash_meta).reshape(P, P, P, 32)
     _close(tv, FO.smoothness_from_features(feat, tr["smooth_pts"]), 1e-4, 1e-9, "TV vs oracle")
+
+
+def test_mapping_pipeline_learns_the_scene():
+    """end-to-end sanity on a small synthetic stream: the mapping schedule drives the rendered depth /
+    colour error down (quality smoke test; thresholds are loose on purpose)."""
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+    cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+    cfg["mapping"].update({"first_iters": 100, "sample": 512})
+    cfg["synthetic"].update({"depth_noise": 0.0, "dropout": 0.0})
+    pipe = MappingPipeline(cfg, n_frames=40, seed=1)
+    frames = pipe.prefetch(list(range(31)))
+
+    def err(i):
+        b = frames[i]
+        pipe.model.train()
+        with torch.no_grad():
+            rgb, dep = pipe.slam.render_single(i, b["depth"][None], b["rgb"][None], b["c2w"], b["direction"])
+        return float((dep - b["depth"]).abs().mean()), float((rgb - b["rgb"]).abs().mean())
+
+    pipe.track_frame(0, frames[0])
+    pipe.mapper.init_mapvolume()
+    d0, c0 = err(0)                                    # untrained field on an empty global volume
+    pipe.mapper.first_frame_mapping({k: v for k, v in frames[0].items() if k != "rgb255"}, cfg["mapping"]["first_iters"])
+    d1, c1 = err(0)
+    for i in range(1, 31):
+        pipe.step(i, frames[i])
+    d2, c2 = err(25)                                   # a later frame, seen only through the keyframe schedule
+    assert d1 < 0.5 * d0 and c1 < 0.7 * c0, (d0, d1, c0, c1)
+    assert d2 < 0.10 and c2 < 0.12, (d2, c2)
+    assert int(pipe.slam.mapping_idx[0]) == 25
