@@ -257,6 +257,32 @@ int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const fl
                     const double bbox[6], int bbox_f64, float sc_factor, float* rgb, float* depth,
                     rfx_stream stream);
 
+/* ======================================================================================
+ * Tracker kernels of the random-optimisation pose search (model/ROtracker.py), SURVEY 8(f1).
+ * ==================================================================================== */
+
+/* T1: replaces `compute_vertex` model/ROtracker.py:272-344 (host :426-451).  depth dev [H*W] ->
+ * vertex4 dev [H*W,4] = back-projected (x,y,z) of depth + per-row jitter, and the target tsdf.
+ * The reference draws the jitter from cuRAND (curand_init(seed,row,0)); here u_rows dev [H,2]
+ * supplies the two uniforms per row, or (NULL) a counter-based hash of (seed,row) does.  With
+ * RO.sample_range = 0 (every shipped config) the jitter is exactly 0. */
+int rfx_track_vertex(const float* depth, float* vertex4, const float K[9], int H, int W, float cut_dist, float trunc,
+                     float sample_range, uint32_t seed, const float* u_rows, rfx_stream stream);
+
+/* T2: replaces `compute_normal` model/ROtracker.py:346-403 (host :453-468): central-difference
+ * normals, flipped towards the camera; border pixels are not written (caller zero-fills once). */
+int rfx_track_normal(const float* vertex4, float* normal3, int H, int W, rfx_stream stream);
+
+/* T3: replaces `compute_tsdf_value` model/ROtracker.py:144-270 (host :536-604).  For each of the
+ * n_candidates pose perturbations q6 dev [n,6] (translation, quaternion vector part; scaled by
+ * search_size[6], host) around the pose (R[9] row-major, T[3], host): sum over the sub-sampled pixels
+ * (stride `level`, offset `level_index`) of |tsdf(nearest voxel of the transformed vertex) - target|
+ * into value dev [n], hit count into count dev [n] (both overwritten). */
+int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float origin[3], float voxel,
+                       const float* vertex4, const float* normal3, const float R[9], const float T[3],
+                       const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
+                       int level, int level_index, float* value, float* count, rfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ class TsdfOracle:
         L.orc_gbv_integrate.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F,
                                         C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(Counts)]
         L.orc_gbv_clear.argtypes = [_F, C.c_int64]
+        L.orc_tr_vertex.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F, _F]
+        L.orc_tr_normal.argtypes = [_F, _F, C.c_int, C.c_int]
+        L.orc_tr_evaluate.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, C.c_float, _F, _F, _F, _F, _F, _F, C.c_int, _F,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
         L.orc_fma_mode.restype = C.c_int
         assert L.orc_fma_mode() == int(fma)
 
@@ -94,6 +98,31 @@ class TsdfOracle:
 
     def mv_copy(self, src3, dst3):
         self.lib.orc_mv_copy(src3[0], src3[1], src3[2], dst3[0], dst3[1], dst3[2], src3[0].size)
+
+    # -- tracker -----------------------------------------------------------------------------
+    def tr_vertex(self, depth, K, cut_dist, trunc, sample_range, u_rows):
+        H, W = depth.shape
+        out = np.zeros((H * W, 4), np.float32)
+        u = np.ascontiguousarray(u_rows, np.float32)
+        self.lib.orc_tr_vertex(np.ascontiguousarray(depth, np.float32).reshape(-1), out,
+                               np.ascontiguousarray(K, np.float32).reshape(-1), H, W, float(cut_dist), float(trunc),
+                               float(sample_range), np.ascontiguousarray(u[:, 0]), np.ascontiguousarray(u[:, 1]))
+        return out
+
+    def tr_normal(self, vertex4, H, W):
+        out = np.zeros((H * W, 3), np.float32)
+        self.lib.orc_tr_normal(np.ascontiguousarray(vertex4, np.float32), out, H, W)
+        return out
+
+    def tr_evaluate(self, tsdf, dims, origin, voxel, vertex4, normal3, R, T, q6, ss, K, H, W, level, level_index):
+        P = q6.shape[0]
+        val, cnt = np.zeros(P, np.float32), np.zeros(P, np.float32)
+        self.lib.orc_tr_evaluate(tsdf, int(dims[0]), int(dims[1]), int(dims[2]), np.ascontiguousarray(origin, np.float32),
+                                 float(voxel), np.ascontiguousarray(vertex4, np.float32), np.ascontiguousarray(normal3, np.float32),
+                                 np.ascontiguousarray(R, np.float32).reshape(-1), np.ascontiguousarray(T, np.float32),
+                                 np.ascontiguousarray(q6, np.float32), np.ascontiguousarray(ss, np.float32), P,
+                                 np.ascontiguousarray(K, np.float32).reshape(-1), H, W, int(level), int(level_index), val, cnt)
+        return val, cnt
 
     # -- GBV ---------------------------------------------------------------------------------
     def gbv_integrate(self, trgb, w, res, box, K, c2w, rgb01, depth, trunc, obs_weight=1.0,

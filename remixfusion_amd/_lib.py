@@ -81,6 +81,9 @@ PROTOTYPES = {
     "rfx_tv_forward": (_i, [_P, _i, _i, _P, _P]),
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
     "rfx_random_subset": (_i, [C.c_uint64, _l, _l, _P, _P]),
+    "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
+    "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
+    "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
     "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),
 }
 

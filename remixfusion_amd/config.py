@@ -83,7 +83,10 @@ _BASE: Dict[str, Any] = {   # values of configs/Replica/replica.yaml
     "volume": {"voxel_size": 0.01, "version": "center", "trunc": 0.05, "weight_threshold": 2.0, "weight_clamp": 1.0,
                "t_treshold": 1, "x_config": _axis(4), "y_config": _axis(4), "z_config": _axis(3),
                "first_len": 4, "second_len": 4, "third_len": 3, "more_angel_t": 20},
-    "RO": {"cut": 0, "cut_dist": 8.0},
+    "RO": {"init_size": 0.02, "scaling_coefficient": 0.09, "particle_iter_lens": 20, "PST_size": [10240, 3072, 1024],
+           "PST_seed": 20251205, "count_search": 200, "fix_level_index": 0, "filter_weight": 2, "rgb_rose": 0,
+           "save_volume": 0, "save_freq": 1000, "cut": 0, "cut_dist": 8.0, "sample_range": 0.0, "iterative_scale": True},
+    "tracking": {"ignore_edge_W": 20, "ignore_edge_H": 20, "const_speed": True},
     "video": {"save": False, "save_freq": 20},
     "synthetic": {"room": [[-2.8, 2.8], [-3.6, 2.1], [-1.5, 1.5]], "n_frames": 600, "seed": 20251205,
                   "depth_noise": 0.002, "dropout": 0.05, "pose_opt": True},

@@ -1,0 +1,259 @@
+"""ROTracker: gradient-free pose tracking by randomised (particle-swarm) optimisation against the
+moving TSDF volume.  Host-side mirror of the reference ``model/ROtracker.py:33-971`` with its three
+PyCUDA kernels replaced by librfx (``rfx_track_vertex / _normal / _evaluate``).
+
+Differences, on purpose:
+  * the pre-sampled particle templates ("PST", 60 float TIFFs under PFO/ in the reference, read with
+    cv2) are generated here from a seeded sampler with the same structure -- row 0 is the null
+    perturbation, the rest fill the 6-D unit ball, ordered by decreasing norm (``make_pst``);
+  * ``cal_transform``'s python loop over up to 10 240 candidates is vectorised with numpy (same
+    selection: the first ``count_search`` candidates that beat candidate 0, same weights);
+  * compute_vertex's cuRAND jitter is replaced by a counter-based hash (exactly zero anyway for
+    RO.sample_range = 0, which every reference config uses);
+  * mesh dumps (RO.save_volume) are CPU debug I/O and not built.
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import _F3, _F6, _F9, check, farr, ptr, stream_ptr
+from .traj import Trajectory
+from .Volume import moving_volume
+
+
+def make_pst(n: int, seed: int) -> np.ndarray:
+    """[n,6] particle template: origin first, then points uniform in the 6-D unit ball, farthest first."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n - 1, 6))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    r = rng.uniform(0.0, 1.0, (n - 1, 1)) ** (1.0 / 6.0)
+    pts = g * r
+    pts = pts[np.argsort(-np.linalg.norm(pts, axis=1))]
+    return np.concatenate([np.zeros((1, 6)), pts], 0).astype(np.float32)
+
+
+class ROTracker(object):
+    def __init__(self, cfg, data_stream, device=None) -> None:
+        self.cfg = cfg
+        ro = cfg["RO"]
+        self.data_stream = data_stream
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.estimate_pose = []
+        self.larger_flag = False
+        self.init_size = ro["init_size"]
+        self.scaling_coefficient = ro["scaling_coefficient"]
+        self.particle_iter_lens = ro["particle_iter_lens"]
+        self.PST_size = ro["PST_size"]
+        self.fix_level_index = ro["fix_level_index"]
+        self.count_search = ro["count_search"]
+        self.filter_weight = ro["filter_weight"]
+        self.cut, self.cut_dist = ro["cut"], ro["cut_dist"]
+        self.truncation = cfg["volume"]["trunc"]
+        self.sample_range = ro["sample_range"]
+        self.iterative_scale = ro["iterative_scale"]
+        self.get_pc = cfg["training"]["surface_weight"] > 0
+        self.traj = Trajectory("./results/")
+        self.start_frame, self.end_frame = 0, len(self.data_stream)
+
+        init_batch = self.data_stream[0]
+        init_pose = init_batch["c2w"].squeeze().cpu().numpy()
+        self.RO_pose = []
+        self.MV = moving_volume(cfg, self.traj, init_pose.astype(np.float64), start=0, device=self.device)
+        self.im_h, self.im_w = self.data_stream.H, self.data_stream.W
+        d = self.data_stream
+        self.K = np.array([[d.fx, 0.0, d.cx], [0.0, d.fy, d.cy], [0.0, 0.0, 1.0]])
+        n = self.im_h * self.im_w
+        # reference :111-117: buffers start as ones (border normals are never written and stay non-zero)
+        self.depth_vertex_gpu = torch.ones(n * 4, dtype=torch.float32, device=self.device)
+        self.normal_vertex_gpu = torch.ones(n * 3, dtype=torch.float32, device=self.device)
+        self.move_frameid = 0
+        self.initialize_search_size = np.zeros((6))
+        self.previous_frame_success = False
+        self.tiff_index = [0, 1 + 20, 2 + 40, 3, 4 + 20, 5 + 40, 6 + 0, 7 + 20, 8 + 40, 9 + 0, 10 + 20, 11 + 40, 12 + 0,
+                           13 + 20, 14 + 40, 15 + 0, 16 + 20, 17 + 40, 18 + 0, 19 + 20]
+        self.depth_level = [32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16]
+        self.readpst(ro.get("PST_seed", 20251205), self.PST_size)
+        self.current_global_R = np.zeros((3, 3), dtype=np.float32)
+        self.current_global_T = np.zeros((3), dtype=np.float32)
+        rgb = torch.floor(init_batch["rgb"].squeeze() * 255.0)
+        self.MV.integrate(rgb, init_batch["depth"].squeeze(), self.K, init_pose, self.MV.vol_bnds, obs_weight=1.)
+
+    # ------------------------------------------------------------------ particle templates
+    def readpst(self, seed, PST_size):
+        """same container layout as the reference (:834-866): ALL_PST[class][index] -> [P,6]; device copies."""
+        n_idx = len(self.tiff_index)
+        shapes = {0: (n_idx // 3 + 1, PST_size[0]), 1: (n_idx // 3 + 1, PST_size[1]), 2: (n_idx // 3, PST_size[2])}
+        self.ALL_PST = {c: np.zeros((s[0], s[1], 6), np.float32) for c, s in shapes.items()}
+        for i in range(n_idx):
+            cls = self.tiff_index[i] // 20
+            num = self.tiff_index[i] - cls * 20
+            self.ALL_PST[cls][num // 3] = make_pst(PST_size[cls], seed + 97 * self.tiff_index[i])
+        self.ALL_PST_dev = {c: torch.from_numpy(a).to(self.device) for c, a in self.ALL_PST.items()}
+
+    def get_PST(self, tiff_index):
+        cls = tiff_index // 20
+        return self.ALL_PST[cls][(tiff_index - cls * 20) // 3, ...]
+
+    def _get_PST_dev(self, tiff_index):
+        cls = tiff_index // 20
+        return self.ALL_PST_dev[cls][(tiff_index - cls * 20) // 3]
+
+    # ------------------------------------------------------------------ kernels
+    def init_searchsize(self):
+        self.iter_trans_vector = np.zeros((6), dtype=np.float32)
+        self.search_size = np.zeros((6), dtype=np.float32)
+        self.previous_search_size = np.zeros((6), dtype=np.float32)
+        self.search_size[...] = self.init_size
+
+    def init_depth_vertex(self, depth_im, cam_intr):
+        """reference :426-451."""
+        depth = depth_im if isinstance(depth_im, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(depth_im, np.float32))
+        self.depth_map_gpu = depth.to(self.device, torch.float32).reshape(-1).contiguous()
+        seed_num = random.randint(1, 1000000)
+        check(_lib.load().rfx_track_vertex(ptr(self.depth_map_gpu), ptr(self.depth_vertex_gpu), farr(_F9, np.asarray(cam_intr).reshape(-1)),
+                                           self.im_h, self.im_w, float(self.cut_dist), float(self.truncation),
+                                           float(self.sample_range), seed_num, None, stream_ptr(self.device)), "rfx_track_vertex")
+
+    def init_normal(self):
+        """reference :453-468."""
+        check(_lib.load().rfx_track_normal(ptr(self.depth_vertex_gpu), ptr(self.normal_vertex_gpu), self.im_h, self.im_w,
+                                           stream_ptr(self.device)), "rfx_track_normal")
+
+    def evaluate_tsdf(self, cur_id, level, node_size, cam_intr, level_index):
+        """mean |tsdf - target| per candidate (reference :536-604).  Returns (mean, sum, count) as numpy."""
+        P = int(node_size // 1024) * 1024            # grid = int(node_size/(32*32)) blocks of 1024 candidates
+        val = torch.empty(P, dtype=torch.float32, device=self.device)
+        cnt = torch.empty(P, dtype=torch.float32, device=self.device)
+        mv = self.MV
+        d = mv.vol_dim
+        check(_lib.load().rfx_track_evaluate(ptr(mv.tsdf_vol_gpu), int(d[0]), int(d[1]), int(d[2]), farr(_F3, mv.vol_origin),
+                                             float(mv.voxel_size), ptr(self.depth_vertex_gpu), ptr(self.normal_vertex_gpu),
+                                             farr(_F9, self.current_global_R.reshape(-1)), farr(_F3, self.current_global_T),
+                                             ptr(self._cand_dev), farr(_F6, self.search_size), P,
+                                             farr(_F9, np.asarray(cam_intr).reshape(-1)), self.im_h, self.im_w, int(level),
+                                             int(level_index), ptr(val), ptr(cnt), stream_ptr(self.device)), "rfx_track_evaluate")
+        n_all = self.transform_candidate.shape[0]
+        sv = np.zeros(n_all, np.float32)
+        sc = np.zeros(n_all, np.float32)
+        both = torch.stack([val, cnt]).cpu().numpy()
+        sv[:P], sc[:P] = both[0], both[1]
+        return sv / (sc + 1e-6), sv, sc
+
+    # ------------------------------------------------------------------ host logic
+    def update_PST(self, tsdf, mean_transform, min_scale=1e-3, scale=0.09):
+        """anisotropic search-size update (reference :493-534)."""
+        s = np.abs(np.array([mean_transform[0], mean_transform[1], mean_transform[2], mean_transform[4], mean_transform[5],
+                             mean_transform[6]], dtype=np.float64)) + min_scale
+        s = s / np.sqrt((s ** 2).sum())
+        self.search_size[0:3] = scale * tsdf * s[0:3] + min_scale
+        self.search_size[3:6] = scale * tsdf * s[3:6] + min_scale
+
+    def cal_transform(self, search_value):
+        """fitness-weighted mean of the first ``count_search`` candidates that beat the null candidate
+        (reference :606-709).  Returns (success, min_tsdf, [tx,ty,tz,qw,qx,qy,qz])."""
+        mean_transform = np.zeros((7), dtype=np.float32)
+        origin_tsdf = search_value[0]
+        better = np.flatnonzero(search_value[1:] < origin_tsdf) + 1
+        if better.size == 0:
+            return False, origin_tsdf, mean_transform
+        sel = better[:self.count_search]
+        cand = self.transform_candidate[sel].astype(np.float64)
+        fit = search_value[sel].astype(np.float64)
+        w = float(origin_tsdf) - fit
+        ss = self.search_size.astype(np.float64)
+        q = cand[:, 3:6] * ss[3:6]
+        rad = 1.0 - (q ** 2).sum(1)
+        if (rad < 0).any():
+            raise ValueError("invalid quaternion in the particle template (reference exits here, :662-669)")
+        qw = np.sqrt(rad)
+        sw = w.sum()
+        mean_tsdf = (fit * w).sum() / sw
+        mean_transform[0:3] = (cand[:, 0:3] * w[:, None]).sum(0) / sw * ss[0:3]
+        qm = np.concatenate([[(qw * w).sum() / sw], (cand[:, 3:6] * w[:, None]).sum(0) / sw * ss[3:6]])
+        mean_transform[3:7] = qm / np.sqrt((qm ** 2).sum())
+        return True, mean_tsdf, mean_transform
+
+    def random_optimization(self, cur_id, cam_pose, rgb_im, depth_im, cam_intr, beta=0.9, inherit=False):
+        """20 iterations of: evaluate the particle set around the current pose, move to the fitness-weighted
+        mean, rescale the search box (reference :713-831)."""
+        self.current_global_R = np.asarray(cam_pose[:3, :3], np.float32).copy()
+        self.current_global_T = np.asarray(cam_pose[:3, 3], np.float32).copy()
+        if inherit is True and self.previous_frame_success:
+            self.search_size = self.initialize_search_size
+        else:
+            self.init_searchsize()
+        self.init_depth_vertex(depth_im, cam_intr)
+        self.init_normal()
+        previous_success, success, count_particle, level_index = False, False, 0, 5
+        for i in range(self.particle_iter_lens):
+            if not success:
+                count_particle = 0
+            PST_class = count_particle % 3
+            self.transform_candidate = self.get_PST(self.tiff_index[count_particle])
+            self._cand_dev = self._get_PST_dev(self.tiff_index[count_particle])
+            level = self.depth_level[count_particle]
+            search_value, sv, sc = self.evaluate_tsdf(cur_id, level, self.PST_size[PST_class], cam_intr, level_index)
+            success, min_tsdf, mean_transform = self.cal_transform(search_value)
+            qw, qx, qy, qz = mean_transform[3:7]
+            if success:
+                if count_particle < 19:
+                    count_particle += 1
+                Rinc = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                                 [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                                 [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]], dtype=np.float32)
+                self.current_global_T += mean_transform[:3]
+                self.current_global_R = np.matmul(Rinc, self.current_global_R)
+            level_index = 1 if self.fix_level_index else level_index + 5
+            level_index = level_index % (self.depth_level[count_particle])
+            self.update_PST(min_tsdf, mean_transform, scale=self.scaling_coefficient)
+            if previous_success and success:
+                self.search_size[:] = beta * self.search_size + (1 - beta) * self.previous_search_size
+            elif success:
+                if self.iterative_scale:
+                    previous_success = True
+                self.previous_search_size[:] = self.search_size
+            if not success:
+                previous_success = False
+            if i == 0:
+                if success:
+                    self.initialize_search_size = self.search_size
+                    self.previous_frame_success = True
+                else:
+                    self.previous_frame_success = False
+        cam_pose_iter = np.eye(4, dtype=np.float32)
+        cam_pose_iter[:3, :3] = self.current_global_R
+        cam_pose_iter[:3, 3] = self.current_global_T
+        return cam_pose_iter
+
+    def do_tracking(self, init_pose, decoder, batch, device):
+        """reference :869-907.  Returns (pose [4,4] numpy, rgb 0..255, depth) -- images stay on the device."""
+        if isinstance(init_pose, torch.Tensor):
+            init_pose = init_pose.detach().cpu().numpy()
+        depth = batch["depth"].squeeze()
+        rgb = torch.floor(batch["rgb"].squeeze() * 255.0)
+        self.gt_pose = batch["c2w"].squeeze().cpu().numpy()
+        cam_pose_iter = self.random_optimization(batch["frame_id"], init_pose, rgb, depth, self.K)
+        return cam_pose_iter, rgb, depth
+
+    def post_processing(self, cur_id, cam_pose_iter, rgb, depth, est_c2w_data):
+        """follow the camera with the volume, then integrate the frame (reference :911-945)."""
+        move_flag, old_volbnd = self.MV.check_move_volume_new(cur_id, np.asarray(cam_pose_iter, np.float64), self.traj,
+                                                              version=self.MV.version, larger_flag=self.larger_flag,
+                                                              get_pc=self.get_pc)
+        if move_flag:
+            start = 0 if self.MV.start_id == 0 else self.MV.start_id
+            self.MV.start_id = cur_id
+            self.MV.frame_to_Vrange[(start, cur_id - 1)] = old_volbnd
+            self.larger_flag = False
+            self.move_frameid = cur_id
+        self.MV.integrate(rgb, depth, self.K, cam_pose_iter, old_volbnd, obs_weight=1.)
+
+    def cal_ape_error(self, gt, our_t):
+        gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
+        our_t = our_t.cpu().numpy() if isinstance(our_t, torch.Tensor) else np.asarray(our_t)
+        return float(np.average(np.abs(gt[:3, 3] - our_t)))

@@ -1,0 +1,74 @@
+"""Tracker: per-frame pose tracking loop (reference mp_slam/tracker.py:15-197): constant-velocity
+prediction, ROTracker pose search against the moving TSDF volume, relative-pose bookkeeping, volume
+update.  ``track_frame`` is the body of the reference's ``tracking()``; ``run()`` keeps the loop."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from ..model.ROtracker import ROTracker
+
+
+def orthogonalize_rotation(R: np.ndarray) -> np.ndarray:
+    """nearest rotation (SVD), as the reference's orthogonalize_rotation_matrix_tolerate does."""
+    U, _, Vt = np.linalg.svd(R.astype(np.float64))
+    if np.linalg.det(U @ Vt) < 0:
+        U[:, -1] *= -1
+    return (U @ Vt).astype(np.float32)
+
+
+class Tracker:
+    def __init__(self, config, SLAM, model, dataset, est_c2w_data, RO_c2w_data, est_c2w_data_rel, tracking_idx, mapping_idx,
+                 tracking_stop_flag, pose_gt, update_local_MV, all_fuse_pose, device) -> None:
+        self.config, self.slam, self.dataset = config, SLAM, dataset
+        self.est_c2w_data, self.RO_c2w_data, self.est_c2w_data_rel = est_c2w_data, RO_c2w_data, est_c2w_data_rel
+        self.tracking_idx, self.mapping_idx, self.tracking_stop_flag = tracking_idx, mapping_idx, tracking_stop_flag
+        self.update_local_MV, self.all_fuse_pose, self.share_model, self.pose_gt = update_local_MV, all_fuse_pose, model, pose_gt
+        self.frames_num = len(dataset)
+        self.device = device
+        self.RO_Tracker = ROTracker(config, dataset, device=device)
+        self.all_poses = []
+
+    def predict_current_pose(self, frame_id, constant_speed=True):
+        """reference :55-72."""
+        if frame_id == 1 or (not constant_speed):
+            self.est_c2w_data[frame_id] = self.est_c2w_data[frame_id - 1]
+        else:
+            pp = self.RO_c2w_data[frame_id - 2].cpu().numpy().astype(np.float64)
+            p = self.RO_c2w_data[frame_id - 1].cpu().numpy().astype(np.float64)
+            pred = (p @ np.linalg.inv(pp)) @ p
+            pred[:3, :3] = orthogonalize_rotation(pred[:3, :3])
+            self.est_c2w_data[frame_id] = torch.from_numpy(pred.astype(np.float32)).to(self.device)
+        return self.est_c2w_data[frame_id]
+
+    def tracking(self, batch, frame_id):
+        """reference :74-134."""
+        cur_c2w = self.predict_current_pose(frame_id, self.config["tracking"]["const_speed"])
+        RO_pose_np, rgb, depth = self.RO_Tracker.do_tracking(cur_c2w, None, batch, self.device)
+        self.RO_Tracker.RO_pose.append(RO_pose_np)
+        cur = torch.from_numpy(RO_pose_np).float().to(self.device)
+        self.est_c2w_data[frame_id] = cur
+        self.RO_c2w_data[frame_id] = cur
+        self.all_poses.append(cur.cpu())
+        ke = self.config["mapping"]["keyframe_every"]
+        if frame_id % ke != 0:
+            key = self.RO_c2w_data[(frame_id // ke) * ke]
+            self.est_c2w_data_rel[frame_id] = cur @ torch.linalg.inv_ex(key).inverse
+        self.RO_Tracker.post_processing(frame_id, RO_pose_np, rgb, depth, self.est_c2w_data)
+
+    def run(self):
+        """reference :173-197 (waits for the mapper when it lags)."""
+        m = self.config["mapping"]
+        for idx in range(self.frames_num):
+            batch = self.dataset[idx]
+            if idx == 0:
+                self.all_poses.append(self.est_c2w_data[0].detach().cpu())
+                self.RO_c2w_data[0] = self.est_c2w_data[0].detach().clone()
+                continue
+            while self.mapping_idx[0] < idx - m["map_every"] - m["map_every"] // 2:
+                time.sleep(0.02)
+            self.tracking(batch, idx)
+            self.tracking_idx[0] = idx
+        self.tracking_stop_flag[0] = 1

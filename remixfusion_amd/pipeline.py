@@ -44,6 +44,17 @@ class MappingPipeline:
             self.slam.seed_everything(seed)
             self.mapper = Mapper(config, self.slam, self.model)
             self.mapper.shard = shard
+        # synthetic.tracker = True: estimate poses with the ROTracker (BASELINE config 3) instead of GT poses;
+        # the tracker then owns the moving volume, like in the reference (model/ROtracker.py:84)
+        self.tracker = None
+        if self.slam is not None and config["synthetic"].get("tracker", False):
+            from .mp_slam.tracker import Tracker
+            s = self.slam
+            del self.mv
+            self.tracker = Tracker(config, s, self.model, self.dataset, s.est_c2w_data, s.RO_c2w_data, s.est_c2w_data_rel,
+                                   s.tracking_idx, s.mapping_idx, s.tracking_stop_flag, s.pose_gt, s.update_local_MV,
+                                   s.keyframeDatabase.all_fuse_pose, self.device)
+            self.mv = self.tracker.RO_Tracker.MV
         self.frames_done = 0
 
     # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
@@ -66,6 +77,14 @@ class MappingPipeline:
     def track_frame(self, i: int, batch: Dict):
         """tracker side with GT pose: follow the camera with the volume, then integrate
         (ROtracker.post_processing, model/ROtracker.py:911-945)."""
+        if self.tracker is not None:
+            if i == 0:
+                self.slam.est_c2w_data[0] = batch["c2w"].to(self.device)
+                self.slam.RO_c2w_data[0] = batch["c2w"].to(self.device)
+            else:
+                self.tracker.tracking({k: v for k, v in batch.items() if k != "rgb255"}, i)
+                self.slam.tracking_idx[0] = i
+            return
         c2w = batch["c2w"]
         pose_np = c2w.numpy().astype(np.float64) if not c2w.is_cuda else c2w.cpu().numpy().astype(np.float64)
         if i > 0:
