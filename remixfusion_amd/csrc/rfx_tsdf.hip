@@ -26,6 +26,9 @@
 #ifndef MV_U
 #define MV_U 4
 #endif
+#ifndef MV_TD
+#define MV_TD 32      // pixels per side of a coarse max-depth tile
+#endif
 
 namespace rfx {
 
@@ -55,14 +58,19 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
                                                          float2* __restrict__ dimg,
                                                          unsigned* __restrict__ dmax_bits, int H, int W,
                                                          float fx, float fy, float cx, float cy, int colmajor) {
-    const int n = H * W;
+    // one block per MV_TD x MV_TD pixel tile: packs {depth, 1/lambda} and stores the tile's max depth
+    // in dmax_bits[1 + tile] (plain store, no atomics).  dmax_bits[0] is unused.
+    const int tw = (W + MV_TD - 1) / MV_TD;
+    const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
     float m = 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int py = i / W, px = i - py * W;
-        float d = depth[i];
-        float vx = (((float)px) - cx) / fx;
-        float vy = (((float)py) - cy) / fy;
-        float lambda = sqrtf(madd(vx, vx, vy * vy) + 1.0f);
+    for (int k = threadIdx.x; k < MV_TD * MV_TD; k += blockDim.x) {
+        const int py = ty * MV_TD + k / MV_TD, px = tx * MV_TD + k % MV_TD;
+        if (py >= H || px >= W) continue;
+        const int i = py * W + px;
+        const float d = depth[i];
+        const float vx = (((float)px) - cx) / fx;
+        const float vy = (((float)py) - cy) / fy;
+        const float lambda = sqrtf(madd(vx, vx, vy * vy) + 1.0f);
         // A voxel row (world z) projects to a near-straight pixel walk.  Storing the image with the
         // walk direction contiguous turns the per-lane gather of a 64-voxel chunk from 64 cache
         // lines into ~12: column-major when the walk is mostly along image y.
@@ -71,14 +79,11 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // one atomic per block (a single address saturates at ~90 atomics/us on MI355X)
     __shared__ float wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.0f) atomicMax(dmax_bits, __float_as_uint(m));
-    }
+    if (threadIdx.x == 0)
+        dmax_bits[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
 }
 
 // ---------------------------------------------------------------------------- per-voxel math
@@ -232,7 +237,6 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
             if (risky) {
                 z0 = 0; z1 = P.dz;      // literal-decode rows are not culled (they may alias)
             } else {
-                const float dmax = __uint_as_float(*dmax_bits);
                 const float wx = P.origin[0] + (float)rx * P.voxel - P.c2w[3];
                 const float wy = P.origin[1] + (float)ry * P.voxel - P.c2w[7];
                 const float wz = P.origin[2] - P.c2w[11];
@@ -242,12 +246,11 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
                 const float Bx = P.c2w[8] * P.voxel, By = P.c2w[9] * P.voxel, Bz = P.c2w[10] * P.voxel;
                 const float fx = P.K[0], fy = P.K[4], cx = P.K[2], cy = P.K[5];
                 const float m = 0.05f;   // pixel margin
-                const float zfar = (dmax + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f;
                 const float mag = fabsf(Ax) + fabsf(Ay) + fabsf(Az) +
                                   (float)P.dz * (fabsf(Bx) + fabsf(By) + fabsf(Bz));
                 const float eps = 1e-4f * fmaxf(fx, fy) * mag + 1e-4f;
                 float lo = 0.0f, hi = (float)(P.dz - 1);
-                bool empty = !(dmax > 0.0f);
+                bool empty = false;
                 auto clip = [&](float a, float b) {   // keep z with a + b z >= -eps
                     a += eps;
                     const float q = -a * __builtin_amdgcn_rcpf(b);   // ~1 ulp: absorbed by eps and the +-1 voxel margin
@@ -262,7 +265,26 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
                 clip(fy * Ay + (cy + 0.5f + m) * Az, fy * By + (cy + 0.5f + m) * Bz);    // py >= 0
                 clip(((float)P.H - 0.5f + m - cy) * Az - fy * Ay,
                      ((float)P.H - 0.5f + m - cy) * Bz - fy * By);                       // py < H
-                clip(zfar - Az, -Bz);                                                    // cam_z <= zfar
+                if (!empty && lo <= hi) {
+                    // The row is a straight line in the image: its pixels lie in the bounding box of the two
+                    // end points.  No voxel of the row can update if it is deeper than the deepest pixel of the
+                    // coarse tiles that box touches (+ trunc): clip the far end again, per row.
+                    float u0, v0, u1, v1;
+                    {
+                        const float za = fmaxf(Az + lo * Bz, 1e-6f), zb = fmaxf(Az + hi * Bz, 1e-6f);
+                        const float ra = __builtin_amdgcn_rcpf(za), rb = __builtin_amdgcn_rcpf(zb);
+                        u0 = fx * (Ax + lo * Bx) * ra + cx; v0 = fy * (Ay + lo * By) * ra + cy;
+                        u1 = fx * (Ax + hi * Bx) * rb + cx; v1 = fy * (Ay + hi * By) * rb + cy;
+                    }
+                    const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
+                    const int tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)), tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
+                    const int tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)), tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
+                    float tm = 0.0f;
+                    for (int tv = tv0; tv <= tv1; ++tv)
+                        for (int tu = tu0; tu <= tu1; ++tu) tm = fmaxf(tm, __uint_as_float(dmax_bits[1 + tv * tw + tu]));
+                    if (!(tm > 0.0f)) empty = true;
+                    else clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz);
+                }
                 if (!empty && lo <= hi) {
                     z0 = max(0, (int)floorf(lo) - 1);
                     z1 = min(P.dz, (int)ceilf(hi) + 2);
@@ -602,6 +624,8 @@ static void decode_split(int dx, int dy, int dz, int index_decode, int* risky_ro
 
 using namespace rfx;
 
+static inline size_t mv_header_bytes(size_t tiles) { return ((1 + tiles) * sizeof(unsigned) + 255) / 256 * 256; }
+
 extern "C" {
 
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
@@ -609,7 +633,8 @@ int rfx_last_hip_error(void) { return g_last_hip_error; }
 
 size_t rfx_tsdf_integrate_workspace_bytes(int H, int W) {
     if (H <= 0 || W <= 0) return 0;
-    return 256 + (size_t)H * W * sizeof(float2);
+    const size_t tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
+    return mv_header_bytes(tiles) + (size_t)H * W * sizeof(float2);
 }
 
 int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
@@ -645,9 +670,9 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
     P.dimg_colmajor = (fabsf(K[4] * c2w[9]) >= fabsf(K[0] * c2w[8])) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     unsigned* dmax_bits = reinterpret_cast<unsigned*>(workspace);
-    float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + 256);
-    RFX_HIP_TRY(hipMemsetAsync(dmax_bits, 0, sizeof(unsigned), st));
-    const int prepass_blocks = (int)std::min<int64_t>(256, ((int64_t)H * W + 1023) / 1024);
+    const size_t n_tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
+    float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + mv_header_bytes(n_tiles));
+    const int prepass_blocks = (int)n_tiles;
     hipLaunchKernelGGL(mv_prepass_kernel, dim3(prepass_blocks), dim3(256), 0, st, depth, dimg,
                        dmax_bits, H, W, K[0], K[4], K[2], K[5], P.dimg_colmajor);
     RFX_LAUNCH_CHECK();
