@@ -283,6 +283,20 @@ int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float or
                        const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
                        int level, int level_index, float* value, float* count, rfx_stream stream);
 
+/* ---- iso-surface extraction -------------------------------------------------------
+ * MC1/MC2 replace the host `skimage.measure.marching_cubes(raw, level=isolevel, mask=mask)` call of
+ * utils.py:158 (extract_mesh_github).  volume dev [X,Y,Z] fp32 (z fastest), mask dev [X,Y,Z] u8 or NULL
+ * (a cell is polygonised only when its 8 samples are unmasked and not NaN); a sample < level is inside.
+ * Cells are numbered (x*(Y-1) + y)*(Z-1) + z.  Tables are host-generated (remixfusion_amd/mesh.py):
+ * n_tri dev [256] int32; tri_edges dev [256, max_tri*3] int32 edge ids 0..11 in the order
+ * (0,1)(0,2)(0,4)(1,3)(1,5)(2,3)(2,6)(3,7)(4,5)(4,6)(5,7)(6,7) of corner ids cx + 2cy + 4cz. */
+int rfx_mc_count(const float* volume, const uint8_t* mask, int X, int Y, int Z, float level, const int* n_tri, int* counts,
+                 rfx_stream stream);
+/* offsets dev [cells] int64 = exclusive scan of counts; verts dev [3*total, 3] fp32 in sample-index
+ * coordinates; keys dev [3*total] int64 identify the cut grid edge (equal keys == the same vertex). */
+int rfx_mc_emit(const float* volume, const uint8_t* mask, int X, int Y, int Z, float level, const int* tri_edges, int max_tri,
+                const int* counts, const long long* offsets, float* verts, long long* keys, rfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

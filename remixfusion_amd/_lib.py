@@ -84,6 +84,8 @@ PROTOTYPES = {
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
+    "rfx_mc_count": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _P]),
+    "rfx_mc_emit": (_i, [_P, _P, _i, _i, _i, _f, _P, _i, _P, _P, _P, _P, _P]),
     "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),
 }
 

@@ -189,6 +189,30 @@ class SLAM:
         self.rba_optimizer = optim.Adam(rba, betas=(0.9, 0.99))
 
     @torch.no_grad()
+    # ---- mesh export (reference slam.py:348-414; marching cubes runs on the device, see mesh.py)
+    def _mesh_path(self, name):
+        return os.path.join(self.config["data"]["output"], self.config["data"]["exp_name"], name)
+
+    def _save_mesh(self, path, sdf_fn, color_fn, voxel_size):
+        from ..mesh import extract_mesh, write_ply
+        mesh = extract_mesh(sdf_fn, self.model.query_w_res, self.config, self.bounding_box, color_func=color_fn,
+                            marching_cube_bound=self.marching_cube_bound, voxel_size=voxel_size)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        write_ply(path, mesh)
+        return mesh
+
+    def save_mesh(self, i, voxel_size=0.05):
+        return self._save_mesh(self._mesh_path("mesh_track{}.ply".format(int(i))), self.model.query_sdf_res,
+                               self.model.query_color_residual, voxel_size)
+
+    def save_mesh_final(self, voxel_size=0.05):
+        return self._save_mesh(self._mesh_path("mesh.ply"), self.model.query_sdf_res, self.model.query_color_residual,
+                               voxel_size)
+
+    def save_mesh_explicit(self, i, voxel_size=0.05):
+        return self._save_mesh(self._mesh_path("mesh_track{}_ex.ply".format(int(i))), self.model.query_sdf_ex,
+                               self.model.query_color_ex, voxel_size)
+
     def render_single(self, frame_id, gt_depth, gt_color, cam_pose, ray_d, prefix=None, gap=1):
         """Full-frame rgb/depth prediction (reference :288-344) through the fused renderer."""
         gt_color = gt_color.squeeze(0)[::gap, ::gap, :]
