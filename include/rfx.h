@@ -150,10 +150,14 @@ typedef struct rfx_field_desc {
 /* E1 alone (query_sdf_res(embed=True), mp_slam/slam.py:209): x01 dev [n,3] -> feat dev [n, L*F]. */
 int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
                             float* feat, rfx_stream stream);
-/* backward of the above: dfeat dev [n, L*F] -> atomically accumulated into dtable (dev, same
- * shape as table, caller zero-fills) and, if dx01 != NULL, dx01 dev [n,3] (overwritten). */
+/* backward of the above: dfeat dev [n, L*F] -> accumulated (float atomics) into dtable (dev, same
+ * shape as table, caller zero-fills) and, if dx01 != NULL, dx01 dev [n,3] (overwritten).
+ * workspace (optional, dev, >= rfx_grid_encode_backward_workspace_bytes): enables the LDS-privatised
+ * scatter (per-segment accumulation in LDS, contiguous flush); NULL = direct atomics. */
+size_t rfx_grid_encode_backward_workspace_bytes(int64_t n, int n_levels);
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
-                             const float* dfeat, float* dtable, float* dx01, rfx_stream stream);
+                             const float* dfeat, float* dtable, float* dx01, void* workspace, size_t workspace_bytes,
+                             rfx_stream stream);
 
 /* E2 alone: tcnn OneBlob, x01 dev [n,3] -> dev [n, 3*n_bins]. */
 int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, float* out, rfx_stream stream);

@@ -61,7 +61,8 @@ PROTOTYPES = {
     "rfx_gbv_integrate": (_i, [_P, _P, _i, _F6, _F9, _P, _P, _P, _i, _i, _f, _f, _P]),
     "rfx_gbv_clear": (_i, [_P, _l, _P]),
     "rfx_grid_encode_forward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P]),
-    "rfx_grid_encode_backward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _P, _P]),
+    "rfx_grid_encode_backward_workspace_bytes": (C.c_size_t, [_l, _i]),
+    "rfx_grid_encode_backward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _P, _P, C.c_size_t, _P]),
     "rfx_oneblob_forward": (_i, [_P, _l, _i, _i, _P, _P]),
     "rfx_field_forward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P]),
     "rfx_field_backward_workspace_bytes": (_sz, [_l]),

@@ -160,6 +160,183 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
     }
 }
 
+// ---------------------------------------------------------------- E1 backward, LDS-privatised scatter
+// Scattered fp32 atomics are executed by the memory side one lane at a time; the same additions done in
+// LDS cost a few cycles and the table is then updated with *contiguous* atomics (one 256 B request per
+// wave), which the memory side retires ~16x faster.  Each block owns one segment of one level
+// (SCATTER_SEG entries = 128 KB of LDS) and one slice ("chunk") of the points; it walks its points, keeps
+// the corner contributions that land in its segment, and flushes the non-zero accumulators.
+// A level of `size` entries is cut into ceil(size / SCATTER_SEG) segments: 1..4 for T = 2^16.
+//
+// Points arrive ray-major (or lattice-major for the TV term), so neighbours share grid cells on the
+// coarse levels -- and LDS serialises same-address atomics.  Two measures: (1) a thread owns a *run* of
+// K consecutive points and accumulates the 8x2 corner sums in registers while the cell stays the same,
+// touching LDS only when it changes; (2) the lanes of a wave are therefore K points apart.  A staging
+// pass re-orders the inputs (chunk, iteration, thread)-major so those strided runs are read coalesced.
+#ifndef SCATTER_SEG_ENTRIES
+#define SCATTER_SEG_ENTRIES 16384
+#endif
+#ifndef SCATTER_TARGET_BLOCKS
+#define SCATTER_TARGET_BLOCKS 512
+#endif
+constexpr unsigned SCATTER_SEG = SCATTER_SEG_ENTRIES;
+constexpr int SCATTER_THREADS = 1024;
+constexpr int SCATTER_MAX_SEGMENTS = 640;      // above this (T >= 2^20) the per-segment point sweeps dominate
+constexpr int64_t SCATTER_MIN_POINTS = 4096;
+
+struct ScatterPlan {
+    int seg_start[RFX_MAX_LEVELS + 1];
+    int chunks;          // slices of the point list
+    int K;               // points per thread and chunk; a chunk covers K * SCATTER_THREADS points
+    int64_t slots;       // chunks * K * SCATTER_THREADS
+};
+
+static void scatter_shape(int64_t n, int total_segments, int* chunks, int* K) {
+    int c = total_segments > 0 ? SCATTER_TARGET_BLOCKS / total_segments : 1;
+    const int64_t max_chunks = (n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS;
+    if (c > max_chunks) c = (int)max_chunks;
+    if (c < 1) c = 1;
+    const int64_t per = (n + c - 1) / c;
+    *chunks = c;
+    *K = (int)((per + SCATTER_THREADS - 1) / SCATTER_THREADS);
+}
+
+// upper bound of staged slots for any plan of scatter_shape(): each chunk pads to a multiple of 1024 points
+static size_t scatter_scratch_floats(int64_t n, int n_levels) {
+    const size_t slots = (size_t)n + (size_t)((n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS + 1) * SCATTER_THREADS;
+    return slots * (size_t)(2 * n_levels + 3);
+}
+
+// slot (chunk c, iteration i, thread t) <- point c*K*1024 + t*K + i.  Planes: L x float2[slots], then x,y,z.
+__global__ __launch_bounds__(256) void scatter_stage_kernel(const float* __restrict__ dfeat, int ld, int n_levels,
+                                                            const float* __restrict__ x01, int64_t n, int K, int64_t slots,
+                                                            float* __restrict__ scratch) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const int64_t per = (int64_t)K * SCATTER_THREADS;
+    const int64_t c = s / per, r = s % per;
+    const int64_t p = c * per + (r % SCATTER_THREADS) * K + r / SCATTER_THREADS;
+    float2* __restrict__ planes = reinterpret_cast<float2*>(scratch);
+    float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
+    if (p < n) {
+        const float2* __restrict__ row = reinterpret_cast<const float2*>(dfeat + p * (int64_t)ld);
+        for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
+        xs[s] = x01[p * 3]; xs[slots + s] = x01[p * 3 + 1]; xs[2 * slots + s] = x01[p * 3 + 2];
+    } else {
+        for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
+        xs[s] = 0.5f; xs[slots + s] = 0.5f; xs[2 * slots + s] = 0.5f;
+    }
+}
+
+__global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_grid_desc g, ScatterPlan plan, int n_levels,
+                                                                           const float* __restrict__ scratch,
+                                                                           float* __restrict__ dtable) {
+    extern __shared__ float acc[];
+    int l = 0;
+    while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
+    const Level lv = get_level(g, l);
+    const unsigned base = (blockIdx.x - plan.seg_start[l]) * SCATTER_SEG;
+    const unsigned cnt = min(SCATTER_SEG, lv.size - base);
+    for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    const int64_t slots = plan.slots;
+    const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
+    const float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
+    int64_t s = (int64_t)blockIdx.y * plan.K * SCATTER_THREADS + threadIdx.x;
+
+    Cell cur;                       // cell of the running register accumulation
+    bool open = false;
+    float a0[8], a1[8];
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned r = corner_index(lv, cur, k) - base;
+#if defined(SCATTER_DBG) && SCATTER_DBG == 2
+            if (r < cnt) { acc[2 * r] = a0[k]; acc[2 * r + 1] = a1[k]; }
+#else
+            if (r < cnt) {
+                atomicAdd(&acc[2 * r], a0[k]);
+                atomicAdd(&acc[2 * r + 1], a1[k]);
+            }
+#endif
+        }
+    };
+    // software-pipelined: the loads of point i+1 are in flight while point i is processed
+    float2 gv_n = gvp[s];
+    float xn[3] = {xs[s], xs[slots + s], xs[2 * slots + s]};
+    for (int i = 0; i < plan.K; ++i) {
+        const float2 gv = gv_n;
+        const float x[3] = {xn[0], xn[1], xn[2]};
+        s += SCATTER_THREADS;
+        if (i + 1 < plan.K) {
+            gv_n = gvp[s];
+            xn[0] = xs[s]; xn[1] = xs[slots + s]; xn[2] = xs[2 * slots + s];
+        }
+        if (gv.x == 0.f && gv.y == 0.f) continue;
+        const Cell c = locate(lv, x);
+        const bool same = open && c.g[0] == cur.g[0] && c.g[1] == cur.g[1] && c.g[2] == cur.g[2];
+        if (!same) {
+            if (open) flush();
+            cur = c;
+            open = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = corner_weight(c, k);
+            a0[k] += w * gv.x;
+            a1[k] += w * gv.y;
+        }
+    }
+    if (open) flush();
+    __syncthreads();
+    float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
+    for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) {
+        const float v = acc[i];
+#if defined(SCATTER_DBG) && SCATTER_DBG == 1
+        if (v == 12345.f) out[i] = v;
+#elif defined(SCATTER_DBG) && SCATTER_DBG == 3
+        if (v != 0.f) out[i] = v;
+#else
+        if (v != 0.f) atomicAdd(out + i, v);
+#endif
+    }
+}
+
+// dtable += scatter of dfeat (row stride ld).  With a scratch buffer of scatter_scratch_floats() the
+// LDS path is taken when the table is small enough to sweep segment by segment; otherwise direct atomics.
+static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
+                               int ld, float* dtable, float* scratch, hipStream_t st) {
+    ScatterPlan plan;
+    int total = 0;
+    for (int l = 0; l < g.n_levels; ++l) {
+        plan.seg_start[l] = total;
+        total += (int)((g.size[l] + SCATTER_SEG - 1) / SCATTER_SEG);
+    }
+    for (int l = g.n_levels; l <= RFX_MAX_LEVELS; ++l) plan.seg_start[l] = total;
+    if (!scratch || total > SCATTER_MAX_SEGMENTS || n < SCATTER_MIN_POINTS) {
+        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
+                           dfeat, ld, dtable, (float*)nullptr, 0);
+        return RFX_OK;
+    }
+    scatter_shape(n, total, &plan.chunks, &plan.K);
+    plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
+    if ((size_t)plan.slots * (2 * g.n_levels + 3) > scatter_scratch_floats(n, g.n_levels)) return RFX_ERR_WORKSPACE;
+    hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, dfeat, ld, g.n_levels,
+                       x01, n, plan.K, plan.slots, scratch);
+    const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(grid_scatter_lds_kernel, dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan, g.n_levels,
+                       scratch, dtable);
+    return RFX_OK;
+}
+
 __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __restrict__ x01, int64_t n, int fp16,
                                                               float* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +357,7 @@ constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H
 constexpr int DW_BLOCKS = 512;
 
 struct BwdWs {
-    float *x1, *h1, *dh1, *g, *dy2, *h3, *dh3, *dx1, *partial;
+    float *x1, *h1, *dh1, *g, *dy2, *h3, *dh3, *dx1, *demb_t, *partial;
 };
 
 __host__ __device__ inline size_t ws_floats_per_point() { return LD_X1 + 3 * LD_H + LD_G + LD_DY2 + LD_H + LD_DX1; }
@@ -199,7 +376,8 @@ static BwdWs carve(void* ws, int64_t n) {
     w.h3 = p; p += np * LD_H;
     w.dh3 = p; p += np * LD_H;
     w.dx1 = p; p += np * LD_DX1;
-    w.partial = p;
+    w.partial = p; p += (size_t)DW_BLOCKS * 4 * DW_TOTAL;
+    w.demb_t = p;                                      // staged d_emb / points of the LDS scatter
     return w;
 }
 
@@ -575,15 +753,31 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
     return RFX_OK;
 }
 
+size_t rfx_grid_encode_backward_workspace_bytes(int64_t n, int n_levels) {
+    if (n <= 0 || n_levels <= 0) return 0;
+    return scatter_scratch_floats(n, n_levels) * sizeof(float);
+}
+
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
-                             const float* dfeat, float* dtable, float* dx01, rfx_stream stream) {
+                             const float* dfeat, float* dtable, float* dx01, void* workspace, size_t workspace_bytes,
+                             rfx_stream stream) {
     if (n == 0) return RFX_OK;
     if (!g || !table || !x01 || !dfeat || n < 0) return RFX_ERR_ARG;
     if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
     if (n == 0 || (!dtable && !dx01)) return RFX_OK;
-    hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
-                       table, x01, n, dfeat, g->n_levels * 2, dtable, dx01, 0);
-    RFX_LAUNCH_CHECK();
+    if (dtable) {
+        if (workspace && (workspace_bytes < rfx_grid_encode_backward_workspace_bytes(n, g->n_levels) || ((uintptr_t)workspace & 7)))
+            return RFX_ERR_WORKSPACE;
+        int rc = launch_grid_scatter(*g, table, x01, n, dfeat, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
+                                     as_stream(stream));
+        if (rc) return rc;
+        RFX_LAUNCH_CHECK();
+    }
+    if (dx01) {
+        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
+                           table, x01, n, dfeat, g->n_levels * 2, (float*)nullptr, dx01, 0);
+        RFX_LAUNCH_CHECK();
+    }
     return RFX_OK;
 }
 
@@ -638,7 +832,7 @@ int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, 
 size_t rfx_field_backward_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
     const size_t np = align_up((size_t)n, 64);
-    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * 4 * DW_TOTAL) * sizeof(float);
+    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * 4 * DW_TOTAL + scatter_scratch_floats(n, RFX_MAX_LEVELS)) * sizeof(float);
 }
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
@@ -688,9 +882,16 @@ int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_
     if (!x01 || n < 0) return RFX_ERR_ARG;
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
-    hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k.hash,
-                       k.table, x01, n, ws.dx1, LD_DX1, d_hash, dx01, 0);
-    RFX_LAUNCH_CHECK();
+    if (d_hash) {
+        rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, ws.demb_t, as_stream(stream));
+        if (rc) return rc;
+        RFX_LAUNCH_CHECK();
+    }
+    if (dx01) {
+        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k.hash,
+                           k.table, x01, n, ws.dx1, LD_DX1, (float*)nullptr, dx01, 0);
+        RFX_LAUNCH_CHECK();
+    }
     return RFX_OK;
 }
 

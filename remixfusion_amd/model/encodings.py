@@ -72,8 +72,13 @@ class _GridEncodeFn(torch.autograd.Function):
         dout = dout.contiguous()
         dparams = torch.zeros_like(params) if ctx.needs_input_grad[1] else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = None
+        if dparams is not None:       # staging buffer of the LDS-privatised scatter
+            nb = int(lib.rfx_grid_encode_backward_workspace_bytes(n, int(module.desc.n_levels)))
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
         check(lib.rfx_grid_encode_backward(module.desc, ptr(params), ptr(x), n, ptr(dout), ptr(dparams), ptr(dx),
-                                           stream_ptr(x.device)), "rfx_grid_encode_backward")
+                                           ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(x.device)),
+              "rfx_grid_encode_backward")
         return dx, dparams, None
 
 

@@ -134,13 +134,12 @@ def test_point_queries_match_oracle():
     _close(emb.reshape(-1, 32), FO.query_sdf_res(fp, x, embed=True), 1e-5, 1e-6, "embed=True")
 
 
-@pytest.mark.parametrize("clamp", [False, True])
-def test_field_backward_matches_autograd_of_oracle(clamp):
+@pytest.mark.parametrize("clamp,n", [(False, 3001), (True, 3001), (True, 9001)])    # n >= 4096: LDS-privatised scatter
+def test_field_backward_matches_autograd_of_oracle(clamp, n):
     cfg, m = _model(hash_scale=0.5)
     cfg["mapping"]["clamp"] = 1.5
     fp = _oracle_params(cfg, m)
     fp.map_clamp = 1.5
-    n = 3001
     x = _points(n, seed=5, lo=0.02, hi=0.98)
     g = torch.Generator().manual_seed(11)
     draw = torch.randn((n, 4), generator=g)
@@ -166,12 +165,14 @@ def test_field_backward_matches_autograd_of_oracle(clamp):
     assert m.GBV.params.grad is None
 
 
-def test_grid_encode_backward_standalone():
-    cfg, m = _model()
+@pytest.mark.parametrize("name,n", [("office0", 2000), ("office0", 12000), ("scene0000", 12000)])
+def test_grid_encode_backward_standalone(name, n):
+    """n < 4096: direct atomics; n >= 4096: LDS-privatised scatter (T = 2^16: <= 4 segments / level, 2^19: 32)."""
+    cfg, m = _model(name, gbv_fill=False)
     fp = _oracle_params(cfg, m)
-    x = _points(2000, seed=2, lo=0.01, hi=0.99)
+    x = _points(n, seed=2, lo=-0.05, hi=1.05)           # a few points outside the unit cube: dense levels wrap
     g = torch.Generator().manual_seed(4)
-    dy = torch.randn((2000, 32), generator=g)
+    dy = torch.randn((n, 32), generator=g)
     xo = x.clone().requires_grad_(True)
     fp.hash_table.requires_grad_(True)
     FO.grid_encode(xo, fp.hash_table, fp.hash_meta).backward(dy)
