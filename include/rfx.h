@@ -301,6 +301,27 @@ int rfx_mc_count(const float* volume, const uint8_t* mask, int X, int Y, int Z, 
 int rfx_mc_emit(const float* volume, const uint8_t* mask, int X, int Y, int Z, float level, const int* tri_edges, int max_tri,
                 const int* counts, const long long* offsets, float* verts, long long* keys, rfx_stream stream);
 
+/* ---- RBA pose-refinement MLP -------------------------------------------------------
+ * P1-P3 replace the torch graph of model/rba.py:60-100 (RBA.forward: Linear(7,256)-ELU-[Linear(256,256)-ELU]x2
+ * -Linear(256,6), residual * scale, camera 0 pinned, kornia angle_axis_to_rotation_matrix, make_c2w) and
+ * its autograd backward, which mp_slam/mapper.py:456,489-497 run in every bundle-adjustment iteration.
+ * Weights are torch Linear layouts ([out,in] row-major) on the device; hidden must be 256. */
+typedef struct rfx_rba_params {
+    const float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
+    int32_t hidden;
+} rfx_rba_params;
+typedef struct rfx_rba_grads {          /* any pointer may be NULL (that gradient is skipped) */
+    float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
+} rfx_rba_grads;
+size_t rfx_rba_acts_floats(int64_t K);   /* size of `acts` (forward -> backward) */
+size_t rfx_rba_grads_floats(int64_t K);  /* size of the backward workspace */
+/* cam_ids dev [K] int64 (rows of init_r/init_t dev [num_cams,3]); poses16 dev [K,16] row-major c2w. */
+int rfx_rba_forward(const rfx_rba_params* p, const float* init_r, const float* init_t, const int64_t* cam_ids, int64_t K,
+                    int num_cams, float scale, float* poses16, float* acts, rfx_stream stream);
+/* dposes16 dev [K,16] = dL/dc2w; parameter gradients are overwritten (deterministic sums over K). */
+int rfx_rba_backward(const rfx_rba_params* p, const float* acts, int64_t K, const float* dposes16, float scale,
+                     const rfx_rba_grads* g, float* workspace, rfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,14 @@ class SamplerDesc(C.Structure):
                 ("n_range_d", C.c_int32), ("n_samples_d", C.c_int32), ("perturb", C.c_float)]
 
 
+class RbaParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("hidden", C.c_int32)]
+
+
+class RbaGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")]
+
+
 _P = C.c_void_p
 _F3 = C.c_float * 3
 _F6 = C.c_float * 6
@@ -85,6 +93,10 @@ PROTOTYPES = {
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
+    "rfx_rba_acts_floats": (C.c_size_t, [_l]),
+    "rfx_rba_grads_floats": (C.c_size_t, [_l]),
+    "rfx_rba_forward": (_i, [C.POINTER(RbaParams), _P, _P, _P, _l, _i, _f, _P, _P, _P]),
+    "rfx_rba_backward": (_i, [C.POINTER(RbaParams), _P, _l, _P, _f, C.POINTER(RbaGrads), _P, _P]),
     "rfx_mc_count": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _P]),
     "rfx_mc_emit": (_i, [_P, _P, _i, _i, _i, _f, _P, _i, _P, _P, _P, _P, _P]),
     "rfx_render_rays": (_i, [C.POINTER(FieldDesc), C.POINTER(SamplerDesc), _P, _P, _P, _P, _l, _D6, _i, _f, _P, _P, _P]),

@@ -1,0 +1,234 @@
+// rfx_pose.hip -- the RBA pose-refinement MLP as three launches instead of ~80 ATen ops.
+// Replaces the host-side torch graph of the reference's model/rba.py:60-100 (7 -> 256 -> 256 -> 256 -> 6
+// ELU MLP, residuals scaled by `scale`, camera 0 pinned, then kornia's angle_axis_to_rotation_matrix)
+// that every bundle-adjustment iteration runs forward and backward (mp_slam/mapper.py:456,489-497).
+// K (keyframes) is small -- tens to a few hundred -- so the work is latency, not throughput:
+//   P1 rba_forward_kernel   block = camera, thread = hidden unit; activations kept for the backward
+//   P2 rba_backward_kernel  block = camera: dL/dpose -> dL/d(axis-angle, t) -> pre-activation grads
+//   P3 rba_wgrad_kernel     thread = parameter element, loops over the cameras (deterministic sums)
+#include "rfx_common.h"
+
+namespace rfx {
+
+constexpr int RBA_H = 256;                 // hidden width (reference model/rba.py:71-75)
+constexpr int RBA_IN = 7;
+constexpr int RBA_OUT = 6;
+constexpr int RBA_ACT_LD = 8 + 3 * RBA_H + 8;      // inp[8] | H1 | H2 | H3 | aa[3], keep, pad
+constexpr int RBA_GRAD_LD = 3 * RBA_H + 8;         // dP1 | dP2 | dP3 | dout[6], pad
+
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.f : h + 1.f; }
+
+// kornia 0.6.12 angle_axis_to_rotation_matrix: Rodrigues with w = aa / (theta + eps); first-order
+// branch below theta^2 = eps.  R row-major.
+__device__ void rodrigues(const float aa[3], float eps, float R[9]) {
+    const float t2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    if (t2 > eps) {
+        const float th = sqrtf(t2), inv = 1.0f / (th + eps);
+        const float w0 = aa[0] * inv, w1 = aa[1] * inv, w2 = aa[2] * inv;
+        const float c = cosf(th), s = sinf(th), k = 1.0f - c;
+        R[0] = c + k * w0 * w0;      R[1] = -s * w2 + k * w0 * w1; R[2] = s * w1 + k * w0 * w2;
+        R[3] = s * w2 + k * w1 * w0; R[4] = c + k * w1 * w1;       R[5] = -s * w0 + k * w1 * w2;
+        R[6] = -s * w1 + k * w2 * w0; R[7] = s * w0 + k * w2 * w1; R[8] = c + k * w2 * w2;
+    } else {
+        R[0] = 1.f;    R[1] = -aa[2]; R[2] = aa[1];
+        R[3] = aa[2];  R[4] = 1.f;    R[5] = -aa[0];
+        R[6] = -aa[1]; R[7] = aa[0];  R[8] = 1.f;
+    }
+}
+
+// dL/daa given G = dL/dR (row-major), for the same formula
+__device__ void rodrigues_backward(const float aa[3], float eps, const float G[9], float daa[3]) {
+    const float gS[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};
+    const float t2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    if (!(t2 > eps)) { daa[0] = gS[0]; daa[1] = gS[1]; daa[2] = gS[2]; return; }
+    const float th = sqrtf(t2), inv = 1.0f / (th + eps);
+    const float w[3] = {aa[0] * inv, aa[1] * inv, aa[2] * inv};
+    const float c = cosf(th), s = sinf(th), k = 1.0f - c;
+    float Gw[3], Gtw[3], gWW = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        Gw[i] = G[3 * i] * w[0] + G[3 * i + 1] * w[1] + G[3 * i + 2] * w[2];
+        Gtw[i] = G[i] * w[0] + G[3 + i] * w[1] + G[6 + i] * w[2];
+        gWW += Gw[i] * w[i];
+    }
+    const float dc = (G[0] + G[4] + G[8]) - gWW;
+    const float ds = gS[0] * w[0] + gS[1] * w[1] + gS[2] * w[2];
+    float dw[3], dth = -s * dc + c * ds;
+    for (int i = 0; i < 3; ++i) {
+        dw[i] = s * gS[i] + k * (Gw[i] + Gtw[i]);
+        dth -= dw[i] * aa[i] * inv * inv;
+    }
+    for (int i = 0; i < 3; ++i) daa[i] = dw[i] * inv + dth * aa[i] / th;
+}
+
+struct RbaW {
+    const float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
+};
+struct RbaG {
+    float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
+};
+
+__device__ __forceinline__ float dot_row(const float* __restrict__ row, const float* __restrict__ v, int n) {
+    float acc = 0.f;
+    for (int i = 0; i < n; i += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(row + i);
+        acc = fmaf(a.x, v[i], acc); acc = fmaf(a.y, v[i + 1], acc);
+        acc = fmaf(a.z, v[i + 2], acc); acc = fmaf(a.w, v[i + 3], acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(RBA_H) void rba_forward_kernel(RbaW W, const float* __restrict__ init_r,
+                                                            const float* __restrict__ init_t, const int64_t* __restrict__ cam_ids,
+                                                            int num_cams, float scale, float eps, float* __restrict__ poses,
+                                                            float* __restrict__ acts) {
+    __shared__ float sa[RBA_H], sb[RBA_H], sin7[8], sout[8];
+    const int k = blockIdx.x, j = threadIdx.x;
+    const int64_t id = cam_ids[k];
+    float* __restrict__ row = acts + (size_t)k * RBA_ACT_LD;
+    if (j < 8) {
+        float v = 0.f;
+        if (j == 0) v = ((float)id / (float)num_cams) * 2.0f - 1.0f;
+        else if (j < 4) v = init_r[id * 3 + (j - 1)];
+        else if (j < 7) v = init_t[id * 3 + (j - 4)];
+        sin7[j] = v;
+        row[j] = v;
+    }
+    __syncthreads();
+    float h = W.b0[j];
+    for (int i = 0; i < RBA_IN; ++i) h = fmaf(W.w0[j * RBA_IN + i], sin7[i], h);
+    h = elu(h);
+    sa[j] = h; row[8 + j] = h;
+    __syncthreads();
+    h = elu(W.b1[j] + dot_row(W.w1 + (size_t)j * RBA_H, sa, RBA_H));
+    sb[j] = h; row[8 + RBA_H + j] = h;
+    __syncthreads();
+    h = elu(W.b2[j] + dot_row(W.w2 + (size_t)j * RBA_H, sb, RBA_H));
+    sa[j] = h; row[8 + 2 * RBA_H + j] = h;          // sa was last read before the previous barrier
+    __syncthreads();
+    if (j < RBA_OUT) {
+        const float keep = id != 0 ? 1.0f : 0.0f;    // camera 0 is the gauge (reference rba.py:90-91)
+        sout[j] = (W.b3[j] + dot_row(W.w3 + (size_t)j * RBA_H, sa, RBA_H)) * scale * keep;
+    }
+    __syncthreads();
+    if (j == 0) {
+        const float aa[3] = {sout[0] + sin7[1], sout[1] + sin7[2], sout[2] + sin7[3]};
+        float R[9];
+        rodrigues(aa, eps, R);
+        float* __restrict__ P = poses + (size_t)k * 16;
+        for (int r = 0; r < 3; ++r) {
+            P[4 * r] = R[3 * r]; P[4 * r + 1] = R[3 * r + 1]; P[4 * r + 2] = R[3 * r + 2];
+            P[4 * r + 3] = sout[3 + r] + sin7[4 + r];
+        }
+        P[12] = 0.f; P[13] = 0.f; P[14] = 0.f; P[15] = 1.f;
+        float* tail = row + 8 + 3 * RBA_H;
+        tail[0] = aa[0]; tail[1] = aa[1]; tail[2] = aa[2]; tail[3] = id != 0 ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(RBA_H) void rba_backward_kernel(RbaW W, const float* __restrict__ acts,
+                                                             const float* __restrict__ dposes, float scale, float eps,
+                                                             float* __restrict__ grads) {
+    __shared__ float sa[RBA_H], sb[RBA_H], sd[8];
+    const int k = blockIdx.x, j = threadIdx.x;
+    const float* __restrict__ row = acts + (size_t)k * RBA_ACT_LD;
+    float* __restrict__ g = grads + (size_t)k * RBA_GRAD_LD;
+    if (j == 0) {
+        const float* __restrict__ D = dposes + (size_t)k * 16;
+        const float* tail = row + 8 + 3 * RBA_H;
+        const float aa[3] = {tail[0], tail[1], tail[2]};
+        const float G[9] = {D[0], D[1], D[2], D[4], D[5], D[6], D[8], D[9], D[10]};
+        float daa[3];
+        rodrigues_backward(aa, eps, G, daa);
+        const float f = scale * tail[3];
+        sd[0] = daa[0] * f; sd[1] = daa[1] * f; sd[2] = daa[2] * f;
+        sd[3] = D[3] * f; sd[4] = D[7] * f; sd[5] = D[11] * f;
+        for (int o = 0; o < RBA_OUT; ++o) g[3 * RBA_H + o] = sd[o];
+    }
+    __syncthreads();
+    float v = 0.f;
+    for (int o = 0; o < RBA_OUT; ++o) v = fmaf(W.w3[o * RBA_H + j], sd[o], v);
+    v *= elu_grad_from_out(row[8 + 2 * RBA_H + j]);
+    sa[j] = v; g[2 * RBA_H + j] = v;                 // dP3
+    __syncthreads();
+    v = 0.f;
+    for (int i = 0; i < RBA_H; ++i) v = fmaf(W.w2[(size_t)i * RBA_H + j], sa[i], v);
+    v *= elu_grad_from_out(row[8 + RBA_H + j]);
+    sb[j] = v; g[RBA_H + j] = v;                     // dP2
+    __syncthreads();
+    v = 0.f;
+    for (int i = 0; i < RBA_H; ++i) v = fmaf(W.w1[(size_t)i * RBA_H + j], sb[i], v);
+    v *= elu_grad_from_out(row[8 + j]);
+    g[j] = v;                                        // dP1
+}
+
+// parameter gradients, overwritten: element e of the concatenation [w0 | b0 | w1 | b1 | w2 | b2 | w3 | b3]
+__global__ __launch_bounds__(256) void rba_wgrad_kernel(const float* __restrict__ acts, const float* __restrict__ grads, int K,
+                                                        RbaG G) {
+    constexpr int N0 = RBA_H * RBA_IN, N1 = RBA_H * RBA_H, N3 = RBA_OUT * RBA_H;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int g_off, a_off, ld_in, n_in;       // column of the pre-activation grad block, of the input activation block
+    float* out;
+    bool bias = false;
+    if (e < N0) { g_off = 0; a_off = 0; n_in = RBA_IN; out = G.w0; }
+    else if ((e -= N0) < RBA_H) { g_off = 0; a_off = 0; n_in = 1; out = G.b0; bias = true; }
+    else if ((e -= RBA_H) < N1) { g_off = RBA_H; a_off = 8; n_in = RBA_H; out = G.w1; }
+    else if ((e -= N1) < RBA_H) { g_off = RBA_H; a_off = 0; n_in = 1; out = G.b1; bias = true; }
+    else if ((e -= RBA_H) < N1) { g_off = 2 * RBA_H; a_off = 8 + RBA_H; n_in = RBA_H; out = G.w2; }
+    else if ((e -= N1) < RBA_H) { g_off = 2 * RBA_H; a_off = 0; n_in = 1; out = G.b2; bias = true; }
+    else if ((e -= RBA_H) < N3) { g_off = 3 * RBA_H; a_off = 8 + 2 * RBA_H; n_in = RBA_H; out = G.w3; }
+    else if ((e -= N3) < RBA_OUT) { g_off = 3 * RBA_H; a_off = 0; n_in = 1; out = G.b3; bias = true; }
+    else return;
+    (void)ld_in;
+    if (!out) return;
+    const int i = e / n_in, jj = e - i * n_in;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float gp = grads[(size_t)k * RBA_GRAD_LD + g_off + i];
+        acc = bias ? acc + gp : fmaf(gp, acts[(size_t)k * RBA_ACT_LD + a_off + jj], acc);
+    }
+    out[e] = acc;
+}
+
+}  // namespace rfx
+
+using namespace rfx;
+
+extern "C" {
+
+size_t rfx_rba_acts_floats(int64_t K) { return K > 0 ? (size_t)K * RBA_ACT_LD : 0; }
+size_t rfx_rba_grads_floats(int64_t K) { return K > 0 ? (size_t)K * RBA_GRAD_LD : 0; }
+
+static bool rba_params_ok(const rfx_rba_params* p) {
+    return p && p->w0 && p->b0 && p->w1 && p->b1 && p->w2 && p->b2 && p->w3 && p->b3 && p->hidden == RBA_H;
+}
+
+int rfx_rba_forward(const rfx_rba_params* p, const float* init_r, const float* init_t, const int64_t* cam_ids, int64_t K,
+                    int num_cams, float scale, float* poses16, float* acts, rfx_stream stream) {
+    if (K == 0) return RFX_OK;
+    if (p && p->hidden != RBA_H) return RFX_ERR_UNSUPPORTED;
+    if (!rba_params_ok(p) || !init_r || !init_t || !cam_ids || !poses16 || !acts || K < 0 || num_cams <= 0) return RFX_ERR_ARG;
+    RbaW W{p->w0, p->b0, p->w1, p->b1, p->w2, p->b2, p->w3, p->b3};
+    hipLaunchKernelGGL(rba_forward_kernel, dim3((unsigned)K), dim3(RBA_H), 0, as_stream(stream), W, init_r, init_t, cam_ids,
+                       num_cams, scale, 1e-6f, poses16, acts);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_rba_backward(const rfx_rba_params* p, const float* acts, int64_t K, const float* dposes16, float scale,
+                     const rfx_rba_grads* g, float* workspace, rfx_stream stream) {
+    if (K == 0) return RFX_OK;
+    if (p && p->hidden != RBA_H) return RFX_ERR_UNSUPPORTED;
+    if (!rba_params_ok(p) || !acts || !dposes16 || !g || !workspace || K < 0) return RFX_ERR_ARG;
+    RbaW W{p->w0, p->b0, p->w1, p->b1, p->w2, p->b2, p->w3, p->b3};
+    hipLaunchKernelGGL(rba_backward_kernel, dim3((unsigned)K), dim3(RBA_H), 0, as_stream(stream), W, acts, dposes16, scale, 1e-6f,
+                       workspace);
+    RFX_LAUNCH_CHECK();
+    RbaG G{g->w0, g->b0, g->w1, g->b1, g->w2, g->b2, g->w3, g->b3};
+    const int total = RBA_H * RBA_IN + RBA_H + 2 * (RBA_H * RBA_H + RBA_H) + RBA_OUT * RBA_H + RBA_OUT;
+    hipLaunchKernelGGL(rba_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), acts, workspace, (int)K, G);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+}  // extern "C"

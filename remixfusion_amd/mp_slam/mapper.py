@@ -188,6 +188,10 @@ class Mapper:
         current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
         all_index = torch.arange(0, poses.shape[0] + 1, device=self.device).unsqueeze(-1)
         poses_all = self.model.rba(all_index)
+        if not m["opt_pose"]:
+            # no optimizer consumes pose gradients in this phase (the reference still back-propagates into the
+            # RBA MLP, :489-497, and discards the result): cut the graph at the poses
+            poses_all = poses_all.detach()
         for i in range(m["BA_iters"]):
             rays, ids_all = self._sample_rays(current_rays)
             rays_o, rays_d, target_s, target_d = self._world_rays(rays, ids_all, poses_all)
