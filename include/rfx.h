@@ -254,6 +254,21 @@ int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* g
  * Deterministic in (seed, population). */
 int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream);
 
+/* M1 ray batch of one optimisation iteration: replaces the host glue of mp_slam/mapper.py:394-409
+ * (KeyFrameDatabase.sample_global_rays + random.sample over the current frame + torch.cat + poses_all[ids]
+ * + rays_o/rays_d).  Rays are 7 floats (camera dir 3 | rgb 3 | depth 1).  The first n_kf_samples rays are
+ * rfx_random_subset(seed_kf, rays_per_kf*num_kf) of kf_rays dev [num_kf*rays_per_kf, 7], posed by
+ * poses16[kf_frame_ids[slot] / keyframe_every]; the last n_cur are rfx_random_subset(seed_cur,
+ * cur_population) of cur_rays, posed by poses16[K-1].  Outputs dev: rays_o/rays_d/target_rgb/d_cam [n,3],
+ * target_d [n], pose_idx int32 [n]. */
+int rfx_gather_rays(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                    uint64_t seed_cur, const float* poses16, int K, float* rays_o, float* rays_d, float* target_rgb,
+                    float* target_d, float* d_cam, int32_t* pose_idx, rfx_stream stream);
+/* its backward w.r.t. the poses: dposes16 dev [K,16] (overwritten) from g_o/g_d dev [n,3] (either may be NULL). */
+int rfx_pose_grad(const float* g_o, const float* g_d, const float* d_cam, const int32_t* pose_idx, int64_t n, int K,
+                  float* dposes16, rfx_stream stream);
+
 /* Fused render (SLAM.render_single, mp_slam/slam.py:290-344): S1 + points + Q1 + R1 in one launch,
  * one wave per ray; nothing but rays, rgb and depth touches HBM.  u01 dev [n,S] (NULL = no jitter). */
 int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const float* rays_o,

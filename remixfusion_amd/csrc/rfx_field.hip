@@ -630,37 +630,45 @@ __global__ __launch_bounds__(256) void field_dw_partial_kernel(BwdWs ws, const f
         a4 = mfma32(dy4, h3, a4);
         (void)gg;
     }
-    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  Write this wave's partial.
-    float* out = partial + w_id * DW_TOTAL;
+    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  The four waves of the block are
+    // summed in LDS in a fixed order (wave 0 stores, waves 1..3 add in turn), then the block writes ONE partial.
+    __shared__ float acc[DW_TOTAL];
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wv == turn) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = krow(r, h);
+            for (int r = 0; r < 16; ++r) {
+                const int o = krow(r, h);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int i1 = 32 * j + lo;
-            if (i1 < N_IN1) out[o * N_IN1 + i1] = a1[j][r];
-            if (i1 < N_IN3) out[N_H * N_IN1 + N_OUT2 * N_H + o * N_IN3 + i1] = a3[j][r];
+                for (int j = 0; j < 3; ++j) {
+                    const int i1 = 32 * j + lo;
+                    if (i1 < N_IN1) { float& d = acc[o * N_IN1 + i1]; d = turn ? d + a1[j][r] : a1[j][r]; }
+                    if (i1 < N_IN3) { float& d = acc[N_H * N_IN1 + N_OUT2 * N_H + o * N_IN3 + i1]; d = turn ? d + a3[j][r] : a3[j][r]; }
+                }
+                if (o < N_OUT2) { float& d = acc[N_H * N_IN1 + o * N_H + lo]; d = turn ? d + a2[r] : a2[r]; }
+                if (o < N_OUT4) { float& d = acc[N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + o * N_H + lo]; d = turn ? d + a4[r] : a4[r]; }
+            }
         }
-        if (o < N_OUT2) out[N_H * N_IN1 + o * N_H + lo] = a2[r];
-        if (o < N_OUT4) out[N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + o * N_H + lo] = a4[r];
+        __syncthreads();
     }
+    float* out = partial + (size_t)blockIdx.x * DW_TOTAL;
+    for (int i = threadIdx.x; i < DW_TOTAL; i += 256) out[i] = acc[i];
 }
 
-// deterministic second stage: block = 32 consecutive outputs x 8 slices of the partial list
+// deterministic second stage: block = 16 consecutive outputs x 16 slices of the partial list
 __global__ __launch_bounds__(256) void field_dw_reduce_kernel(const float* __restrict__ partial, int n_partials,
                                                               float* __restrict__ dw1, float* __restrict__ dw2,
                                                               float* __restrict__ dw3, float* __restrict__ dw4) {
-    __shared__ float red[8][32];
-    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
+    __shared__ float red[16][16];
+    const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
     float s = 0.f;
     if (i < DW_TOTAL)
-        for (int k = slice; k < n_partials; k += 8) s += partial[(size_t)k * DW_TOTAL + i];
+        for (int k = slice; k < n_partials; k += 16) s += partial[(size_t)k * DW_TOTAL + i];
     red[slice][col] = s;
     __syncthreads();
     if (slice != 0 || i >= DW_TOTAL) return;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) s += red[k][col];
+    for (int k = 1; k < 16; ++k) s += red[k][col];
     const int o1 = N_H * N_IN1, o2 = o1 + N_OUT2 * N_H, o3 = o2 + N_H * N_IN3;
     if (i < o1) { if (dw1) dw1[i] += s; }
     else if (i < o2) { if (dw2) dw2[i - o1] += s; }
@@ -867,7 +875,7 @@ int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float*
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 31) / 32), dim3(256), 0, st, ws.partial, DW_BLOCKS * 4,
+    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 15) / 16), dim3(256), 0, st, ws.partial, DW_BLOCKS,
                        dw1, dw2, dw3, dw4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

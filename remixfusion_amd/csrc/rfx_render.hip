@@ -481,10 +481,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-__global__ __launch_bounds__(256) void random_subset_kernel(uint64_t seed, int64_t N, int64_t k, int half_bits,
-                                                            int64_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
+__device__ __forceinline__ int64_t feistel_index(uint64_t seed, int64_t i, int64_t N, int half_bits) {
     const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
     uint64_t x = (uint64_t)i;
     do {
@@ -499,7 +496,93 @@ __global__ __launch_bounds__(256) void random_subset_kernel(uint64_t seed, int64
         }
         x = ((uint64_t)l << half_bits) | r;
     } while (x >= (uint64_t)N);       // cycle walking: a permutation of [0, 2^(2 half_bits)) restricted to [0, N)
-    out[i] = (int64_t)x;
+    return (int64_t)x;
+}
+
+static int feistel_half_bits(int64_t population) {
+    int bits = 1;
+    while (bits < 63 && (1LL << bits) < population) ++bits;
+    return (bits + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void random_subset_kernel(uint64_t seed, int64_t N, int64_t k, int half_bits,
+                                                            int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    out[i] = feistel_index(seed, i, N, half_bits);
+}
+
+// ------------------------------------------------------------------ M1: ray batch of one BA iteration
+// Replaces the per-iteration host glue of mp_slam/mapper.py:394-409 (sample_global_rays + random.sample of
+// current-frame pixels + cat + poses_all[ids] + rays_o / rays_d): one launch draws both index sets,
+// gathers the 7-float rays (cam dir 3 | rgb 3 | depth 1), and rotates them by the ray's pose.
+struct GatherK {
+    const float* kf_rays; int64_t rays_per_kf, kf_population; const int64_t* kf_frame_ids; int keyframe_every;
+    const float* cur_rays; int64_t cur_population;
+    int64_t n_kf, n_cur; uint64_t seed_kf, seed_cur; int hb_kf, hb_cur;
+    const float* poses; int K;
+};
+
+__global__ __launch_bounds__(256) void gather_rays_kernel(GatherK g, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                          float* __restrict__ tgt_rgb, float* __restrict__ tgt_d,
+                                                          float* __restrict__ d_cam, int* __restrict__ pose_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_kf + g.n_cur) return;
+    const float* ray;
+    int k;
+    if (i < g.n_kf) {
+        const int64_t idx = feistel_index(g.seed_kf, i, g.kf_population, g.hb_kf);
+        ray = g.kf_rays + idx * 7;
+        k = (int)(g.kf_frame_ids[idx / g.rays_per_kf] / g.keyframe_every);
+        k = ((k % g.K) + g.K) % g.K;
+    } else {
+        const int64_t idx = feistel_index(g.seed_cur, i - g.n_kf, g.cur_population, g.hb_cur);
+        ray = g.cur_rays + idx * 7;
+        k = g.K - 1;                                   // the current frame rides on the last pose
+    }
+    const float dc[3] = {ray[0], ray[1], ray[2]};
+    const float* __restrict__ P = g.poses + (size_t)k * 16;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rays_d[i * 3 + r] = P[4 * r] * dc[0] + P[4 * r + 1] * dc[1] + P[4 * r + 2] * dc[2];
+        rays_o[i * 3 + r] = P[4 * r + 3];
+        tgt_rgb[i * 3 + r] = ray[3 + r];
+        d_cam[i * 3 + r] = dc[r];
+    }
+    tgt_d[i] = ray[6];
+    pose_idx[i] = k;
+}
+
+// dL/dposes[k] (rows 0..2): rotation part += g_d (x) d_cam, translation column += g_o; block = pose,
+// fixed-order block reduction (deterministic).
+__global__ __launch_bounds__(256) void pose_grad_kernel(const float* __restrict__ g_o, const float* __restrict__ g_d,
+                                                        const float* __restrict__ d_cam, const int* __restrict__ pose_idx,
+                                                        int64_t n, float* __restrict__ dposes) {
+    __shared__ float red[256][13];
+    const int k = blockIdx.x;
+    float a[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) a[q] = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        if (pose_idx[i] != k) continue;
+        const float dc[3] = {d_cam[i * 3], d_cam[i * 3 + 1], d_cam[i * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float gd = g_d ? g_d[i * 3 + r] : 0.f;
+            a[4 * r] += gd * dc[0]; a[4 * r + 1] += gd * dc[1]; a[4 * r + 2] += gd * dc[2];
+            a[4 * r + 3] += g_o ? g_o[i * 3 + r] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) red[threadIdx.x][q] = a[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) red[threadIdx.x][q] += red[threadIdx.x + s][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) dposes[(size_t)k * 16 + threadIdx.x] = threadIdx.x < 12 ? red[0][threadIdx.x] : 0.f;
 }
 
 static int make_sampler(const rfx_sampler_desc* d, SamplerK* k) {
@@ -653,12 +736,48 @@ int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* g
 int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream) {
     if (k == 0) return RFX_OK;
     if (!out || population <= 0 || k < 0 || k > population) return RFX_ERR_ARG;
-    int bits = 1;
-    while (bits < 63 && (1LL << bits) < population) ++bits;
-    const int half_bits = (bits + 1) / 2;
+    const int half_bits = feistel_half_bits(population);
     if (half_bits > 31) return RFX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(random_subset_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
                        population, k, half_bits, out);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_gather_rays(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                    uint64_t seed_cur, const float* poses16, int K, float* rays_o, float* rays_d, float* target_rgb,
+                    float* target_d, float* d_cam, int32_t* pose_idx, rfx_stream stream) {
+    const int64_t n = n_kf_samples + n_cur;
+    if (n == 0) return RFX_OK;
+    if (n_kf_samples < 0 || n_cur < 0 || K <= 0 || keyframe_every <= 0 || !poses16 || !rays_o || !rays_d || !target_rgb ||
+        !target_d || !d_cam || !pose_idx)
+        return RFX_ERR_ARG;
+    GatherK g{};
+    g.kf_rays = kf_rays; g.rays_per_kf = rays_per_kf; g.kf_population = rays_per_kf * num_kf; g.kf_frame_ids = kf_frame_ids;
+    g.keyframe_every = keyframe_every; g.cur_rays = cur_rays; g.cur_population = cur_population;
+    g.n_kf = n_kf_samples; g.n_cur = n_cur; g.seed_kf = seed_kf; g.seed_cur = seed_cur; g.poses = poses16; g.K = K;
+    if (n_kf_samples > 0) {
+        if (!kf_rays || !kf_frame_ids || rays_per_kf <= 0 || num_kf <= 0 || n_kf_samples > g.kf_population) return RFX_ERR_ARG;
+        g.hb_kf = feistel_half_bits(g.kf_population);
+        if (g.hb_kf > 31) return RFX_ERR_UNSUPPORTED;
+    }
+    if (n_cur > 0) {
+        if (!cur_rays || cur_population <= 0 || n_cur > cur_population) return RFX_ERR_ARG;
+        g.hb_cur = feistel_half_bits(cur_population);
+        if (g.hb_cur > 31) return RFX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(gather_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), g, rays_o, rays_d,
+                       target_rgb, target_d, d_cam, pose_idx);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_pose_grad(const float* g_o, const float* g_d, const float* d_cam, const int32_t* pose_idx, int64_t n, int K,
+                  float* dposes16, rfx_stream stream) {
+    if (K <= 0 || !dposes16 || n < 0) return RFX_ERR_ARG;
+    if (n > 0 && (!d_cam || !pose_idx)) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(pose_grad_kernel, dim3((unsigned)K), dim3(256), 0, as_stream(stream), g_o, g_d, d_cam, pose_idx, n, dposes16);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -43,6 +43,43 @@ class _WorldRaysFn(torch.autograd.Function):
         return gp, None, None
 
 
+class _RayBatchFn(torch.autograd.Function):
+    """sampling + gather + posing of one iteration's rays in ONE launch (``rfx_gather_rays``; reference
+    mapper.py:394-409), with the pose gradient as one more (``rfx_pose_grad``).  Draws the same indices
+    as ``_sample_rays`` + ``_world_rays`` for the same state of python's ``random``."""
+
+    @staticmethod
+    def forward(ctx, poses_all, kf, current_rays, n_kf_samples, n_cur, keyframe_every):
+        lib = _lib.load()
+        dev = poses_all.device
+        n = int(n_kf_samples) + int(n_cur)
+        P = poses_all.detach().to(torch.float32).contiguous()
+        K = P.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        rays_o, rays_d, tgt, d_cam = (torch.empty((n, 3), **f32) for _ in range(4))
+        tgt_d = torch.empty((n, 1), **f32)
+        pose_idx = torch.empty(n, dtype=torch.int32, device=dev)
+        seed_kf, seed_cur = random.getrandbits(64), random.getrandbits(64)        # same draw order as the unfused path
+        check(lib.rfx_gather_rays(ptr(kf.rays), kf.num_rays_to_save, len(kf), kf.frame_ids_dev.data_ptr(), int(keyframe_every),
+                                  ptr(current_rays), current_rays.shape[0], int(n_kf_samples), int(n_cur), seed_kf, seed_cur,
+                                  ptr(P), K, ptr(rays_o), ptr(rays_d), ptr(tgt), ptr(tgt_d), ptr(d_cam), pose_idx.data_ptr(),
+                                  stream_ptr(dev)), "rfx_gather_rays")
+        ctx.save_for_backward(d_cam, pose_idx)
+        ctx.K = K
+        ctx.mark_non_differentiable(tgt, tgt_d)
+        return rays_o, rays_d, tgt, tgt_d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d, _gt, _gtd):
+        d_cam, pose_idx = ctx.saved_tensors
+        gp = torch.empty((ctx.K, 4, 4), dtype=torch.float32, device=d_cam.device)
+        go = g_o.to(torch.float32).contiguous() if g_o is not None else None
+        gd = g_d.to(torch.float32).contiguous() if g_d is not None else None
+        check(_lib.load().rfx_pose_grad(ptr(go), ptr(gd), ptr(d_cam), pose_idx.data_ptr(), d_cam.shape[0], ctx.K, ptr(gp),
+                                        stream_ptr(d_cam.device)), "rfx_pose_grad")
+        return gp, None, None, None, None, None
+
+
 class Mapper:
     def __init__(self, config, SLAM, model) -> None:
         self.config, self.slam, self.model = config, SLAM, model
@@ -153,6 +190,15 @@ class Mapper:
         rays_o, rays_d = _WorldRaysFn.apply(poses_all, ids_all, rays[..., :3].contiguous())
         return rays_o, rays_d, rays[..., 3:6], rays[..., 6:7]
 
+    def _ray_batch(self, current_rays, poses_all):
+        """rays of one iteration: mapping.sample keyframe rays + the current frame's share, in world space."""
+        m = self.config["mapping"]
+        if not self.keyframe.device_sampling:          # reference sampling (python random.sample on the host)
+            rays, ids_all = self._sample_rays(current_rays)
+            return self._world_rays(rays, ids_all, poses_all)
+        n_cur = max(m["sample"] // len(self.keyframe.frame_ids), m["min_pixels_cur"])
+        return _RayBatchFn.apply(poses_all, self.keyframe, current_rays, m["sample"], n_cur, m["keyframe_every"])
+
     def global_mapping(self, batch, cur_frame_id):
         """map update over all keyframes + the current frame (reference :366-423)."""
         m = self.config["mapping"]
@@ -166,8 +212,7 @@ class Mapper:
             poses_all = poses
             poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze().clone()
         for i in range(m["iters"]):
-            rays, ids_all = self._sample_rays(current_rays)
-            rays_o, rays_d, target_s, target_d = self._world_rays(rays, ids_all, poses_all)
+            rays_o, rays_d, target_s, target_d = self._ray_batch(current_rays, poses_all)
             ret = self.model.mapping(rays_o, rays_d, target_s, target_d)
             loss = self.slam.get_loss_from_ret(ret, smooth=True, iter=i)
             loss.backward(retain_graph=True)
@@ -193,8 +238,7 @@ class Mapper:
             # RBA MLP, :489-497, and discards the result): cut the graph at the poses
             poses_all = poses_all.detach()
         for i in range(m["BA_iters"]):
-            rays, ids_all = self._sample_rays(current_rays)
-            rays_o, rays_d, target_s, target_d = self._world_rays(rays, ids_all, poses_all)
+            rays_o, rays_d, target_s, target_d = self._ray_batch(current_rays, poses_all)
             ret = self.model.mapping(rays_o, rays_d, target_s, target_d, clamp=True)
             loss = self.slam.get_loss_from_ret(ret, fs=True, smooth=True, iter=i)
             loss.backward(retain_graph=True)

@@ -59,3 +59,44 @@ def test_fused_rba_in_the_pose_loop():
     a, b = m1(ids), m2.forward_torch(ids)
     assert float((a - b).detach().abs().max()) < 1e-4
     assert float((a[1:, :3, 3] - target[1:, :3, 3]).detach().abs().mean()) < 0.05 - 1e-3      # moved towards the target
+
+
+def test_fused_ray_batch_equals_sample_plus_world_rays():
+    """rfx_gather_rays / rfx_pose_grad vs the unfused host glue (sample_global_rays + random_subset + cat +
+    poses[ids] + einsum), same python `random` state -> same rays, same pose gradient."""
+    import random
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+    cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+    cfg["mapping"].update({"first_iters": 5, "sample": 512, "iters": 1, "BA_iters": 1})
+    pipe = MappingPipeline(cfg, n_frames=30, seed=1)
+    frames = pipe.prefetch(list(range(17)))
+    pipe.start(frames[0])
+    for i in range(1, 17):
+        pipe.step(i, frames[i])
+    mp = pipe.mapper
+    assert len(mp.keyframe) == 4 and mp.keyframe.device_sampling
+    b = frames[16]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    K = 5
+    g = torch.Generator().manual_seed(2)
+    poses = torch.eye(4).repeat(K, 1, 1)
+    poses[:, :3, :] += 0.3 * torch.randn((K, 3, 4), generator=g)
+    p1 = poses.cuda().requires_grad_(True)
+    p2 = poses.cuda().requires_grad_(True)
+    random.seed(77)
+    o1, d1, s1, t1 = mp._ray_batch(cur, p1)
+    random.seed(77)
+    rays, ids_all = mp._sample_rays(cur)
+    o2, d2, s2, t2 = mp._world_rays(rays, ids_all, p2)
+    n = 512 + max(512 // 4, cfg["mapping"]["min_pixels_cur"])
+    assert o1.shape == (n, 3) and t1.shape == (n, 1)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(t1, t2)
+    assert float((d1 - d2).detach().abs().max()) < 1e-6
+    go, gd = torch.randn((n, 3), generator=g).cuda(), torch.randn((n, 3), generator=g).cuda()
+    (g1,) = torch.autograd.grad([o1, d1], [p1], [go, gd])
+    (g2,) = torch.autograd.grad([o2, d2], [p2], [go, gd])
+    assert float((g1 - g2).abs().max()) < 1e-4 * float(g2.abs().max())
+    assert float(g1[:, 3].abs().max()) == 0.0
