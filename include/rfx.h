@@ -248,6 +248,12 @@ int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const floa
  * dfeat = gscale_dev[0] * scale * d(sum)/d feat. */
 int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream stream);
 int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream);
+/* the lattice itself (mp_slam/slam.py:198-207): pts dev [P^3,3] = ((ijk + u6[3:6]) * voxel + lo + u6[0:3] * offset_max
+ * + margin), offset_max = hi - lo - P*voxel - 2*margin, divided by (hi - lo) after subtracting lo when
+ * `normalise`; u6 dev [6] uniform(0,1).  bbox = (x0,x1,y0,y1,z0,z1); bbox_f64 = 1 reproduces torch's float64 promotion
+ * for non-integer bounds, 0 the integer-bound case (jitter truncated to 0, fp32 arithmetic). */
+int rfx_tv_lattice(const float* u6, int P, float voxel, float margin, const double bbox[6], int bbox_f64, int normalise,
+                   float* pts, rfx_stream stream);
 
 /* k distinct pseudo-random indices out of range(population), on the device: replaces python's
  * random.sample in the ray samplers (model/keyframe.py:33,89; mp_slam/mapper.py:396).  out dev int64[k].

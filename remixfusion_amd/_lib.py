@@ -93,6 +93,7 @@ PROTOTYPES = {
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
+    "rfx_tv_lattice": (_i, [_P, _i, _f, _f, _D6, _i, _i, _P, _P]),
     "rfx_gather_rays": (_i, [_P, _l, _l, _P, _i, _P, _l, _l, _l, C.c_uint64, C.c_uint64, _P, _i, _P, _P, _P, _P, _P, _P, _P]),
     "rfx_pose_grad": (_i, [_P, _P, _P, _P, _l, _i, _P, _P]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),

@@ -472,6 +472,40 @@ __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restric
     }
 }
 
+// TV lattice points (mp_slam/slam.py:198-207): P^3 points at spacing `voxel`, anchored at
+// bound_lo + offset with offset = u[0:3] * offset_max + margin, plus a sub-voxel jitter u[3:6], then
+// normalised by the bound.  torch's type promotion is reproduced: a float64 bound -> everything in
+// double with the jitter; an integer bound -> the jitter's cast to int64 truncates it to 0 and the rest runs in fp32.
+struct LatticeK {
+    double lo[3], hi[3];
+    int f64, normalise, P;
+    float voxel, margin;
+};
+
+__global__ __launch_bounds__(256) void tv_lattice_kernel(LatticeK L, const float* __restrict__ u6, float* __restrict__ pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)L.P * L.P * L.P;
+    if (i >= n) return;
+    const int c[3] = {(int)(i / ((int64_t)L.P * L.P)), (int)((i / L.P) % L.P), (int)(i % L.P)};
+    const double grid = (double)(L.P) * (double)L.voxel;          // (sample_points - 1) * voxel_size
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float out;
+        if (L.f64) {
+            const double ext = L.hi[d] - L.lo[d];
+            const double off = (double)u6[d] * (ext - grid - 2.0 * (double)L.margin) + (double)L.margin;
+            const double p = ((double)c[d] + (double)u6[3 + d]) * (double)L.voxel + L.lo[d] + off;
+            out = (float)(L.normalise ? (p - L.lo[d]) / ext : p);
+        } else {
+            const float ext = (float)(L.hi[d] - L.lo[d]);
+            const float off = u6[d] * ((ext - (float)grid) - (float)(2.0 * (double)L.margin)) + L.margin;
+            const float p = ((float)c[d] * L.voxel + (float)L.lo[d]) + off;
+            out = L.normalise ? (p - (float)L.lo[d]) / ext : p;
+        }
+        pts[i * 3 + d] = out;
+    }
+}
+
 // ------------------------------------------------------------------ distinct random indices
 // Replaces python's random.sample(range(N), k) of the ray samplers (model/keyframe.py:33,89;
 // mp_slam/mapper.py:396): out[i] = pi(i), i < k, where pi is a keyed pseudo-random permutation of
@@ -729,6 +763,18 @@ int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* g
     const int64_t total = (int64_t)P * P * P * C;
     hipLaunchKernelGGL(tv_backward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0,
                        as_stream(stream), feat, P, C, scale, gscale_dev, dfeat);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_tv_lattice(const float* u6, int P, float voxel, float margin, const double bbox[6], int bbox_f64, int normalise,
+                   float* pts, rfx_stream stream) {
+    if (!u6 || !bbox || !pts || P <= 0 || !(voxel > 0.f)) return RFX_ERR_ARG;
+    LatticeK L;
+    for (int d = 0; d < 3; ++d) { L.lo[d] = bbox[2 * d]; L.hi[d] = bbox[2 * d + 1]; }
+    L.f64 = bbox_f64 ? 1 : 0; L.normalise = normalise ? 1 : 0; L.P = P; L.voxel = voxel; L.margin = margin;
+    const int64_t n = (int64_t)P * P * P;
+    hipLaunchKernelGGL(tv_lattice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), L, u6, pts);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

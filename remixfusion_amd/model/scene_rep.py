@@ -129,7 +129,7 @@ class _MappingFn(torch.autograd.Function):
     (rgb_loss, depth_loss, sdf_loss, fs_loss, rgb_map, depth_map)."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, target_rgb, target_d, table, w1, w2, w3, w4, model, clamp):
+    def forward(ctx, rays_o, rays_d, target_rgb, target_d, table, w1, w2, w3, w4, model, clamp, wvec=None):
         lib = _lib.load()
         cfg = model.config
         tr = cfg["training"]
@@ -163,10 +163,13 @@ class _MappingFn(torch.autograd.Function):
         ctx.model, ctx.clamp, ctx.dims = model, clamp, (n, S)
         ctx.mark_non_differentiable(z)
         del out
-        return lc[0], lc[1], lc[2], lc[3], rgb_map, depth_map, z, raw.view(n, S, 4)
+        # wvec dev [4]: also hand back sum_i w_i * loss_i so the caller's weighting costs no extra graph nodes
+        ctx.wvec = wvec
+        total = torch.dot(lc[:4], wvec) if wvec is not None else lc.new_zeros(())
+        return lc[0], lc[1], lc[2], lc[3], rgb_map, depth_map, z, raw.view(n, S, 4), total
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_sdf, g_fs, g_rgb_map, g_depth_map, _gz, g_raw):
+    def backward(ctx, g_rgb, g_depth, g_sdf, g_fs, g_rgb_map, g_depth_map, _gz, g_raw, g_total):
         lib = _lib.load()
         o, d, z, x01, raw, rgb_map, depth_map, tgt, td, lc, table, w1, w2, w3, w4 = ctx.saved_tensors
         model, (n, S) = ctx.model, ctx.dims
@@ -174,8 +177,13 @@ class _MappingFn(torch.autograd.Function):
         tr = cfg["training"]
         dev = o.device
         st = stream_ptr(dev)
-        zero = lc.new_zeros(())
-        gout = torch.stack([g if g is not None else zero for g in (g_rgb, g_depth, g_sdf, g_fs)]).to(torch.float32).contiguous()
+        singles = (g_rgb, g_depth, g_sdf, g_fs)
+        gout = (g_total.to(torch.float32) * ctx.wvec) if (g_total is not None and ctx.wvec is not None) else None
+        if gout is None or any(g is not None for g in singles):
+            zero = lc.new_zeros(())
+            gs = torch.stack([g if g is not None else zero for g in singles]).to(torch.float32)
+            gout = gs if gout is None else gout + gs
+        gout = gout.contiguous()
         d_raw = torch.empty_like(raw)
         trunc, sc = float(tr["trunc"]), float(cfg["data"]["sc_factor"])
         check(lib.rfx_mapping_loss_backward(ptr(raw), ptr(z), ptr(rgb_map), ptr(depth_map), ptr(tgt), ptr(td), n, S, trunc, sc,
@@ -199,7 +207,7 @@ class _MappingFn(torch.autograd.Function):
             dp = dx.view(n, S, 3) / model._extent_on(dev)
             go = dp.sum(1) if need[0] else None
             gd = (dp * z[..., None]).sum(1) if need[1] else None
-        return go, gd, None, None, dt, dws[0], dws[1], dws[2], dws[3], None, None
+        return go, gd, None, None, dt, dws[0], dws[1], dws[2], dws[3], None, None, None
 
 
 # ------------------------------------------------------------------------------ the module
@@ -427,10 +435,21 @@ class JointEncoding(nn.Module):
             return self.render_rays(rays_o, rays_d, target_d=target_d, tracking=tracking, render_flag=render_flag)
         # train mode: one fused autograd node (sampler + points + field + compositing + losses)
         w1, w2, w3, w4 = self.decoder_res.fused_weights()
-        rgb_l, depth_l, sdf_l, fs_l, rgb_map, depth_map, _z, _raw = _MappingFn.apply(
-            rays_o, rays_d, target_rgb, target_d, self.embed_res_fn.params, w1, w2, w3, w4, self, bool(clamp))
+        rgb_l, depth_l, sdf_l, fs_l, rgb_map, depth_map, _z, _raw, total = _MappingFn.apply(
+            rays_o, rays_d, target_rgb, target_d, self.embed_res_fn.params, w1, w2, w3, w4, self, bool(clamp),
+            self._loss_weights(rays_o.device))
+        # "loss_weighted" = rgb_weight*rgb + depth_weight*depth + sdf_weight*sdf + fs_weight*fs (training.* weights),
+        # what SLAM.get_loss_from_ret assembles from the four entries above, pre-summed inside the node
         return {"rgb_res_loss": rgb_l, "depth_res_loss": depth_l, "sdf_res_loss": sdf_l, "fs_res_loss": fs_l,
-                "rgb_res": rgb_map, "depth_res": depth_map}
+                "rgb_res": rgb_map, "depth_res": depth_map, "loss_weighted": total}
+
+    def _loss_weights(self, device) -> torch.Tensor:
+        tr = self.config["training"]
+        key = (str(device), float(tr["rgb_weight"]), float(tr["depth_weight"]), float(tr["sdf_weight"]), float(tr["fs_weight"]))
+        if getattr(self, "_wvec_key", None) != key:
+            self._wvec = torch.tensor(key[1:], dtype=torch.float32, device=device)
+            self._wvec_key = key
+        return self._wvec
 
     def mapping_unfused(self, rays_o, rays_d, target_rgb, target_d, clamp=False):
         """the same objective assembled from the individual kernels + torch ops (kept for tests: the

@@ -22,8 +22,9 @@ class _SmoothFn(torch.autograd.Function):
     TV gradient + hash scatter backward (reference mp_slam/slam.py:209-215)."""
 
     @staticmethod
-    def forward(ctx, table, pts01, enc, P, denom):
+    def forward(ctx, table, pts01, enc, P, denom, weight=1.0):
         lib = _lib.load()
+        denom = float(denom) / float(weight)          # weight * TV / denom, formed inside the node
         x = pts01.detach().reshape(-1, 3).to(torch.float32).contiguous()
         n = x.shape[0]
         feat = torch.empty((n, enc.n_output_dims), dtype=torch.float32, device=x.device)
@@ -48,7 +49,7 @@ class _SmoothFn(torch.autograd.Function):
         ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)      # staging of the LDS-privatised scatter
         check(lib.rfx_grid_encode_backward(ctx.enc.desc, ptr(table), ptr(x), x.shape[0], ptr(dfeat), ptr(dt), None,
                                            ptr(ws), ws.numel() * 4, st), "rfx_grid_encode_backward")
-        return dt, None, None, None, None
+        return dt, None, None, None, None, None
 
 
 class SLAM:
@@ -119,37 +120,52 @@ class SLAM:
     def get_loss_from_ret(self, ret, rgb=True, sdf=True, depth=True, fs=True, smooth=False, tracking=False, iter=0):
         """weighted sum of the four mapping losses (+ smooth_weight * TV) (reference :145-190)."""
         tr = self.config["training"]
-        loss = 0
-        if rgb:
-            loss += tr["rgb_weight"] * ret["rgb_res_loss"]
-        if depth:
-            loss += tr["depth_weight"] * ret["depth_res_loss"]
-        if sdf:
-            loss += tr["sdf_weight"] * ret["sdf_res_loss"]
-        if fs:
-            loss += tr["fs_weight"] * ret["fs_res_loss"]
+        if rgb and depth and sdf and fs and "loss_weighted" in ret:
+            loss = ret["loss_weighted"]             # the same weighted sum, formed inside the fused mapping node
+        else:
+            loss = 0
+            if rgb:
+                loss += tr["rgb_weight"] * ret["rgb_res_loss"]
+            if depth:
+                loss += tr["depth_weight"] * ret["depth_res_loss"]
+            if sdf:
+                loss += tr["sdf_weight"] * ret["sdf_res_loss"]
+            if fs:
+                loss += tr["fs_weight"] * ret["fs_res_loss"]
         if smooth and tr["smooth_weight"] > 0:
-            loss += tr["smooth_weight"] * self.smoothness(tr["smooth_pts"], tr["smooth_vox"], margin=tr["smooth_margin"])
+            loss = loss + self.smoothness(tr["smooth_pts"], tr["smooth_vox"], margin=tr["smooth_margin"],
+                                          weight=tr["smooth_weight"])
         return loss
 
-    def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05, color=False):
-        """Total variation of the raw hash features on a randomly placed lattice (reference :193-217).
-        The integer lattice is cached on the device instead of being rebuilt on the CPU every call."""
+    def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05, color=False, weight=None):
+        """Total variation of the raw hash features on a randomly placed lattice (reference :193-217);
+        ``weight`` (optional) scales the result inside the autograd node.  The lattice is laid out by
+        ``rfx_tv_lattice`` from six device uniforms (the reference builds it on the CPU every call)."""
+        P = sample_points - 1
+        dev = self.device
+        u6 = torch.rand(6, device=dev)
+        pts = torch.empty((P * P * P, 3), dtype=torch.float32, device=dev)
+        m = self.model
+        check(_lib.load().rfx_tv_lattice(ptr(u6), P, float(voxel_size), float(margin), m._bbox6, m._bbox_f64,
+                                         1 if self.config["grid"]["tcnn_encoding"] else 0, ptr(pts), stream_ptr(dev)),
+              "rfx_tv_lattice")
+        return _SmoothFn.apply(m.embed_res_fn.params, pts, m.embed_res_fn, P, float(sample_points ** 3),
+                               1.0 if weight is None else float(weight))
+
+    def smoothness_points_torch(self, u6, sample_points, voxel_size, margin):
+        """the lattice of the reference as tensor ops (:198-207), from the same six uniforms (tests)."""
         bb = self.bounding_box
         volume = bb[:, 1] - bb[:, 0]
         grid_size = (sample_points - 1) * voxel_size
         offset_max = bb[:, 1] - bb[:, 0] - grid_size - 2 * margin
         # torch.rand is fp32 and then cast like the reference's `.to(offset_max)` / `.to(volume)`: with an
         # all-integer mapping.bound `volume` is int64 and the lattice jitter truncates to 0 (reference quirk)
-        offset = torch.rand(3, device=offset_max.device).to(offset_max.dtype) * offset_max + margin
+        offset = u6[:3].to(offset_max.dtype) * offset_max + margin
         P = sample_points - 1
-        if P not in self._tv_coords:
-            ar = torch.arange(0, P, dtype=torch.long, device=self.device)
-            self._tv_coords[P] = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).float()
-        coords = self._tv_coords[P].to(volume)
-        pts = (coords + torch.rand((1, 1, 1, 3), device=volume.device).to(volume.dtype)) * voxel_size + bb[:, 0] + offset
-        pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0]) if self.config["grid"]["tcnn_encoding"] else pts
-        return _SmoothFn.apply(self.model.embed_res_fn.params, pts_tcnn, self.model.embed_res_fn, P, float(sample_points ** 3))
+        ar = torch.arange(0, P, dtype=torch.long, device=self.device)
+        coords = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).float().to(volume)
+        pts = (coords + u6[3:].reshape(1, 1, 1, 3).to(volume.dtype)) * voxel_size + bb[:, 0] + offset
+        return (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0]) if self.config["grid"]["tcnn_encoding"] else pts
 
     def smoothness_unfused(self, pts_tcnn, sample_points):
         """reference formulation on top of query_sdf_res(embed=True) (kept for tests)."""

@@ -365,14 +365,9 @@ def test_fused_mapping_node_equals_unfused_path_and_tv_node():
     tv.backward()
     ga = m.embed_res_fn.params.grad.clone()
     torch.manual_seed(3)
-    bb = slam.bounding_box
     P = tr["smooth_pts"] - 1
-    offset_max = bb[:, 1] - bb[:, 0] - P * tr["smooth_vox"] - 2 * tr["smooth_margin"]
-    offset = torch.rand(3, device="cuda").to(offset_max.dtype) * offset_max + tr["smooth_margin"]
-    ar = torch.arange(0, P, device="cuda")
-    coords = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), dim=-1).to(bb)
-    pts = (coords + torch.rand((1, 1, 1, 3), device="cuda").to(bb.dtype)) * tr["smooth_vox"] + bb[:, 0] + offset
-    pts01 = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0])
+    u6 = torch.rand(6, device="cuda")                      # the six uniforms slam.smoothness drew
+    pts01 = slam.smoothness_points_torch(u6, tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"])
     m.embed_res_fn.params.grad = None
     tv_ref = slam.smoothness_unfused(pts01, tr["smooth_pts"])
     tv_ref.backward()
@@ -382,6 +377,41 @@ def test_fused_mapping_node_equals_unfused_path_and_tv_node():
     fp = _oracle_params(cfg, m)
     feat = FO.grid_encode(pts01.reshape(-1, 3).float().cpu(), fp.hash_table, fp.hash_meta).reshape(P, P, P, 32)
     _close(tv, FO.smoothness_from_features(feat, tr["smooth_pts"]), 1e-4, 1e-9, "TV vs oracle")
+    # weight folded into the node; weighted sum of the four losses folded into the mapping node
+    torch.manual_seed(3)
+    m.embed_res_fn.params.grad = None
+    tvw = slam.smoothness(tr["smooth_pts"], tr["smooth_vox"], margin=tr["smooth_margin"], weight=0.37)
+    tvw.backward()
+    _close(tvw, 0.37 * tv.detach(), 1e-6, 1e-12, "weighted TV")
+    _close(m.embed_res_fn.params.grad, 0.37 * ga, 2e-3, 1e-3 * float(ga.abs().max()) * 0.37, "weighted TV grad")
+    for p in m.parameters():
+        p.grad = None
+    torch.manual_seed(9)
+    ret = m.mapping(o.cuda(), d.cuda(), tgt.cuda(), td.cuda(), clamp=True)
+    _close(ret["loss_weighted"], FO.total_loss(ret, w).detach(), 1e-6, 1e-9, "loss_weighted")
+    assert slam.get_loss_from_ret(ret) is ret["loss_weighted"]
+    ret["loss_weighted"].backward()
+    _close(m.embed_res_fn.params.grad, ha, 2e-3, 1e-3 * float(ha.abs().max()), "hash grad through loss_weighted")
+
+
+@pytest.mark.parametrize("name", ["office0", "cafeteria"])     # float64 bound / integer bound (jitter truncates, fp32 math)
+def test_tv_lattice_kernel_matches_tensor_ops(name):
+    from remixfusion_amd.datasets import get_dataset
+    from remixfusion_amd.mp_slam.slam import SLAM
+    from remixfusion_amd import _lib as L
+    cfg, m = _model(name, gbv_fill=False)
+    cfg["cam"].update({"H": 60, "W": 80})
+    slam = SLAM(cfg, get_dataset(cfg, device="cuda", n_frames=2), m, torch.device("cuda"))
+    tr = cfg["training"]
+    P = tr["smooth_pts"] - 1
+    u6 = torch.rand(6, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    ref = slam.smoothness_points_torch(u6, tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"]).reshape(-1, 3)
+    pts = torch.empty((P ** 3, 3), device="cuda")
+    L.check(L.load().rfx_tv_lattice(L.ptr(u6), P, float(tr["smooth_vox"]), float(tr["smooth_margin"]), m._bbox6, m._bbox_f64, 1,
+                                    L.ptr(pts), L.stream_ptr(pts.device)), "rfx_tv_lattice")
+    assert (m._bbox_f64 == 1) == (name == "office0")
+    assert float((pts - ref.float()).abs().max()) < 2e-7
+    assert float(pts.min()) >= 0.0 and float(pts.max()) <= 1.0
 
 
 def test_mapping_pipeline_learns_the_scene():
