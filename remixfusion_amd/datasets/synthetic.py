@@ -150,6 +150,10 @@ class SyntheticRoom:
                 "depth": depth.to(torch.float32).contiguous(), "direction": self.rays_d}
 
 
-def get_dataset(cfg: Dict, device: str = "cpu", n_frames: Optional[int] = None) -> SyntheticRoom:
-    """counterpart of datasets/dataset.py:12-53 for the synthetic stream."""
+def get_dataset(cfg: Dict, device: str = "cpu", n_frames: Optional[int] = None):
+    """counterpart of datasets/dataset.py:12-53: the seeded synthetic stream, or a recorded sequence
+    (`dataset: replica | scannet | tum`, see datasets/dataset.py)."""
+    if cfg.get("dataset", "synthetic") != "synthetic":
+        from .dataset import get_recorded_dataset
+        return get_recorded_dataset(cfg)
     return SyntheticRoom(cfg, device=device, n_frames=n_frames)

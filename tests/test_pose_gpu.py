@@ -100,3 +100,34 @@ def test_fused_ray_batch_equals_sample_plus_world_rays():
     (g2,) = torch.autograd.grad([o2, d2], [p2], [go, gd])
     assert float((g1 - g2).abs().max()) < 1e-4 * float(g2.abs().max())
     assert float(g1[:, 3].abs().max()) == 0.0
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """Mapper.save_ckpt / SLAM.load_ckpt (reference mapper.py:257-265, slam.py:128-135): same keys, same state."""
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+    cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+    cfg["mapping"].update({"first_iters": 5, "sample": 512, "iters": 1, "BA_iters": 1})
+    pipe = MappingPipeline(cfg, n_frames=20, seed=1)
+    frames = pipe.prefetch(list(range(7)))
+    pipe.start(frames[0])
+    for i in range(1, 7):
+        pipe.step(i, frames[i])
+    path = str(tmp_path / "checkpoint.pt")
+    pipe.mapper.save_ckpt(path)
+    keys = set(pipe.model.state_dict().keys())
+    assert {"embed_res_fn.params", "GBV.params", "GBW.params"} <= keys
+    assert any(k.startswith("decoder_res.") for k in keys) and any(k.startswith("rba.layers.") for k in keys)
+    other = MappingPipeline(cfg, n_frames=20, seed=5)
+    other.slam.load_ckpt(path)
+    for k, v in pipe.model.state_dict().items():
+        assert torch.equal(v, other.model.state_dict()[k]), k
+    assert torch.equal(other.slam.est_c2w_data.cpu(), pipe.slam.est_c2w_data.cpu())
+    b = frames[5]
+    pipe.model.train(); other.model.train()
+    with torch.no_grad():
+        r1 = pipe.slam.render_single(5, b["depth"][None], b["rgb"][None], b["c2w"], b["direction"], gap=4)
+        r2 = other.slam.render_single(5, b["depth"][None], b["rgb"][None], b["c2w"], b["direction"], gap=4)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
