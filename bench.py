@@ -9,7 +9,7 @@ moving 1 cm volume every frame, and -- whenever the reference's mapper would wak
 map_every = 5 frames) -- keyframe integration into the global volume plus iters (5) map and
 BA_iters (5) pose optimisation steps of the residual field (forward, backward, Adam), exactly
 the reference schedule.  All frames are rendered and resident in HBM before the timed region.
-Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @ 1 cm, GT poses).
+Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @ 1 cm, ground-truth-initialised poses).
 At N>1 every rank maps its own spatial partition of an N-times larger scene (weak scaling) and
 exchanges the boundary planes of the global volume with its neighbours over RCCL.
 
@@ -334,7 +334,7 @@ def main():
         "config": {"workload": f"{args.config}: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume "
                                f"{'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
                                f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
-                               f"{cfg['mapping']['iters']}+{cfg['mapping']['BA_iters']} iters every {cfg['mapping']['map_every']} frames, GT poses",
+                               f"{cfg['mapping']['iters']} map + {cfg['mapping']['BA_iters']} pose iters every {cfg['mapping']['map_every']} frames, poses initialised from the ground-truth trajectory and refined by the RBA pose MLP",
                    "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},
         "render_rays_per_s": round(render, 1) if render else None,
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,

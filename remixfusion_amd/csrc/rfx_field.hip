@@ -593,7 +593,7 @@ __device__ __forceinline__ float ldrow(const float* base, int64_t pt, int ld, in
     return (pt < n && col < ncol) ? base[pt * ld + col] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void field_dw_partial_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
+__global__ __launch_bounds__(256, 2) void field_dw_partial_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
                                                                float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, lo = lane & 31, h = lane >> 5;
     const int wv = threadIdx.x >> 6;
