@@ -24,9 +24,10 @@
 namespace rfx {
 
 // ---------------------------------------------------------------- Q1 forward kernel
+template <bool POS16>
 __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                             float* __restrict__ raw4) {
-    __shared__ float wl[FWD_SLOTS * 64];
+    __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
     stage_weights(f, wl, FWD_SLOTS);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f,
         Enc e;
         encode_point(f, x, e);
         Mlp m;
-        mlp_forward_123<false>(f, x, wl, lane, e, m);
+        mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
         float raw[4];
         mlp_forward_4(wl, lane, e, m, raw);
         if (p < n) reinterpret_cast<float4*>(raw4)[p] = make_float4(raw[0], raw[1], raw[2], raw[3]);
@@ -46,10 +47,10 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f,
 }
 
 // Q2: query_sdf_res (always +-1 clamp) / query_color_residual (decoder fed the raw GBV tsdf)
-template <int MODE>   // 0: sdf, 1: colour
+template <int MODE, bool POS16>   // MODE 0: sdf, 1: colour
 __global__ __launch_bounds__(256, FWD_WAVES) void field_query_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                           float* __restrict__ out) {
-    __shared__ float wl[FWD_SLOTS * 64];
+    __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
     stage_weights(f, wl, FWD_SLOTS);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_query_kernel(FieldK f, c
         encode_point(f, x, e);
         if (MODE == 1) e.cin = e.ex[0];          // scene_rep.py:294: ex_Trgb[...,:1] unscaled
         Mlp m;
-        mlp_forward_123<false>(f, x, wl, lane, e, m);
+        mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
         if (MODE == 0) {
             float a = m.h2[0][0], b = m.h2[1][0];
             swap32(a, b);
@@ -416,9 +417,10 @@ __device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16&
 }
 
 // ---------------------------------------------------------------- backward kernel A (MFMA chain)
+template <bool POS16>
 __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                              const float* __restrict__ draw4, BwdWs ws) {
-    extern __shared__ float wl[];
+    extern __shared__ __attribute__((aligned(16))) float wl[];
     stage_weights(f, wl, ALL_SLOTS);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -435,13 +437,8 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
         // ---- stage X1 (emb part inside the forward; pos/cin after the forward has used them)
         float* x1row = ws.x1 + p * LD_X1;
         Mlp m;
-        mlp_forward_123<true>(f, x, wl, lane, e, m, x1row, valid);
-        // pos is in tile-operand form: swap back to own-point rows for staging
-#pragma unroll
-        for (int s = 0; s < 24; ++s) swap32(e.pos[2 * s], e.pos[2 * s + 1]);
+        mlp_forward_123<true, POS16>(f, x, wl, lane, e, m, x1row, valid);    // stages emb and pos itself
         if (valid) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) st4(x1row, 32 + 4 * i, e.pos[4 * i], e.pos[4 * i + 1], e.pos[4 * i + 2], e.pos[4 * i + 3]);
             st4(x1row, 80, e.cin, 0.f, 0.f, 0.f);
             st4(x1row, 84, 0.f, 0.f, 0.f, 0.f); st4(x1row, 88, 0.f, 0.f, 0.f, 0.f); st4(x1row, 92, 0.f, 0.f, 0.f, 0.f);
         }
@@ -807,7 +804,8 @@ int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, floa
     if (rc) return rc;
     if (!x01 || !raw4 || n < 0) return RFX_ERR_ARG;
     if (n == 0) return RFX_OK;
-    hipLaunchKernelGGL(field_forward_kernel, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
+    if (k.pos_fp16) hipLaunchKernelGGL(field_forward_kernel<true>, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
+    else hipLaunchKernelGGL(field_forward_kernel<false>, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -820,7 +818,8 @@ int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, fl
     if (!x01 || !sdf || n < 0) return RFX_ERR_ARG;
     if (n == 0) return RFX_OK;
     k.clamp_mode = 0;   // query_sdf_res clamps to +-1 regardless of self.clamp (scene_rep.py:233)
-    hipLaunchKernelGGL((field_query_kernel<0>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, sdf);
+    if (k.pos_fp16) hipLaunchKernelGGL((field_query_kernel<0, true>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, sdf);
+    else hipLaunchKernelGGL((field_query_kernel<0, false>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, sdf);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -832,7 +831,8 @@ int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, 
     if (rc) return rc;
     if (!x01 || !rgb3 || n < 0) return RFX_ERR_ARG;
     if (n == 0) return RFX_OK;
-    hipLaunchKernelGGL((field_query_kernel<1>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, rgb3);
+    if (k.pos_fp16) hipLaunchKernelGGL((field_query_kernel<1, true>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, rgb3);
+    else hipLaunchKernelGGL((field_query_kernel<1, false>), dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, rgb3);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -857,11 +857,16 @@ int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t 
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
     static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
     if (!attr_set) {
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel),
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(field_backward_kernel, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
+    if (k.pos_fp16)
+        hipLaunchKernelGGL(field_backward_kernel<true>, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
+    else
+        hipLaunchKernelGGL(field_backward_kernel<false>, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -7,8 +7,10 @@ namespace rfx {
 
 // ---------------------------------------------------------------- staged weight layout (LDS)
 #ifndef HASH_GROUP
-#define HASH_GROUP 2
+#define HASH_GROUP 2          // hash levels per trip of the lookup loop (loads in flight = 8 * HASH_GROUP)
 #endif
+#define RFX_PRAGMA(x) _Pragma(#x)
+#define RFX_UNROLL(n) RFX_PRAGMA(unroll n)
 #ifndef FWD_WAVES
 #define FWD_WAVES 2
 #endif
@@ -30,9 +32,46 @@ struct FieldK {            // by-value kernel argument
     int clamp_mode, pos_fp16;
 };
 
+// ---- OneBlob x weights on the fp16 matrix pipe (pos_fp16 = 1, tinycudann's default) -----------------
+// The 48 OneBlob inputs are *exactly* fp16 numbers, so pos . W can run on v_mfma_f32_32x32x16_f16
+// (16 k per instruction at 32 cycles instead of 2 k at 64 on the fp32 form) without rounding the
+// activations.  The fp32 weight is split W = hi + lo with hi = fp16(W), lo = fp16((W - hi) * 2^11): the
+// lo products are accumulated FIRST into the zeroed tile, the tile is scaled by 2^-11 (exact), and the hi
+// products follow -- 22 significant bits of W, fp32 accumulation, no extra accumulator registers.
+// The 24 fp32 slots of the pos part of a layer hold instead 6 groups (k-block 0..2) x (lo, hi) of one
+// 16-byte A fragment per lane: lane (m = l & 31, h = l >> 5) owns W[m][16 kb + 8 h + 0..7].
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+constexpr float POS_LO_SCALE = 2048.0f;          // 2^11
+
+__device__ __forceinline__ unsigned pack_half2(float a, float b) {     // round-to-nearest-even, like __float2half_rn
+    half2v v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned pack_half2(_Float16 a, _Float16 b) {
+    half2v v = {a, b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float w16_part(float w, int hi_part) {
+    const float hi = (float)(_Float16)w;
+    return hi_part ? hi : (w - hi) * POS_LO_SCALE;
+}
+// dword i (0 .. 24*64) of the packed pos region of a layer whose pos columns start at w[m*ld + col0]
+__device__ inline float packed_pos_weight(const float* __restrict__ w, int ld, int col0, int i) {
+    const int g = i >> 8, rem = i & 255, l = rem >> 2, j2 = rem & 3;      // group = kb*2 + (0 lo | 1 hi)
+    const int kb = g >> 1, part = g & 1, m = l & 31, h = l >> 5;
+    const int p = 16 * kb + 8 * h + 2 * j2;
+    const float* row = w + m * ld + col0 + p;
+    return __uint_as_float(pack_half2(w16_part(row[0], part), w16_part(row[1], part)));
+}
+
 // value of staged slot `slot`, lane `l` (see header comment of each layer below)
 __device__ inline float staged_weight(const FieldK& f, int slot, int l) {
     const int lo = l & 31, h = l >> 5;
+    if (f.pos_fp16) {
+        if (slot >= OFF1 + 16 && slot < OFF1 + 40) return packed_pos_weight(f.w1, N_IN1, N_EMB, (slot - (OFF1 + 16)) * 64 + l);
+        if (slot >= OFF3 && slot < OFF3 + 24) return packed_pos_weight(f.w3, N_IN3, 0, (slot - OFF3) * 64 + l);
+    }
     if (slot < OFF2) {                       // L1: A[hid][k=2s+h] = W1[hid][k]
         const int k = 2 * (slot - OFF1) + h;
         return k < N_IN1 ? f.w1[lo * N_IN1 + k] : 0.f;
@@ -79,6 +118,7 @@ __device__ inline void stage_weights(const FieldK& f, float* wl, int n_slots) {
 // ---------------------------------------------------------------- per-point encodings (own-point layout)
 struct Enc {
     float pos[N_POS];
+    unsigned pos16[N_POS / 2];   // POS16 path: fp16 pairs; after mlp_forward_123: tile-operand form
     float ex[4];      // GBV (tsdf in c_trunc units, r, g, b)
     float tres;       // tsdf rescaled/clamped: the residual added to the sdf output
     float cin;        // tsdf fed to the decoder
@@ -107,17 +147,76 @@ struct Mlp {
 
 // Hash-grid levels are looked up and fed to the matrix cores level by level (level l = k-step l),
 // so the 32 features are never all live.  STAGE: also write them to x1row (backward staging).
-// consumes e.pos / e.cin / e.ex; leaves e.pos in *tile-operand* form (swapped pairs).
-template <bool STAGE>
+// consumes e.cin / e.ex; computes OneBlob itself (POS16: packed fp16 fragments in e.pos16, else fp32 e.pos in
+// tile-operand form).  STAGE also writes pos (own-point fp32) to x1row[32..79].
+__device__ __forceinline__ half8 frag16(unsigned a, unsigned b, unsigned c, unsigned d) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = {a, b, c, d};
+    return __builtin_bit_cast(half8, v);
+}
+__device__ __forceinline__ half8 lds_frag16(const float* __restrict__ wl, int slot0, int group, int lane) {
+    return *reinterpret_cast<const half8*>(wl + slot0 * 64 + group * 256 + lane * 4);
+}
+// acc(tile0, tile1) += W_pos . pos for the three k-blocks of one part (0 = lo, 1 = hi)
+__device__ __forceinline__ void pos_mfma16(const float* __restrict__ wl, int slot0, int part, int lane, const unsigned* p16,
+                                           f32x16& t0, f32x16& t1) {
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        const half8 a = lds_frag16(wl, slot0, kb * 2 + part, lane);
+        const half8 b0 = frag16(p16[8 * kb], p16[8 * kb + 2], p16[8 * kb + 4], p16[8 * kb + 6]);
+        const half8 b1 = frag16(p16[8 * kb + 1], p16[8 * kb + 3], p16[8 * kb + 5], p16[8 * kb + 7]);
+        t0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, t1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void scale16(f32x16& t, float s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] *= s;
+}
+
+template <bool STAGE, bool POS16>
 __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
                                                 int lane, Enc& e, Mlp& m, float* x1row = nullptr,
                                                 bool valid = true) {
     m.h1[0] = zero16(); m.h1[1] = zero16();
+    if (POS16) {
+        // OneBlob first: its lo-weight products must enter the empty accumulators (see above)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float v[16];
+            oneblob_dim<16>(x[d], false, v);
+            _Float16 hv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) hv[k] = (_Float16)v[k];         // the fp16 rounding tinycudann's OneBlob output has
+            if (STAGE && valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) =
+                        make_float4((float)hv[4 * i], (float)hv[4 * i + 1], (float)hv[4 * i + 2], (float)hv[4 * i + 3]);
+            }
+            // dwords 0..3 = k 0..7 (lane half 0's fragment), 4..7 = k 8..15; interleaved as (a_i, b_i) pairs for the swap
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = __uint_as_float(pack_half2(hv[2 * i], hv[2 * i + 1]));
+                float b = __uint_as_float(pack_half2(hv[8 + 2 * i], hv[8 + 2 * i + 1]));
+                swap32(a, b);                // a: tile-0 fragment dword i, b: tile-1 fragment dword i
+                e.pos16[8 * d + 2 * i] = __float_as_uint(a);
+                e.pos16[8 * d + 2 * i + 1] = __float_as_uint(b);
+            }
+        }
+        pos_mfma16(wl, OFF1 + 16, 0, lane, e.pos16, m.h1[0], m.h1[1]);
+        scale16(m.h1[0], 1.0f / POS_LO_SCALE); scale16(m.h1[1], 1.0f / POS_LO_SCALE);
+        pos_mfma16(wl, OFF1 + 16, 1, lane, e.pos16, m.h1[0], m.h1[1]);
+    }
     // a real loop (2 levels per trip): level constants are fetched per trip instead of keeping all
     // 16 x 5 of them live in SGPRs, and the code stays small enough for the instruction cache
-#pragma unroll 2
+RFX_UNROLL(HASH_GROUP)
     for (int s = 0; s < 16; ++s) {
+#if defined(FIELD_DBG) && FIELD_DBG == 4
+        const float2 v = make_float2(x[0] * (float)s, x[1]);          // timing experiment: no hash lookups
+#else
         const float2 v = lookup2(f.table, get_level(f.hash, s), x);
+#endif
         if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v;
         float a = v.x, b = v.y;
         swap32(a, b);
@@ -125,14 +224,21 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         m.h1[0] = mfma32(w, a, m.h1[0]);
         m.h1[1] = mfma32(w, b, m.h1[1]);
     }
+    if (!POS16) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) oneblob_dim<16>(x[d], f.pos_fp16 != 0, e.pos + 16 * d);
+        for (int d = 0; d < 3; ++d) oneblob_dim<16>(x[d], false, e.pos + 16 * d);
+        if (STAGE && valid) {
 #pragma unroll
-    for (int s = 0; s < 24; ++s) {
-        swap32(e.pos[2 * s], e.pos[2 * s + 1]);
-        const float w = wl[(OFF1 + 16 + s) * 64 + lane];
-        m.h1[0] = mfma32(w, e.pos[2 * s], m.h1[0]);
-        m.h1[1] = mfma32(w, e.pos[2 * s + 1], m.h1[1]);
+            for (int i = 0; i < 12; ++i)
+                *reinterpret_cast<float4*>(x1row + N_EMB + 4 * i) = make_float4(e.pos[4 * i], e.pos[4 * i + 1], e.pos[4 * i + 2], e.pos[4 * i + 3]);
+        }
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            swap32(e.pos[2 * s], e.pos[2 * s + 1]);
+            const float w = wl[(OFF1 + 16 + s) * 64 + lane];
+            m.h1[0] = mfma32(w, e.pos[2 * s], m.h1[0]);
+            m.h1[1] = mfma32(w, e.pos[2 * s + 1], m.h1[1]);
+        }
     }
     {
         float a = e.cin, b = 0.f;
@@ -142,6 +248,10 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         m.h1[1] = mfma32(w, b, m.h1[1]);
     }
     m.h2[0] = zero16(); m.h2[1] = zero16();
+#if defined(FIELD_DBG) && FIELD_DBG == 3
+    m.h2[0] = m.h1[0]; m.h2[1] = m.h1[1]; m.h3[0] = m.h1[1]; m.h3[1] = m.h1[0];   // timing experiment: no layer 2/3 MFMAs
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float w = wl[(OFF2 + r) * 64 + lane];
@@ -149,11 +259,17 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         m.h2[1] = mfma32(w, fmaxf(m.h1[1][r], 0.f), m.h2[1]);
     }
     m.h3[0] = zero16(); m.h3[1] = zero16();
+    if (POS16) {
+        pos_mfma16(wl, OFF3, 0, lane, e.pos16, m.h3[0], m.h3[1]);
+        scale16(m.h3[0], 1.0f / POS_LO_SCALE); scale16(m.h3[1], 1.0f / POS_LO_SCALE);
+        pos_mfma16(wl, OFF3, 1, lane, e.pos16, m.h3[0], m.h3[1]);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 24; ++s) {
-        const float w = wl[(OFF3 + s) * 64 + lane];
-        m.h3[0] = mfma32(w, e.pos[2 * s], m.h3[0]);
-        m.h3[1] = mfma32(w, e.pos[2 * s + 1], m.h3[1]);
+        for (int s = 0; s < 24; ++s) {
+            const float w = wl[(OFF3 + s) * 64 + lane];
+            m.h3[0] = mfma32(w, e.pos[2 * s], m.h3[0]);
+            m.h3[1] = mfma32(w, e.pos[2 * s + 1], m.h3[1]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float4* _
 
 // ------------------------------------------------------------------ fused eval renderer
 // one wave per ray; lanes = samples; S1 + points + Q1 (encode + MFMA MLP) + R1, all in registers.
+template <bool POS16>
 __global__ __launch_bounds__(256, FWD_WAVES) void render_rays_kernel(FieldK f, SamplerK s, BoxK box,
                                                                     const float* __restrict__ rays_o,
                                                                     const float* __restrict__ rays_d,
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_rays_kernel(FieldK f, S
                                                                     const float* __restrict__ u01, int64_t n_rays,
                                                                     float sc, float* __restrict__ rgb,
                                                                     float* __restrict__ depth) {
-    __shared__ float wl[FWD_SLOTS * 64];
+    __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
     __shared__ float zsh[4][MAX_S];
     stage_weights(f, wl, FWD_SLOTS);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_rays_kernel(FieldK f, S
             Enc e;
             encode_point(f, x, e);
             Mlp m;
-            mlp_forward_123<false>(f, x, wl, lane, e, m);
+            mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
             float raw[4];
             mlp_forward_4(wl, lane, e, m, raw);
             rv[c] = make_float4(raw[0], raw[1], raw[2], raw[3]);
@@ -707,8 +708,12 @@ int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const fl
     if (rc) return rc;
     if (!rays_o || !rays_d || !target_d || !bbox || !rgb || !depth || n_rays < 0) return RFX_ERR_ARG;
     if (n_rays == 0) return RFX_OK;
-    hipLaunchKernelGGL(render_rays_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
-                       make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
+    if (fk.pos_fp16)
+        hipLaunchKernelGGL(render_rays_kernel<true>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
+                           make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
+    else
+        hipLaunchKernelGGL(render_rays_kernel<false>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
+                           make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -109,12 +109,16 @@ def test_oneblob_forward():
         assert abs(float(got.sum(1).mean()) - 3.0) < 1e-2   # each dim's bins integrate to 1
 
 
-@pytest.mark.parametrize("clamp", [False, True])
-def test_field_forward_matches_oracle(clamp):
+@pytest.mark.parametrize("clamp,pos_fp16", [(False, True), (True, True), (True, False)])
+def test_field_forward_matches_oracle(clamp, pos_fp16):
+    """pos_fp16=True (tinycudann default): OneBlob on the fp16 matrix pipe with hi/lo-split weights;
+    False: all-fp32 path."""
     cfg, m = _model()
     cfg["mapping"]["clamp"] = 1.5
     fp = _oracle_params(cfg, m)
     fp.map_clamp = 1.5
+    fp.pos_fp16 = pos_fp16
+    m.embedpos_fn.fp16 = pos_fp16
     for n in (1, 63, 64, 65, 1000, 4133):
         x = _points(max(n, 7), seed=n)[:n]
         m.clamp = clamp

@@ -17,4 +17,4 @@ for i in range(21, nf): pipe.step(i, frames[i])
 torch.cuda.synchronize()
 pr.disable()
 print("fps", (nf - 21) / (time.time() - t0))
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:9000])
