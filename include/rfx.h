@@ -145,7 +145,16 @@ typedef struct rfx_field_desc {
     float         clamp_hi;             /* mapping.clamp when clamp mode is on, else 1       */
     int32_t       clamp_mode;           /* JointEncoding.clamp (scene_rep.py:332-337)        */
     int32_t       pos_fp16;             /* 1 = round OneBlob outputs to fp16 (tcnn default)  */
+    const float*  staged;               /* optional dev [rfx_field_staged_floats()]: w1..w4 in
+                                           MFMA operand order, written by rfx_field_stage_weights
+                                           for the CURRENT weights; NULL = every block re-derives
+                                           the layout from w1..w4 itself (slower prologue)      */
 } rfx_field_desc;
+
+/* D1 weight staging: one small launch per weight update instead of a gather per block.  `staged` must be
+ * 16-byte aligned; f->staged is ignored here. */
+size_t rfx_field_staged_floats(void);
+int rfx_field_stage_weights(const rfx_field_desc* f, float* staged, rfx_stream stream);
 
 /* E1 alone (query_sdf_res(embed=True), mp_slam/slam.py:209): x01 dev [n,3] -> feat dev [n, L*F]. */
 int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,

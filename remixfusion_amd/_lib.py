@@ -28,7 +28,7 @@ class FieldDesc(C.Structure):
     _fields_ = [("hash", GridDesc), ("hash_table", C.c_void_p), ("gbv", C.c_void_p), ("gbv_res", C.c_int32),
                 ("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("w4", C.c_void_p),
                 ("tsdf_scale", C.c_float), ("c_trunc", C.c_float), ("trunc", C.c_float),
-                ("clamp_hi", C.c_float), ("clamp_mode", C.c_int32), ("pos_fp16", C.c_int32)]
+                ("clamp_hi", C.c_float), ("clamp_mode", C.c_int32), ("pos_fp16", C.c_int32), ("staged", C.c_void_p)]
 
 
 class SamplerDesc(C.Structure):
@@ -93,6 +93,8 @@ PROTOTYPES = {
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
+    "rfx_field_staged_floats": (C.c_size_t, []),
+    "rfx_field_stage_weights": (_i, [C.POINTER(FieldDesc), _P, _P]),
     "rfx_tv_lattice": (_i, [_P, _i, _f, _f, _D6, _i, _i, _P, _P]),
     "rfx_gather_rays": (_i, [_P, _l, _l, _P, _i, _P, _l, _l, _l, C.c_uint64, C.c_uint64, _P, _i, _P, _P, _P, _P, _P, _P, _P]),
     "rfx_pose_grad": (_i, [_P, _P, _P, _P, _l, _i, _P, _P]),

@@ -731,7 +731,14 @@ int make_fieldk(const rfx_field_desc* d, FieldK* k) {
     k->w1 = d->w1; k->w2 = d->w2; k->w3 = d->w3; k->w4 = d->w4;
     k->c_trunc = d->c_trunc; k->trunc = d->trunc; k->clamp_hi = d->clamp_hi;
     k->clamp_mode = d->clamp_mode; k->pos_fp16 = d->pos_fp16;
+    k->staged = d->staged;
+    if (k->staged && ((uintptr_t)k->staged & 15)) return RFX_ERR_ARG;
     return RFX_OK;
+}
+
+__global__ __launch_bounds__(256) void stage_weights_kernel(FieldK f, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ALL_SLOTS * 64) out[i] = staged_weight(f, i >> 6, i & 63);
 }
 
 static inline int wave_grid(int64_t n, int max_blocks) {
@@ -744,6 +751,19 @@ static inline int wave_grid(int64_t n, int max_blocks) {
 using namespace rfx;
 
 extern "C" {
+
+size_t rfx_field_staged_floats(void) { return (size_t)ALL_SLOTS * 64; }
+
+int rfx_field_stage_weights(const rfx_field_desc* f, float* staged, rfx_stream stream) {
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (!staged || ((uintptr_t)staged & 15)) return RFX_ERR_ARG;
+    k.staged = nullptr;
+    hipLaunchKernelGGL(stage_weights_kernel, dim3((ALL_SLOTS * 64 + 255) / 256), dim3(256), 0, as_stream(stream), k, staged);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
 
 int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n, float* feat,
                             rfx_stream stream) {

@@ -30,6 +30,7 @@ struct FieldK {            // by-value kernel argument
     const float *w1, *w2, *w3, *w4;
     float c_trunc, trunc, clamp_hi;
     int clamp_mode, pos_fp16;
+    const float* staged;       // ALL_SLOTS*64 floats in operand order (rfx_field_stage_weights) or nullptr
 };
 
 // ---- OneBlob x weights on the fp16 matrix pipe (pos_fp16 = 1, tinycudann's default) -----------------
@@ -111,7 +112,13 @@ __device__ inline float staged_weight(const FieldK& f, int slot, int l) {
 }
 
 __device__ inline void stage_weights(const FieldK& f, float* wl, int n_slots) {
-    for (int i = threadIdx.x; i < n_slots * 64; i += blockDim.x) wl[i] = staged_weight(f, i >> 6, i & 63);
+    if (f.staged) {          // pre-staged image: a straight 16-byte copy (L2-resident after the first block)
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(f.staged);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = threadIdx.x; i < n_slots * 16; i += blockDim.x) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < n_slots * 64; i += blockDim.x) wl[i] = staged_weight(f, i >> 6, i & 63);
+    }
     __syncthreads();
 }
 

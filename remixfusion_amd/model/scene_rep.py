@@ -286,7 +286,20 @@ class JointEncoding(nn.Module):
         d.clamp_mode = 1 if clamp else 0
         d.clamp_hi = float(self.config["mapping"]["clamp"]) if clamp else 1.0
         d.pos_fp16 = 1 if getattr(self.embedpos_fn, "fp16", True) else 0
+        d.staged = self._staged_weights(d, (w1, w2, w3, w4))
         return d
+
+    def _staged_weights(self, d: FieldDesc, ws) -> int:
+        """decoder weights in MFMA operand order: one tiny launch per descriptor (i.e. per forward / backward
+        call), after which the kernels copy the image instead of every block gathering it from the four Linear
+        tensors.  Re-staged every time on purpose: optimizers update the weights in place."""
+        lib = _lib.load()
+        buf = getattr(self, "_staged_buf", None)
+        if buf is None or buf.device != ws[0].device:
+            buf = self._staged_buf = torch.empty(int(lib.rfx_field_staged_floats()), dtype=torch.float32, device=ws[0].device)
+        d.staged = None
+        check(lib.rfx_field_stage_weights(C.byref(d), ptr(buf), stream_ptr(buf.device)), "rfx_field_stage_weights")
+        return buf.data_ptr()
 
     def _sampler_desc(self) -> SamplerDesc:
         tr, cam = self.config["training"], self.config["cam"]

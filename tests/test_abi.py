@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     from remixfusion_amd import _lib
     assert C.sizeof(_lib.GridDesc) == 8 + 5 * 16 * 4
     assert C.sizeof(_lib.SamplerDesc) == 24
-    assert C.sizeof(_lib.FieldDesc) == C.sizeof(_lib.GridDesc) + 8 + 8 + 8 + 4 * 8 + 4 * 4 + 2 * 4
+    assert C.sizeof(_lib.FieldDesc) == C.sizeof(_lib.GridDesc) + 8 + 8 + 8 + 4 * 8 + 4 * 4 + 2 * 4 + 8
 
 
 def test_argument_validation_without_gpu():

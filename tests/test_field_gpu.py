@@ -449,3 +449,33 @@ def test_mapping_pipeline_learns_the_scene():
     assert d1 < 0.5 * d0 and c1 < 0.7 * c0, (d0, d1, c0, c1)
     assert d2 < 0.10 and c2 < 0.12, (d2, c2)
     assert int(pipe.slam.mapping_idx[0]) == 25
+
+
+def test_prestaged_weight_image_equals_in_kernel_staging():
+    """rfx_field_stage_weights + the 16-byte copy prologue vs every block deriving the operand layout itself;
+    the image is refreshed when the weights change in place."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    cfg, m = _model()
+    lib = L.load()
+    x = _points(3000, seed=3).cuda().contiguous()
+    outs = []
+    for staged in (True, False):
+        d = m._field_desc(False)
+        assert d.staged
+        if not staged:
+            d.staged = None
+        raw = torch.empty((x.shape[0], 4), device="cuda")
+        L.check(lib.rfx_field_forward(C.byref(d), L.ptr(x), x.shape[0], L.ptr(raw), L.stream_ptr(x.device)), "fwd")
+        outs.append(raw)
+    assert torch.equal(outs[0], outs[1])
+    before = m.query_color_sdf(x).clone()
+    with torch.no_grad():
+        m.decoder_res.fused_weights()[2].mul_(1.5)          # in-place update, like an optimizer step
+    after = m.query_color_sdf(x)
+    assert float((after[:, :3] - before[:, :3]).detach().abs().max()) > 1e-4
+    d = m._field_desc(False)
+    d.staged = None
+    raw = torch.empty((x.shape[0], 4), device="cuda")
+    L.check(lib.rfx_field_forward(C.byref(d), L.ptr(x), x.shape[0], L.ptr(raw), L.stream_ptr(x.device)), "fwd")
+    assert torch.equal(after, raw)
