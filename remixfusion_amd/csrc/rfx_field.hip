@@ -343,8 +343,22 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     float v[48];
+    if (fp16) {          // the packed path the fused kernels use (4 boundary evaluations per coordinate)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) oneblob_dim<16>(x01[p * 3 + d], fp16 != 0, v + 16 * d);
+        for (int d = 0; d < 3; ++d) {
+            unsigned dw[8];
+            oneblob_dim_packed16(x01[p * 3 + d], dw);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const half2v h = __builtin_bit_cast(half2v, dw[i]);
+                v[16 * d + 2 * i] = (float)h[0];
+                v[16 * d + 2 * i + 1] = (float)h[1];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) oneblob_dim<16>(x01[p * 3 + d], false, v + 16 * d);
+    }
     float4* o = reinterpret_cast<float4*>(out + p * 48);
 #pragma unroll
     for (int i = 0; i < 12; ++i) o[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);

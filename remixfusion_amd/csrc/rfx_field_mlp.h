@@ -156,6 +156,48 @@ struct Mlp {
 // so the 32 features are never all live.  STAGE: also write them to x1row (backward staging).
 // consumes e.cin / e.ex; computes OneBlob itself (POS16: packed fp16 fragments in e.pos16, else fp32 e.pos in
 // tile-operand form).  STAGE also writes pos (own-point fp32) to x1row[32..79].
+// OneBlob (16 bins) of one coordinate as 16 fp16 values in 8 dwords (half k in dword k/2): the values of
+// oneblob_dim<16>(x, fp16 = true) (to within 2^-24 absolute: a boundary a hair outside the kernel can round one
+// ulp short of saturation in the full evaluation and leak one fp16 subnormal into a bin that is 0 here).
+// The kernel is 1/16 wide, so only the boundaries L(kb-1..kb+2) around
+// kb = floor(16 frac(x)) are unsaturated: four polynomial evaluations instead of sixteen, and the three
+// non-zero outputs are dropped into place with a dword rotation.  Valid while |k/16 - x| < 1.5 for every k
+// (the three periodic copies tinycudann sums cover that range); other x take the full evaluation.
+__device__ __forceinline__ float oneblob_L16(int k, float x) {
+    const float t = (float)k * 0.0625f - x;
+    const float r = (t > 0.5f) ? 1.0f : ((t < -0.5f) ? -1.0f : 0.0f);
+    return quartic_cdf(t - r, 16.0f) + (1.0f + r);
+}
+
+__device__ __forceinline__ void oneblob_dim_packed16(float x, unsigned dw[8]) {
+#if defined(FIELD_DBG) && FIELD_DBG == 2
+    for (int i = 0; i < 8; ++i) dw[i] = pack_half2(x * (float)i, x);      // timing experiment
+    return;
+#endif
+    if (x >= -0.5f && x < 1.5f) {
+        const float y = x - floorf(x);
+        int kb = (int)floorf(y * 16.0f);
+        kb = min(max(kb, 0), 15);
+        const int c0 = (kb + 15) & 15, c1 = kb, c2 = (kb + 1) & 15, c3 = (kb + 2) & 15;
+        const float L0 = oneblob_L16(c0, x), L1 = oneblob_L16(c1, x), L2 = oneblob_L16(c2, x), L3 = oneblob_L16(c3, x);
+        const _Float16 h0 = (_Float16)(((c1 == 0) ? L1 + 1.0f : L1) - L0);      // out[c0] = L(c0 + 1) - L(c0), L(16) = L(0) + 1
+        const _Float16 h1 = (_Float16)(((c2 == 0) ? L2 + 1.0f : L2) - L1);      // out[c1]
+        const _Float16 h2 = (_Float16)(((c3 == 0) ? L3 + 1.0f : L3) - L2);      // out[c2]
+        const _Float16 z = (_Float16)0.0f;
+        const bool odd = (c0 & 1) != 0;
+        const unsigned A = odd ? pack_half2(z, h0) : pack_half2(h0, h1);
+        const unsigned B = odd ? pack_half2(h1, h2) : pack_half2(h2, z);
+        const int q = c0 >> 1, q1 = (q + 1) & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dw[i] = (i == q) ? A : ((i == q1) ? B : 0u);
+    } else {
+        float v[16];
+        oneblob_dim<16>(x, false, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dw[i] = pack_half2(v[2 * i], v[2 * i + 1]);
+    }
+}
+
 __device__ __forceinline__ half8 frag16(unsigned a, unsigned b, unsigned c, unsigned d) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v = {a, b, c, d};
@@ -190,22 +232,20 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         // OneBlob first: its lo-weight products must enter the empty accumulators (see above)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float v[16];
-            oneblob_dim<16>(x[d], false, v);
-            _Float16 hv[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) hv[k] = (_Float16)v[k];         // the fp16 rounding tinycudann's OneBlob output has
+            unsigned dw[8];
+            oneblob_dim_packed16(x[d], dw);
             if (STAGE && valid) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) =
-                        make_float4((float)hv[4 * i], (float)hv[4 * i + 1], (float)hv[4 * i + 2], (float)hv[4 * i + 3]);
+                for (int i = 0; i < 4; ++i) {
+                    const half2v p0 = __builtin_bit_cast(half2v, dw[2 * i]), p1 = __builtin_bit_cast(half2v, dw[2 * i + 1]);
+                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) = make_float4((float)p0[0], (float)p0[1], (float)p1[0], (float)p1[1]);
+                }
             }
-            // dwords 0..3 = k 0..7 (lane half 0's fragment), 4..7 = k 8..15; interleaved as (a_i, b_i) pairs for the swap
+            // dwords 0..3 = k 0..7 (lane half 0's fragment), 4..7 = k 8..15; (a_i, b_i) pairs for the swap
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float a = __uint_as_float(pack_half2(hv[2 * i], hv[2 * i + 1]));
-                float b = __uint_as_float(pack_half2(hv[8 + 2 * i], hv[8 + 2 * i + 1]));
+                float a = __uint_as_float(dw[i]);
+                float b = __uint_as_float(dw[4 + i]);
                 swap32(a, b);                // a: tile-0 fragment dword i, b: tile-1 fragment dword i
                 e.pos16[8 * d + 2 * i] = __float_as_uint(a);
                 e.pos16[8 * d + 2 * i + 1] = __float_as_uint(b);

@@ -107,6 +107,17 @@ def test_oneblob_forward():
         ref = FO.oneblob_encode(x, 16, pos_fp16=fp16)
         _close(got, ref, 0, tol, f"oneblob fp16={fp16}")
         assert abs(float(got.sum(1).mean()) - 3.0) < 1e-2   # each dim's bins integrate to 1
+    # the fp16 path evaluates only the four unsaturated boundaries per coordinate (and falls back to all sixteen
+    # outside [-0.5, 1.5)): identical to rounding the full evaluation, except where a boundary just past the kernel
+    # edge rounds one ulp short of saturation there and leaks 2^-24 (one fp16 subnormal) into the next bin
+    g = torch.Generator().manual_seed(8)
+    xw = torch.rand((20000, 3), generator=g) * 2.6 - 0.8
+    xw[:9, 0] = torch.tensor([0.0, 1.0, -1e-9, 0.0625, 0.5, 0.99999994, -0.5, 1.5, 1.4999999])
+    full = OneBlob(16, fp16=False)(xw.cuda()).half().float()
+    fast = OneBlob(16, fp16=True)(xw.cuda())
+    diff = (fast - full).abs()
+    assert float(diff.max()) <= 2.0 ** -24 and float((diff > 0).float().mean()) < 1e-4
+    assert int((fast != 0).sum(1).max()) <= 12
 
 
 @pytest.mark.parametrize("clamp,pos_fp16", [(False, True), (True, True), (True, False)])
