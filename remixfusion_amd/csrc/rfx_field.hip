@@ -249,9 +249,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     bool open = false;
     float a0[8], a1[8];
     auto flush = [&]() {
+        unsigned idx8[8];
+        corner_indices(lv, cur, idx8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const unsigned r = corner_index(lv, cur, k) - base;
+            const unsigned r = idx8[k] - base;
 #if defined(SCATTER_DBG) && SCATTER_DBG == 2
             if (r < cnt) { acc[2 * r] = a0[k]; acc[2 * r + 1] = a1[k]; }
 #else

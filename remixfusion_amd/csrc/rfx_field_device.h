@@ -72,13 +72,47 @@ __device__ __forceinline__ unsigned corner_index(const Level& L, const Cell& c, 
     return grid_index(L, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
 }
 
+// all eight corner indices of a cell.  One level-uniform branch picks the hash; a dense cell that lies
+// entirely inside the grid (every point inside the unit cube) needs one multiply-add chain and seven adds,
+// no per-corner range checks; border / outside cells take the generic wrapped form.
+__device__ __forceinline__ void corner_indices(const Level& L, const Cell& c, unsigned idx[8]) {
+    if (L.hashed) {
+        const unsigned m = L.size - 1u;
+        const unsigned x0 = c.g[0], x1 = c.g[0] + 1u;
+        const unsigned y0 = c.g[1] * 2654435761u, y1 = y0 + 2654435761u;
+        const unsigned z0 = c.g[2] * 805459861u, z1 = z0 + 805459861u;
+        const unsigned a = y0 ^ z0, b = y1 ^ z0, cc = y0 ^ z1, d = y1 ^ z1;
+        idx[0] = (x0 ^ a) & m; idx[1] = (x1 ^ a) & m; idx[2] = (x0 ^ b) & m; idx[3] = (x1 ^ b) & m;
+        idx[4] = (x0 ^ cc) & m; idx[5] = (x1 ^ cc) & m; idx[6] = (x0 ^ d) & m; idx[7] = (x1 ^ d) & m;
+#if defined(FIELD_DBG) && FIELD_DBG == 1
+        for (int k = 0; k < 8; ++k) idx[k] &= 7;
+#endif
+        return;
+    }
+    const unsigned r = L.res;
+    if (c.g[0] < r - 1u && c.g[1] < r - 1u && c.g[2] < r - 1u) {        // unsigned compare: negative coordinates (incl. -1) fail too
+        const unsigned base = c.g[0] + (c.g[1] + c.g[2] * r) * r;          // < res^3 <= size: never wraps
+        const unsigned rr = r * r;
+        idx[0] = base; idx[1] = base + 1u; idx[2] = base + r; idx[3] = base + r + 1u;
+        idx[4] = base + rr; idx[5] = base + rr + 1u; idx[6] = base + rr + r; idx[7] = base + rr + r + 1u;
+#if defined(FIELD_DBG) && FIELD_DBG == 1
+        for (int k = 0; k < 8; ++k) idx[k] &= 7;
+#endif
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) idx[k] = corner_index(L, c, k);
+}
+
 // F = 2 lookup (hash grid): returns the two interpolated features of one level.
 __device__ __forceinline__ float2 lookup2(const float* __restrict__ table, const Level& L, const float x[3]) {
     const Cell c = locate(L, x);
     const float2* __restrict__ t = reinterpret_cast<const float2*>(table) + L.offset;
+    unsigned idx[8];
+    corner_indices(L, c, idx);
     float2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
     float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -93,9 +127,11 @@ __device__ __forceinline__ float2 lookup2(const float* __restrict__ table, const
 __device__ __forceinline__ float4 lookup4(const float* __restrict__ table, const Level& L, const float x[3]) {
     const Cell c = locate(L, x);
     const float4* __restrict__ t = reinterpret_cast<const float4*>(table) + L.offset;
+    unsigned idx[8];
+    corner_indices(L, c, idx);
     float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -109,9 +145,11 @@ __device__ __forceinline__ float4 lookup4(const float* __restrict__ table, const
 __device__ __forceinline__ float lookup1(const float* __restrict__ table, const Level& L, const float x[3]) {
     const Cell c = locate(L, x);
     const float* __restrict__ t = table + L.offset;
+    unsigned idx[8];
+    corner_indices(L, c, idx);
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[corner_index(L, c, k)];
+    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = fmaf(corner_weight(c, k), v[k], acc);
@@ -126,9 +164,11 @@ __device__ __forceinline__ void lookup_dx(const float* __restrict__ table, const
     const Cell c = locate(L, x);
     const float* __restrict__ t = table + (size_t)L.offset * F;
     float dot[8];
+    unsigned idx8[8];
+    corner_indices(L, c, idx8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const unsigned idx = corner_index(L, c, k);
+        const unsigned idx = idx8[k];
         float s = 0.f;
 #pragma unroll
         for (int f = 0; f < F; ++f) s = fmaf(t[(size_t)idx * F + f], g[f], s);
