@@ -52,6 +52,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}
+        self.spread = {}
         self.enabled = False
 
     def wrap(self, lib, name):
@@ -76,8 +77,11 @@ class KernelTimer:
     def summary(self):
         out = {}
         for name, evs in self.records.items():
-            ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
-            out[name] = (len(ms), float(np.mean(ms)), evs)
+            ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in evs])
+            med = float(np.median(ms))
+            keep = ms <= 5.0 * med              # a launch that sat behind an unrelated stall (seen: one 100 ms sample
+            out[name] = (len(ms), float(np.mean(ms[keep])), evs)     # among 50 of 0.1 ms) would otherwise own the mean
+            self.spread[name] = (med, float(np.max(ms)), int((~keep).sum()))
         return out
 
 
@@ -233,7 +237,9 @@ def main():
     summ = timer.summary()
     cam, tr = cfg["cam"], cfg["training"]
     S = tr["n_range_d"] + tr["n_samples_d"]
-    per_kernel = {k: {"calls": c, "avg_ms": round(ms, 4)} for k, (c, ms, _) in summ.items()}
+    per_kernel = {k: {"calls": c, "avg_ms": round(ms, 4), "median_ms": round(timer.spread[k][0], 4), "max_ms": round(timer.spread[k][1], 4),
+                      "outliers_dropped": timer.spread[k][2]}
+                  for k, (c, ms, _) in summ.items()}
     step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
     dominant = max(step_kernels, key=lambda k: step_kernels[k][0] * step_kernels[k][1]) if step_kernels else None
     roofline = None

@@ -211,6 +211,11 @@ class Mapper:
             last_kf_id = torch.full((1, 1), cur_frame_id // m["keyframe_every"], dtype=torch.int64, device=self.device)
             poses_all = poses
             poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze().clone()
+        direct = self._direct_iterations()
+        if direct is not None:          # same kernels and random draws, launched without an autograd graph
+            for i in range(m["iters"]):
+                direct.map_iteration(current_rays, poses_all)
+            return
         for i in range(m["iters"]):
             rays_o, rays_d, target_s, target_d = self._ray_batch(current_rays, poses_all)
             ret = self.model.mapping(rays_o, rays_d, target_s, target_d)
@@ -232,6 +237,15 @@ class Mapper:
         current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
         all_index = torch.arange(0, poses.shape[0] + 1, device=self.device).unsqueeze(-1)
+        direct = self._direct_iterations() if m["opt_pose"] else None
+        if direct is not None:
+            idx = all_index.reshape(-1).contiguous()
+            for i in range(m["BA_iters"]):
+                direct.pose_iteration(current_rays, idx)
+            with torch.no_grad():
+                poses_all = self.model.rba(all_index)
+            self._write_back_poses(poses_all, frame_ids_all, cur_frame_id)
+            return
         poses_all = self.model.rba(all_index)
         if not m["opt_pose"]:
             # no optimizer consumes pose gradients in this phase (the reference still back-propagates into the
@@ -247,11 +261,23 @@ class Mapper:
                 poses_all = self.model.rba(all_index)
                 self.map_optimizer.zero_grad()
                 self.rba_optimizer.zero_grad()
+        self._write_back_poses(poses_all, frame_ids_all, cur_frame_id)
+
+    def _write_back_poses(self, poses_all, frame_ids_all, cur_frame_id):
+        """refined keyframe poses -> est_c2w_data (reference :507-520)."""
+        m = self.config["mapping"]
         if len(frame_ids_all) > 1 and m["opt_pose"]:
             kfupid = torch.arange(len(frame_ids_all) - 1, device=self.device) * m["keyframe_every"]
             if m["optim_cur"]:
                 self.est_c2w_data[cur_frame_id] = poses_all[-1:].detach().clone()[0]
             self.est_c2w_data[kfupid] = poses_all[:-1].detach().clone()
+
+    def _direct_iterations(self):
+        """graph-free issue of the BA iterations (mp_slam/direct.py) when the configuration allows it."""
+        if getattr(self, "_direct", None) is None:
+            from .direct import DirectIterations
+            self._direct = DirectIterations(self) if DirectIterations.supported(self) else False
+        return self._direct or None
 
     def convert_relative_pose(self, idx=None):
         """absolute pose per frame: keyframes as stored, others = delta @ keyframe (reference :580-624)."""

@@ -133,3 +133,69 @@ def test_checkpoint_round_trip(tmp_path):
         torch.manual_seed(0)
         r2 = other.slam.render_single(5, b["depth"][None], b["rgb"][None], b["c2w"], b["direction"], gap=4)
     assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+
+
+def test_direct_iterations_equal_autograd_iterations():
+    """mp_slam/direct.py (kernels issued without an autograd graph) vs the autograd formulation of one
+    global_mapping / global_pose iteration: same state and random draws -> same gradients.  (Parameters after an
+    Adam step are not compared: with eps = 1e-15 the update is +-lr for any non-zero gradient, so round-off in
+    near-zero entries flips whole steps.)"""
+    import random
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    from remixfusion_amd.mp_slam.direct import DirectIterations
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+    cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+    cfg["mapping"].update({"first_iters": 5, "sample": 512, "iters": 2, "BA_iters": 2})
+    cfg["training"].update({"smooth_pts": 16})
+    pipe = MappingPipeline(cfg, n_frames=30, seed=1)
+    frames = pipe.prefetch(list(range(12)))
+    pipe.start(frames[0])
+    for i in range(1, 11):
+        pipe.step(i, frames[i])
+    mp, model, slam = pipe.mapper, pipe.model, pipe.slam
+    assert mp._direct_iterations() is not None            # the pipeline above ran on the direct path
+    direct = DirectIterations(mp)
+    b = frames[10]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    K = len(mp.keyframe) + 1
+    all_index = torch.arange(0, K, device="cuda").unsqueeze(-1)
+    params = [model.embed_res_fn.params] + list(model.decoder_res.fused_weights())
+    rba_params = list(model.rba.parameters())
+
+    def grads_of(ps):
+        return [p.grad.detach().clone() for p in ps]
+
+    def reset():
+        for p in params + rba_params:
+            p.grad = None
+        random.seed(11); torch.manual_seed(11)
+
+    # ---- map phase
+    poses = slam.est_c2w_data[0:11:5].clone().cuda().float()
+    poses = torch.cat([poses, poses[-1:]], 0)[:K]
+    reset()
+    rays_o, rays_d, ts, td = mp._ray_batch(cur, poses)
+    slam.get_loss_from_ret(model.mapping(rays_o, rays_d, ts, td), smooth=True).backward()
+    ref = grads_of(params)
+    reset()
+    direct.map_gradients(cur, poses)
+    got = grads_of(params)
+    for g, r, nm in zip(got, ref, ("d_hash", "dW1", "dW2", "dW3", "dW4")):
+        assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-12, nm
+    assert float((ref[0] != 0).float().mean()) > 0.001
+    # ---- pose phase
+    reset()
+    poses_all = model.rba(all_index)
+    rays_o, rays_d, ts, td = mp._ray_batch(cur, poses_all)
+    slam.get_loss_from_ret(model.mapping(rays_o, rays_d, ts, td, clamp=True), smooth=True).backward()
+    ref_r, ref_m = grads_of(rba_params), grads_of(params)
+    reset()
+    direct.pose_gradients(cur, all_index.reshape(-1).contiguous())
+    got_r, got_m = grads_of(rba_params), grads_of(params)
+    for g, r in zip(got_r, ref_r):
+        assert float((g - r).abs().max()) <= 5e-3 * float(r.abs().max()) + 1e-12, tuple(r.shape)
+    assert float(ref_r[0].abs().max()) > 0
+    for g, r in zip(got_m, ref_m):
+        assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-12
