@@ -101,7 +101,11 @@ class DirectIterations:
               "rfx_mapping_loss_backward")
         dt = torch.zeros_like(table)
         w = model.decoder_res.fused_weights()
-        dws = [torch.zeros_like(t) for t in w]
+        flat = torch.zeros(sum(t.numel() for t in w), **f32)          # one fill for the four weight gradients
+        dws, off = [], 0
+        for t in w:
+            dws.append(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
         dx = torch.empty_like(x01) if want_ray_grads else None
         ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
         wb = ws.numel() * 4
