@@ -266,11 +266,12 @@ def main():
         pts = float(np.mean([e[2][2] for e in evs]))
         nbytes = pts * (12 + 128 + 1024)
         ach = nbytes / (ms * 1e-3) / 1e9
-        extra_rooflines["field_backward_scatter"] = {"kernel": "grid_encode_backward_kernel (rfx_field_backward_scatter)",
+        extra_rooflines["field_backward_scatter"] = {"kernel": "scatter_stage_kernel + grid_scatter_lds_kernel (rfx_field_backward_scatter)",
                                                      "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                      "points_per_launch": int(pts), "avg_ms": round(ms, 4),
-                                                     "note": "fp32 atomics execute at the memory side: ~1.3 TB/s contiguous, ~0.08 TB/s scattered (MI355X_MICROARCH.md)"}
+                                                     "note": "LDS-privatised: corner sums accumulate with ds_add_f32 per 128 KB table segment, then one contiguous "
+                                                             "global atomic per non-zero entry; bound by LDS atomic throughput, not HBM"}
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]
         pts = float(evs[0][2][6]) * S
@@ -309,13 +310,14 @@ def main():
     # summarised by tools/summarize_pmc.py into profiles/r1_pmc_traffic.json); raw counter bytes.
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        for rk, kn in (("field_backward_scatter", "rfx::grid_encode_backward_kernel"), ("field_forward", "rfx::field_forward_kernel"),
-                       ("field_backward_chain", "rfx::field_backward_kernel"), ("field_backward_weights", "rfx::field_dw_partial_kernel"),
-                       ("render_rays", "rfx::render_rays_kernel"), ("tsdf_integrate", "void rfx::mv_integrate_kernel<4, 4, 4>")):
-            kn = next((k for k in pmc if k.startswith(kn.split("<")[0])), kn)
-            if rk in extra_rooflines and kn in pmc:
-                extra_rooflines[rk]["traffic"] = int(pmc[kn]["hbm_bytes_raw"])
-                extra_rooflines[rk]["traffic_source"] = "profiles/r1_pmc_traffic.json (FETCH_SIZE+WRITE_SIZE, raw)"
+        for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
+                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel",)),
+                        ("field_backward_weights", ("rfx::field_dw_partial_kernel", "rfx::field_dw_reduce_kernel")),
+                        ("render_rays", ("rfx::render_rays_kernel",)), ("tsdf_integrate", ("rfx::mv_integrate_kernel", "rfx::mv_prepass_kernel"))):
+            keys = [k for k in pmc if any(kn in k for kn in kns)]
+            if rk in extra_rooflines and keys:
+                extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes_raw"] for k in keys))
+                extra_rooflines[rk]["traffic_source"] = "profiles/r1_pmc_traffic.json (FETCH_SIZE+WRITE_SIZE, raw; " + " + ".join(keys) + ")"
     except Exception:
         pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
