@@ -171,7 +171,7 @@ def main():
     lib = _lib.load()
     timer = KernelTimer()
     for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_weights",
-                 "rfx_field_backward_scatter", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
+                 "rfx_field_backward_scatter", "rfx_field_backward_scatter_merged", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
                  "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
                  "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):
         timer.wrap(lib, name)
@@ -260,13 +260,15 @@ def main():
         extra_rooflines["field_backward_chain"] = mfma_roofline("rfx_field_backward_chain", MLP_FLOP_PER_POINT, 2)
     if "rfx_field_backward_weights" in summ:
         extra_rooflines["field_backward_weights"] = mfma_roofline("rfx_field_backward_weights", MLP_FLOP_PER_POINT, 0)
-    if "rfx_field_backward_scatter" in summ:
-        # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered
-        cnt, ms, evs = summ["rfx_field_backward_scatter"]
-        pts = float(np.mean([e[2][2] for e in evs]))
+    scat = "rfx_field_backward_scatter_merged" if "rfx_field_backward_scatter_merged" in summ else "rfx_field_backward_scatter"
+    if scat in summ:
+        # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered;
+        # the merged call scatters the ray samples AND the TV lattice points in one sweep
+        cnt, ms, evs = summ[scat]
+        pts = float(np.mean([e[2][2] + (e[2][5] if scat.endswith("merged") else 0) for e in evs]))
         nbytes = pts * (12 + 128 + 1024)
         ach = nbytes / (ms * 1e-3) / 1e9
-        extra_rooflines["field_backward_scatter"] = {"kernel": "scatter_stage_kernel + grid_scatter_lds_kernel (rfx_field_backward_scatter)",
+        extra_rooflines["field_backward_scatter"] = {"kernel": f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})",
                                                      "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                      "points_per_launch": int(pts), "avg_ms": round(ms, 4),
@@ -322,6 +324,7 @@ def main():
         pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
            "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
+           "rfx_field_backward_scatter_merged": "field_backward_scatter",
            "rfx_tsdf_integrate": "tsdf_integrate"}.get(dominant)
     roofline = extra_rooflines.get(key) if key else None
     if roofline is None and extra_rooflines:

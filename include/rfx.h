@@ -198,6 +198,13 @@ int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float*
                                void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,
                                void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* hash-gradient scatter of the chain's d_emb rows (as rfx_field_backward_scatter with dx01 = NULL) MERGED with a
+ * second point set -- extra_x01 dev [m,3], extra_dfeat dev [m, 2L] row-major, e.g. the TV lattice and its feature
+ * gradient -- so that one sweep over the table segments serves both.  scatter_ws: dev, >=
+ * rfx_grid_encode_backward_workspace_bytes(n + extra_n, L), or NULL for direct atomics.  d_hash is accumulated into. */
+int rfx_field_backward_scatter_merged(const rfx_field_desc* f, const float* x01, int64_t n, const float* extra_x01,
+                                      const float* extra_dfeat, int64_t extra_n, float* d_hash, void* workspace,
+                                      size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes, rfx_stream stream);
 int rfx_field_backward_dx(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dx01,
                           void* workspace, size_t workspace_bytes, rfx_stream stream);
 

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
+    "rfx_field_backward_scatter_merged": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _l, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "rfx_field_staged_floats": (C.c_size_t, []),
     "rfx_field_stage_weights": (_i, [C.POINTER(FieldDesc), _P, _P]),
     "rfx_tv_lattice": (_i, [_P, _i, _f, _f, _D6, _i, _i, _P, _P]),

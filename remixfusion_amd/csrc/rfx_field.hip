@@ -209,20 +209,32 @@ static size_t scatter_scratch_floats(int64_t n, int n_levels) {
 }
 
 // slot (chunk c, iteration i, thread t) <- point c*K*1024 + t*K + i.  Planes: L x float2[slots], then x,y,z.
-__global__ __launch_bounds__(256) void scatter_stage_kernel(const float* __restrict__ dfeat, int ld, int n_levels,
-                                                            const float* __restrict__ x01, int64_t n, int K, int64_t slots,
-                                                            float* __restrict__ scratch) {
+// The point list is the concatenation of up to two sources (e.g. the ray samples and the TV lattice), so
+// that one sweep over the table segments serves both.
+struct ScatterSrc {
+    const float* dfeat; int ld; const float* x01; int64_t n;
+};
+
+__global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, ScatterSrc b, int64_t per_a, int64_t per_b, int n_levels,
+                                                            int K, int64_t slots, float* __restrict__ scratch) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
     const int64_t per = (int64_t)K * SCATTER_THREADS;
     const int64_t c = s / per, r = s % per;
-    const int64_t p = c * per + (r % SCATTER_THREADS) * K + r / SCATTER_THREADS;
+    const int64_t j = (r % SCATTER_THREADS) * K + r / SCATTER_THREADS;      // point j of chunk c
+    // every chunk takes an equal share of BOTH sources (a lattice dumped into one chunk would make that
+    // chunk's blocks the tail of the launch: its points collide on the coarse levels)
+    const bool in_a = j < per_a;
+    const ScatterSrc src = in_a ? a : b;
+    const int64_t jj = in_a ? j : j - per_a;
+    const int64_t p = c * (in_a ? per_a : per_b) + jj;
+    const bool live = jj < (in_a ? per_a : per_b) && p < src.n;
     float2* __restrict__ planes = reinterpret_cast<float2*>(scratch);
     float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
-    if (p < n) {
-        const float2* __restrict__ row = reinterpret_cast<const float2*>(dfeat + p * (int64_t)ld);
+    if (live) {
+        const float2* __restrict__ row = reinterpret_cast<const float2*>(src.dfeat + p * (int64_t)src.ld);
         for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
-        xs[s] = x01[p * 3]; xs[slots + s] = x01[p * 3 + 1]; xs[2 * slots + s] = x01[p * 3 + 2];
+        xs[s] = src.x01[p * 3]; xs[slots + s] = src.x01[p * 3 + 1]; xs[2 * slots + s] = src.x01[p * 3 + 2];
     } else {
         for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
         xs[s] = 0.5f; xs[slots + s] = 0.5f; xs[2 * slots + s] = 0.5f;
@@ -310,7 +322,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 // dtable += scatter of dfeat (row stride ld).  With a scratch buffer of scatter_scratch_floats() the
 // LDS path is taken when the table is small enough to sweep segment by segment; otherwise direct atomics.
 static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
-                               int ld, float* dtable, float* scratch, hipStream_t st) {
+                               int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
+                               const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0) {
     ScatterPlan plan;
     int total = 0;
     for (int l = 0; l < g.n_levels; ++l) {
@@ -318,16 +331,24 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
         total += (int)((g.size[l] + SCATTER_SEG - 1) / SCATTER_SEG);
     }
     for (int l = g.n_levels; l <= RFX_MAX_LEVELS; ++l) plan.seg_start[l] = total;
-    if (!scratch || total > SCATTER_MAX_SEGMENTS || n < SCATTER_MIN_POINTS) {
-        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
-                           dfeat, ld, dtable, (float*)nullptr, 0);
+    const int64_t n_all = n + n_b;
+    if (!scratch || total > SCATTER_MAX_SEGMENTS || n_all < SCATTER_MIN_POINTS) {
+        if (n > 0)
+            hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
+                               dfeat, ld, dtable, (float*)nullptr, 0);
+        if (n_b > 0)
+            hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, g, table, x01_b,
+                               n_b, dfeat_b, ld_b, dtable, (float*)nullptr, 0);
         return RFX_OK;
     }
-    scatter_shape(n, total, &plan.chunks, &plan.K);
+    scatter_shape(n_all, total, &plan.chunks, &plan.K);
+    const int64_t per_a = (n + plan.chunks - 1) / plan.chunks, per_b = (n_b + plan.chunks - 1) / plan.chunks;
+    plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
     plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
-    if ((size_t)plan.slots * (2 * g.n_levels + 3) > scatter_scratch_floats(n, g.n_levels)) return RFX_ERR_WORKSPACE;
-    hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, dfeat, ld, g.n_levels,
-                       x01, n, plan.K, plan.slots, scratch);
+    if ((size_t)plan.slots * (2 * g.n_levels + 3) > scatter_scratch_floats(n_all, g.n_levels)) return RFX_ERR_WORKSPACE;
+    const ScatterSrc a{dfeat, ld, x01, n}, b{dfeat_b, ld_b, x01_b, n_b};
+    hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, per_a, per_b,
+                       g.n_levels, plan.K, plan.slots, scratch);
     const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -941,6 +962,25 @@ int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_
                            k.table, x01, n, ws.dx1, LD_DX1, (float*)nullptr, dx01, 0);
         RFX_LAUNCH_CHECK();
     }
+    return RFX_OK;
+}
+
+int rfx_field_backward_scatter_merged(const rfx_field_desc* f, const float* x01, int64_t n, const float* extra_x01,
+                                      const float* extra_dfeat, int64_t extra_n, float* d_hash, void* workspace,
+                                      size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes, rfx_stream stream) {
+    if ((n == 0 && extra_n == 0) || !d_hash) return RFX_OK;
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (n < 0 || extra_n < 0 || (n > 0 && !x01) || (extra_n > 0 && (!extra_x01 || !extra_dfeat))) return RFX_ERR_ARG;
+    if (n > 0 && (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n))) return RFX_ERR_WORKSPACE;
+    if (scatter_ws && (scatter_bytes < rfx_grid_encode_backward_workspace_bytes(n + extra_n, k.hash.n_levels) || ((uintptr_t)scatter_ws & 7)))
+        return RFX_ERR_WORKSPACE;
+    const float* dx1 = n > 0 ? carve(workspace, n).dx1 : nullptr;
+    rc = launch_grid_scatter(k.hash, k.table, x01, n, dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
+                             extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n);
+    if (rc) return rc;
+    RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
 

@@ -112,24 +112,24 @@ class DirectIterations:
         check(lib.rfx_field_backward_chain(C.byref(desc), ptr(x01), n * S, ptr(d_raw), ptr(ws), wb, st), "rfx_field_backward_chain")
         check(lib.rfx_field_backward_weights(n * S, ptr(d_raw), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]), ptr(dws[3]), ptr(ws), wb, st),
               "rfx_field_backward_weights")
-        check(lib.rfx_field_backward_scatter(C.byref(desc), ptr(x01), n * S, ptr(dt), ptr(dx), ptr(ws), wb, st),
-              "rfx_field_backward_scatter")
         go = gd = None
         if want_ray_grads:
+            check(lib.rfx_field_backward_scatter(C.byref(desc), ptr(x01), n * S, None, ptr(dx), ptr(ws), wb, st),
+                  "rfx_field_backward_scatter")
             check(lib.rfx_field_backward_dx(C.byref(desc), ptr(x01), n * S, ptr(d_raw), ptr(dx), ptr(ws), wb, st), "rfx_field_backward_dx")
             dp = dx.view(n, S, 3) / model._extent_on(dev)
             go, gd = dp.sum(1), (dp * z[..., None]).sum(1)
-        # TV backward, accumulated into the same hash-gradient buffer
+        # TV backward; its hash gradient and the field's are scattered by ONE sweep over the table segments
         gs = getattr(self, "_tv_gscale", None)
         if gs is None or gs.device != dev:
             gs = self._tv_gscale = torch.ones(1, **f32)
         dfeat = torch.empty_like(feat)
         scale = float(tr["smooth_weight"]) / float(int(tr["smooth_pts"]) ** 3)
         check(lib.rfx_tv_backward(ptr(feat), P, enc.n_output_dims, scale, ptr(gs), ptr(dfeat), st), "rfx_tv_backward")
-        nb = int(lib.rfx_grid_encode_backward_workspace_bytes(pts.shape[0], int(enc.desc.n_levels)))
+        nb = int(lib.rfx_grid_encode_backward_workspace_bytes(n * S + pts.shape[0], int(enc.desc.n_levels)))
         ws2 = torch.empty(nb // 4, **f32)
-        check(lib.rfx_grid_encode_backward(enc.desc, ptr(table), ptr(pts), pts.shape[0], ptr(dfeat), ptr(dt), None, ptr(ws2),
-                                           ws2.numel() * 4, st), "rfx_grid_encode_backward")
+        check(lib.rfx_field_backward_scatter_merged(C.byref(desc), ptr(x01), n * S, ptr(pts), ptr(dfeat), pts.shape[0], ptr(dt),
+                                                    ptr(ws), wb, ptr(ws2), ws2.numel() * 4, st), "rfx_field_backward_scatter_merged")
         return dt, dws, go, gd, lc
 
     def _set_map_grads(self, dt, dws):
