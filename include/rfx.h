@@ -359,6 +359,47 @@ int rfx_rba_forward(const rfx_rba_params* p, const float* init_r, const float* i
 int rfx_rba_backward(const rfx_rba_params* p, const float* acts, int64_t K, const float* dposes16, float scale,
                      const rfx_rba_grads* g, float* workspace, rfx_stream stream);
 
+/* ---- one bundle-adjustment iteration, forward + backward, in one call (M1) -------------------------------
+ * Sequences the entry points above for the loop bodies of Mapper.global_mapping / global_pose
+ * (mp_slam/mapper.py:394-420, 470-505): rfx_gather_rays -> rfx_sample_z -> rfx_ray_points -> rfx_field_forward ->
+ * rfx_composite_forward -> rfx_mapping_loss_forward -> TV term (rfx_tv_lattice, rfx_grid_encode_forward, rfx_tv_forward)
+ * -> rfx_mapping_loss_backward -> rfx_field_backward_chain/_weights[/_scatter(dx)/_dx -> ray gradients -> rfx_pose_grad]
+ * -> rfx_tv_backward -> rfx_field_backward_scatter_merged.  Optimizers and random draws stay with the caller. */
+typedef struct rfx_ba_desc {
+    rfx_field_desc   field;             /* clamp mode of this phase; `staged` current                       */
+    rfx_sampler_desc sampler;
+    double        bbox[6];
+    int32_t       bbox_f64;
+    float         sc_factor, depth_trunc, trunc;
+    int32_t       rgb_missing_on;
+    const float*  loss_w_dev;           /* dev [4]: d total / d (rgb, depth, sdf, fs) loss                   */
+    int32_t       tv_P;                 /* lattice points per axis (training.smooth_pts - 1)                 */
+    float         tv_voxel, tv_margin;
+    float         tv_scale;             /* training.smooth_weight / smooth_pts^3                             */
+    int32_t       tv_normalise;
+    const float*  kf_rays;              /* see rfx_gather_rays                                               */
+    int64_t       rays_per_kf, num_kf;
+    const int64_t* kf_frame_ids;
+    int32_t       keyframe_every;
+    const float*  cur_rays;
+    int64_t       cur_population, n_kf_samples, n_cur;
+    uint64_t      seed_kf, seed_cur;
+    const float*  poses16;              /* dev [K,16]                                                        */
+    int32_t       K;
+    const float*  u_z;                  /* dev [n,S] uniforms of the sampler jitter, or NULL                 */
+    const float*  u6;                   /* dev [6] uniforms of the TV lattice                                */
+    int64_t       hash_entries;         /* entries (of n_feat floats) of the hash table = size of d_hash     */
+    float*        d_hash;               /* out dev: hash-table gradient (zeroed here)                        */
+    float*        d_w;                  /* out dev [5312]: dW1 | dW2 | dW3 | dW4 (zeroed here)               */
+    float*        d_poses16;            /* out dev [K,16] or NULL (poses fixed: no ray gradients computed)   */
+    float*        losses8;              /* out dev [8] or NULL: the four losses, then their coefficients     */
+    double*       tv_sum;               /* out dev [1] or NULL: un-normalised TV sum                         */
+} rfx_ba_desc;
+size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign binding verify its mirror of the struct */
+size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);
+/* workspace: dev, 256-byte aligned, >= rfx_ba_workspace_bytes(n_kf_samples + n_cur, S, tv_P, L*F, L). */
+int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

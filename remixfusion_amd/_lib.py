@@ -36,6 +36,18 @@ class SamplerDesc(C.Structure):
                 ("n_range_d", C.c_int32), ("n_samples_d", C.c_int32), ("perturb", C.c_float)]
 
 
+class BaDesc(C.Structure):
+    _fields_ = [("field", FieldDesc), ("sampler", SamplerDesc), ("bbox", C.c_double * 6), ("bbox_f64", C.c_int32),
+                ("sc_factor", C.c_float), ("depth_trunc", C.c_float), ("trunc", C.c_float), ("rgb_missing_on", C.c_int32),
+                ("loss_w_dev", C.c_void_p), ("tv_P", C.c_int32), ("tv_voxel", C.c_float), ("tv_margin", C.c_float),
+                ("tv_scale", C.c_float), ("tv_normalise", C.c_int32), ("kf_rays", C.c_void_p), ("rays_per_kf", C.c_int64),
+                ("num_kf", C.c_int64), ("kf_frame_ids", C.c_void_p), ("keyframe_every", C.c_int32), ("cur_rays", C.c_void_p),
+                ("cur_population", C.c_int64), ("n_kf_samples", C.c_int64), ("n_cur", C.c_int64), ("seed_kf", C.c_uint64),
+                ("seed_cur", C.c_uint64), ("poses16", C.c_void_p), ("K", C.c_int32), ("u_z", C.c_void_p), ("u6", C.c_void_p),
+                ("hash_entries", C.c_int64), ("d_hash", C.c_void_p), ("d_w", C.c_void_p), ("d_poses16", C.c_void_p),
+                ("losses8", C.c_void_p), ("tv_sum", C.c_void_p)]
+
+
 class RbaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("hidden", C.c_int32)]
 
@@ -99,6 +111,9 @@ PROTOTYPES = {
     "rfx_tv_lattice": (_i, [_P, _i, _f, _f, _D6, _i, _i, _P, _P]),
     "rfx_gather_rays": (_i, [_P, _l, _l, _P, _i, _P, _l, _l, _l, C.c_uint64, C.c_uint64, _P, _i, _P, _P, _P, _P, _P, _P, _P]),
     "rfx_pose_grad": (_i, [_P, _P, _P, _P, _l, _i, _P, _P]),
+    "rfx_ba_desc_bytes": (C.c_size_t, []),
+    "rfx_ba_workspace_bytes": (C.c_size_t, [_l, _i, _i, _i, _i]),
+    "rfx_ba_forward_backward": (_i, [C.POINTER(BaDesc), _P, C.c_size_t, _P]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),
     "rfx_rba_grads_floats": (C.c_size_t, [_l]),
     "rfx_rba_forward": (_i, [C.POINTER(RbaParams), _P, _P, _P, _l, _i, _f, _P, _P, _P]),
@@ -127,6 +142,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.rfx_abi_version() != 1:
         raise RfxError("librfx.so ABI version mismatch")
+    if lib.rfx_ba_desc_bytes() != C.sizeof(BaDesc):
+        raise RfxError("rfx_ba_desc layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
     _lib = lib
     return lib
 

@@ -1,0 +1,143 @@
+// rfx_ba.hip -- one bundle-adjustment iteration (forward + backward) issued by ONE host call.
+// Reference: the loop bodies of Mapper.global_mapping / global_pose (mp_slam/mapper.py:394-420, 470-505):
+// ray batch -> JointEncoding.mapping (S1 sampler, points, Q1 field, R1 compositing, L1 losses) ->
+// get_loss_from_ret(smooth=True) (TV1) -> loss.backward().  Every stage is an existing librfx entry point; this
+// file only sequences them on one stream from a carved workspace, so the host pays one foreign call per
+// iteration instead of ~20 (the Python side keeps the optimizers and the random draws).
+#include "rfx_common.h"
+#include <algorithm>
+
+namespace rfx {
+
+// d rays_o = sum_s dx / extent, d rays_d = sum_s z * dx / extent (reference: autograd through
+// pts = o + d z, then the bound normalisation; scene_rep.py:388,443).  One wave per ray.
+__global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __restrict__ dx, const float* __restrict__ z,
+                                                              int64_t n, int S, float ex, float ey, float ez,
+                                                              float* __restrict__ go, float* __restrict__ gd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = lane; s < S; s += 64) {
+        const float* g = dx + (ray * S + s) * 3;
+        const float zz = z[ray * S + s];
+        const float px = g[0] / ex, py = g[1] / ey, pz = g[2] / ez;
+        a[0] += px; a[1] += py; a[2] += pz;
+        a[3] += px * zz; a[4] += py * zz; a[5] += pz * zz;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_xor(a[q], o);
+    }
+    if (lane == 0) {
+        go[ray * 3] = a[0]; go[ray * 3 + 1] = a[1]; go[ray * 3 + 2] = a[2];
+        gd[ray * 3] = a[3]; gd[ray * 3 + 1] = a[4]; gd[ray * 3 + 2] = a[5];
+    }
+}
+
+struct BaWs {
+    float *o, *d, *tgt, *d_cam, *td, *z, *x01, *raw, *rgb_map, *depth_map, *lc, *pts, *feat, *d_raw, *dx, *go, *gd, *dfeat, *ones;
+    int* pidx;
+    double* sums;
+    void *bwd_ws, *scat_ws;
+    size_t bwd_bytes, scat_bytes, total;
+};
+
+static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_levels) {
+    BaWs w;
+    size_t off = 0;
+    char* b0 = reinterpret_cast<char*>(base);
+    auto take = [&](size_t bytes) { char* r = b0 ? b0 + off : nullptr; off += al(bytes); return r; };
+    const size_t nS = (size_t)n * S, nt = (size_t)P * P * P;
+    w.o = (float*)take(n * 12); w.d = (float*)take(n * 12); w.tgt = (float*)take(n * 12); w.d_cam = (float*)take(n * 12);
+    w.td = (float*)take(n * 4); w.pidx = (int*)take(n * 4);
+    w.z = (float*)take(nS * 4); w.x01 = (float*)take(nS * 12); w.raw = (float*)take(nS * 16);
+    w.rgb_map = (float*)take(n * 12); w.depth_map = (float*)take(n * 4);
+    w.sums = (double*)take(8 * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
+    w.pts = (float*)take(nt * 12); w.feat = (float*)take(nt * n_feat * 4); w.dfeat = (float*)take(nt * n_feat * 4);
+    w.d_raw = (float*)take(nS * 16); w.dx = (float*)take(nS * 12); w.go = (float*)take(n * 12); w.gd = (float*)take(n * 12);
+    w.bwd_bytes = rfx_field_backward_workspace_bytes((int64_t)nS);
+    w.bwd_ws = take(w.bwd_bytes);
+    w.scat_bytes = rfx_grid_encode_backward_workspace_bytes((int64_t)(nS + nt), n_levels);
+    w.scat_ws = take(w.scat_bytes);
+    w.total = off;
+    return w;
+}
+
+__global__ void set_one_kernel(float* p) { p[0] = 1.0f; }
+
+}  // namespace rfx
+
+using namespace rfx;
+
+extern "C" {
+
+size_t rfx_ba_desc_bytes(void) { return sizeof(rfx_ba_desc); }
+
+size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat, int n_levels) {
+    if (n_rays <= 0 || S <= 0 || tv_P <= 0 || n_feat <= 0 || n_levels <= 0) return 0;
+    return carve_ba(nullptr, n_rays, S, tv_P, n_feat, n_levels).total;
+}
+
+#define RFX_TRY(call)            \
+    do {                         \
+        int _rc = (call);        \
+        if (_rc) return _rc;     \
+    } while (0)
+
+int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (!b || !workspace) return RFX_ERR_ARG;
+    const int64_t n = b->n_kf_samples + b->n_cur;
+    const int S = b->sampler.n_range_d + b->sampler.n_samples_d, P = b->tv_P;
+    const int L = b->field.hash.n_levels, F = b->field.hash.n_feat;
+    if (n <= 0 || S <= 0 || P <= 0 || !b->d_hash || !b->d_w || !b->u6 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0)
+        return RFX_ERR_ARG;
+    if ((uintptr_t)workspace & 255) return RFX_ERR_ARG;
+    if (workspace_bytes < rfx_ba_workspace_bytes(n, S, P, L * F, L)) return RFX_ERR_WORKSPACE;
+    const BaWs w = carve_ba(workspace, n, S, P, L * F, L);
+    hipStream_t st = as_stream(stream);
+    const int64_t nS = n * S, nt = (int64_t)P * P * P;
+    // ---- ray batch
+    RFX_TRY(rfx_gather_rays(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
+                            b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, w.o, w.d, w.tgt, w.td, w.d_cam,
+                            w.pidx, stream));
+    // ---- forward
+    RFX_TRY(rfx_sample_z(&b->sampler, w.td, b->u_z, n, w.z, stream));
+    RFX_TRY(rfx_ray_points(w.o, w.d, w.z, n, S, b->bbox, b->bbox_f64, w.x01, stream));
+    RFX_TRY(rfx_field_forward(&b->field, w.x01, nS, w.raw, stream));
+    RFX_TRY(rfx_composite_forward(w.raw, w.z, n, S, b->trunc, b->sc_factor, w.rgb_map, w.depth_map, nullptr, stream));
+    const float trunc_loss = b->trunc * b->sc_factor;
+    RFX_TRY(rfx_mapping_loss_forward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, trunc_loss, b->depth_trunc, b->rgb_missing_on,
+                                     w.sums, w.lc, w.lc + 4, stream));
+    RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
+    RFX_TRY(rfx_grid_encode_forward(&b->field.hash, b->field.hash_table, w.pts, nt, w.feat, stream));
+    if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));
+    // ---- backward
+    RFX_TRY(rfx_mapping_loss_backward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
+                                      b->depth_trunc, b->rgb_missing_on, w.lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
+    RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
+    RFX_HIP_TRY(hipMemsetAsync(b->d_w, 0, (size_t)(32 * 81 + 16 * 32 + 32 * 66 + 3 * 32) * sizeof(float), st));
+    RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
+    RFX_TRY(rfx_field_backward_weights(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    if (b->d_poses16) {
+        RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_TRY(rfx_field_backward_dx(&b->field, w.x01, nS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
+        const float ex = (float)(b->bbox[1] - b->bbox[0]), ey = (float)(b->bbox[3] - b->bbox[2]), ez = (float)(b->bbox[5] - b->bbox[4]);
+        hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.dx, w.z, n, S, ex, ey, ez, w.go, w.gd);
+        RFX_LAUNCH_CHECK();
+        RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
+    }
+    hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, st, w.ones);
+    RFX_LAUNCH_CHECK();
+    RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, w.ones, w.dfeat, stream));
+    RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
+                                              w.scat_bytes, stream));
+    if (b->losses8) RFX_HIP_TRY(hipMemcpyAsync(b->losses8, w.lc, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return RFX_OK;
+}
+
+}  // extern "C"

@@ -2,12 +2,12 @@
 
 The loss of an iteration (reference mp_slam/mapper.py:394-420 / :470-505: ray batch -> JointEncoding.mapping ->
 get_loss_from_ret(smooth=True) -> backward -> Adam step) is a fixed chain of librfx kernels whose backward is
-known in closed form, so the host can launch forward and backward back to back and hand the gradients to the
-(PyTorch) optimizers itself.  Same kernels, same order, same random draws as the autograd formulation in
-``Mapper.global_mapping / global_pose`` -- only the graph bookkeeping (four Function nodes, the engine's worker
-thread, AccumulateGrad) is gone, the buffers of an iteration are allocated once per batch shape with their device
-pointers resolved up front, and the TV term's hash gradient is scattered together with the field's (one sweep over
-the table, ``rfx_field_backward_scatter_merged``).  ``tests/test_pose_gpu.py`` checks both formulations give the
+known in closed form, so forward and backward are launched back to back by ONE library call
+(``rfx_ba_forward_backward``, csrc/rfx_ba.hip, which only sequences the public entry points) and the gradients are
+handed to the (PyTorch) optimizers here.  Same kernels, same order, same random draws as the autograd formulation in
+``Mapper.global_mapping / global_pose``: what is gone is the graph bookkeeping (four Function nodes, the engine's
+worker thread, AccumulateGrad) and ~20 foreign calls per iteration; the TV term's hash gradient is scattered
+together with the field's (one sweep over the table).  ``tests/test_pose_gpu.py`` checks both formulations give the
 same gradients.  Nothing is pruned: the pose phase still produces the (unused) map gradients the reference's
 backward produces.
 """
@@ -25,6 +25,34 @@ from .._lib import check, stream_ptr
 
 class _Buffers:
     """device buffers of one iteration for a given (rays, samples, lattice, cameras) shape + their pointers."""
+
+    def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K):
+        f32 = dict(dtype=torch.float32, device=dev)
+        t = self.t = SimpleNamespace()
+        t.u = torch.empty((n, S), **f32)
+        t.u6 = torch.empty(6, **f32)
+        t.lc = torch.empty(8, **f32)
+        t.tv_acc = torch.empty(1, dtype=torch.float64, device=dev)
+        t.dt = torch.empty_like(table)
+        t.dw_flat = torch.empty(sum(w.numel() for w in weights), **f32)
+        self.ws_bytes = int(lib.rfx_ba_workspace_bytes(n, S, P, n_feat, n_levels))
+        t.ws = torch.empty(self.ws_bytes // 4 + 64, **f32)
+        self.dws, off = [], 0
+        for w in weights:
+            self.dws.append(t.dw_flat[off:off + w.numel()].view_as(w))
+            off += w.numel()
+        if K:
+            t.poses = torch.empty((K, 4, 4), **f32)
+            t.acts = torch.empty(int(lib.rfx_rba_acts_floats(K)), **f32)
+            t.dposes = torch.empty((K, 4, 4), **f32)
+            t.wsr = torch.empty(int(lib.rfx_rba_grads_floats(K)), **f32)
+        self.p = SimpleNamespace(**{k: v.data_ptr() for k, v in vars(t).items()})
+        self.p.ws = (self.p.ws + 255) // 256 * 256           # the library wants a 256-byte aligned workspace
+        self.n, self.S, self.P = n, S, P
+
+
+class _StageBuffers:
+    """buffers of the stage-by-stage issue (every intermediate is a torch tensor the host can look at)."""
 
     def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K):
         f32 = dict(dtype=torch.float32, device=dev)
@@ -69,6 +97,12 @@ class DirectIterations:
         self.mp, self.model, self.slam = mapper, mapper.model, mapper.slam
         self.lib = _lib.load()
         self._cache = {}
+        self.stagewise_every = 0        # bench.py: issue every k-th iteration stage by stage (timed per entry point)
+        self._count = 0
+
+    def _stagewise_now(self) -> bool:
+        self._count += 1
+        return self.stagewise_every > 0 and self._count % self.stagewise_every == 0
 
     @staticmethod
     def supported(mapper) -> bool:
@@ -89,9 +123,49 @@ class DirectIterations:
                 self._cache.clear()
             b = self._cache[key] = _Buffers(self.lib, dev, n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
                                             self.model.decoder_res.fused_weights(), K)
-        return b, S, P
+        return b
 
-    # ------------------------------------------------------------------ pieces
+    def _n_rays(self):
+        m = self.mp.config["mapping"]
+        return int(m["sample"]) + int(max(m["sample"] // len(self.mp.keyframe.frame_ids), m["min_pixels_cur"]))
+
+    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st):
+        """fill the descriptor of this iteration and launch it (forward + backward)."""
+        lib, model, mp = self.lib, self.model, self.mp
+        cfg = model.config
+        tr, m = cfg["training"], cfg["mapping"]
+        t, p = B.t, B.p
+        dev = t.u.device
+        d = _lib.BaDesc()
+        d.field = model._field_desc(clamp)
+        d.sampler = model._sampler_desc()
+        d.bbox, d.bbox_f64 = model._bbox6, model._bbox_f64
+        d.sc_factor, d.depth_trunc, d.trunc = float(cfg["data"]["sc_factor"]), float(cfg["cam"]["depth_trunc"]), float(tr["trunc"])
+        d.rgb_missing_on = int(tr["rgb_missing"] > 0)
+        d.loss_w_dev = model._loss_weights(dev).data_ptr()
+        d.tv_P, d.tv_voxel, d.tv_margin = B.P, float(tr["smooth_vox"]), float(tr["smooth_margin"])
+        d.tv_scale = float(tr["smooth_weight"]) / float(int(tr["smooth_pts"]) ** 3)
+        d.tv_normalise = 1 if cfg["grid"]["tcnn_encoding"] else 0
+        kf = mp.keyframe
+        d.kf_rays, d.rays_per_kf, d.num_kf = kf.rays.data_ptr(), kf.num_rays_to_save, len(kf)
+        d.kf_frame_ids, d.keyframe_every = kf.frame_ids_dev.data_ptr(), int(m["keyframe_every"])
+        d.cur_rays, d.cur_population = current_rays.data_ptr(), current_rays.shape[0]
+        d.n_kf_samples, d.n_cur = int(m["sample"]), B.n - int(m["sample"])
+        d.seed_kf, d.seed_cur = random.getrandbits(64), random.getrandbits(64)     # same draw order as the autograd path
+        d.poses16, d.K = poses_ptr, K
+        if tr["perturb"] > 0.0:
+            t.u.uniform_()                               # the draw torch.rand((n, S)) makes
+            d.u_z = p.u
+        t.u6.uniform_()                                   # the draw torch.rand(6) makes
+        d.u6 = p.u6
+        enc = model.embed_res_fn
+        d.hash_entries = enc.params.numel() // int(enc.desc.n_feat)
+        d.d_hash, d.d_w, d.d_poses16, d.losses8, d.tv_sum = p.dt, p.dw_flat, d_poses_ptr, p.lc, p.tv_acc
+        check(lib.rfx_ba_forward_backward(C.byref(d), p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
+
+    # ------------------------------------------------------------------ stage-by-stage issue (instrumentation / cross-check)
+    # The same iteration as rfx_ba_forward_backward, one foreign call per stage, so that bench.py can put HIP events
+    # around the individual entry points and tests can compare the two.  Used for every `stagewise_every`-th iteration.
     def _rays(self, B, current_rays, poses_ptr, K, st):
         mp, lib, m = self.mp, self.lib, self.mp.config["mapping"]
         kf = mp.keyframe
@@ -102,9 +176,6 @@ class DirectIterations:
                                   current_rays.data_ptr(), current_rays.shape[0], int(m["sample"]), n_cur, seed_kf, seed_cur,
                                   poses_ptr, K, p.o, p.d, p.tgt, p.td, p.d_cam, p.pidx, st), "rfx_gather_rays")
 
-    def _n_rays(self):
-        m = self.mp.config["mapping"]
-        return int(m["sample"]) + int(max(m["sample"] // len(self.mp.keyframe.frame_ids), m["min_pixels_cur"]))
 
     def _forward_backward(self, B, S, P, clamp, want_ray_grads, st):
         """mapping objective + TV term on the rays in B: forward, then backward into B.dt / B.dws (and, for
@@ -164,6 +235,21 @@ class DirectIterations:
               "rfx_field_backward_scatter_merged")
         return go, gd
 
+
+    def _run_stagewise(self, current_rays, poses_ptr, K, clamp, want_pose_grads, dev, st):
+        tr = self.model.config["training"]
+        enc = self.model.embed_res_fn
+        n = self._n_rays()
+        S, P = int(tr["n_range_d"]) + int(tr["n_samples_d"]), int(tr["smooth_pts"]) - 1
+        key = ("stage", n, S, P, K, str(dev), enc.params.data_ptr())
+        B = self._cache.get(key)
+        if B is None:
+            B = self._cache[key] = _StageBuffers(self.lib, dev, n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
+                                                 self.model.decoder_res.fused_weights(), K)
+        self._rays(B, current_rays, poses_ptr, K, st)
+        go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st)
+        return B, go, gd
+
     def _set_map_grads(self, B):
         self.model.embed_res_fn.params.grad = B.t.dt
         for prm, g in zip(self.model.decoder_res.fused_weights(), B.dws):
@@ -174,10 +260,11 @@ class DirectIterations:
         """forward + backward of one global_mapping iteration: leaves the gradients in .grad."""
         Pm = poses_all.detach().to(torch.float32).contiguous()
         dev = Pm.device
-        st = stream_ptr(dev)
-        B, S, P = self._buffers(self._n_rays(), 0, dev)
-        self._rays(B, current_rays, Pm.data_ptr(), Pm.shape[0], st)
-        self._forward_backward(B, S, P, False, False, st)
+        if self._stagewise_now():
+            B, _, _ = self._run_stagewise(current_rays, Pm.data_ptr(), Pm.shape[0], False, False, dev, stream_ptr(dev))
+        else:
+            B = self._buffers(self._n_rays(), 0, dev)
+            self._run(B, current_rays, Pm.data_ptr(), Pm.shape[0], False, None, stream_ptr(dev))
         self._set_map_grads(B)
         return B.t.lc
 
@@ -203,16 +290,19 @@ class DirectIterations:
         dev = idx.device
         K = idx.shape[0]
         st = stream_ptr(dev)
-        B, S, P = self._buffers(self._n_rays(), K, dev)
-        p = B.p
+        R = self._buffers(self._n_rays(), K, dev)     # owns the RBA buffers in both modes
+        p = R.p
         params = [w for m in rba._linears() for w in (m.weight, m.bias)]
         prm = _lib.RbaParams(*[w.data_ptr() for w in params], 256)
         check(lib.rfx_rba_forward(C.byref(prm), rba.init_r.data_ptr(), rba.init_t.data_ptr(), idx.data_ptr(), K, rba.num_cams,
                                   float(rba.scale), p.poses, p.acts, st), "rfx_rba_forward")
-        self._rays(B, current_rays, p.poses, K, st)
-        go, gd = self._forward_backward(B, S, P, True, True, st)
+        if self._stagewise_now():
+            B, go, gd = self._run_stagewise(current_rays, p.poses, K, True, True, dev, st)
+            check(lib.rfx_pose_grad(go.data_ptr(), gd.data_ptr(), B.p.d_cam, B.p.pidx, B.t.o.shape[0], K, p.dposes, st), "rfx_pose_grad")
+        else:
+            B = R
+            self._run(B, current_rays, p.poses, K, True, p.dposes, st)
         self._set_map_grads(B)                       # produced by the reference's backward too; no optimizer consumes them
-        check(lib.rfx_pose_grad(go.data_ptr(), gd.data_ptr(), p.d_cam, p.pidx, B.t.o.shape[0], K, p.dposes, st), "rfx_pose_grad")
         grads = [torch.empty_like(w) for w in params]
         gdesc = _lib.RbaGrads(*[g.data_ptr() for g in grads])
         check(lib.rfx_rba_backward(C.byref(prm), p.acts, K, p.dposes, float(rba.scale), C.byref(gdesc), p.wsr, st), "rfx_rba_backward")

@@ -199,3 +199,14 @@ def test_direct_iterations_equal_autograd_iterations():
     assert float(ref_r[0].abs().max()) > 0
     for g, r in zip(got_m, ref_m):
         assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-12
+    # ---- the one-call driver (rfx_ba_forward_backward) vs the same iteration issued stage by stage
+    direct.stagewise_every = 1
+    reset()
+    direct.pose_gradients(cur, all_index.reshape(-1).contiguous())
+    st_r, st_m = grads_of(rba_params), grads_of(params)
+    direct.stagewise_every = 0
+    for g, r in zip(got_m[1:], st_m[1:]):
+        assert torch.equal(g, r)                              # dW: deterministic reductions, identical kernels
+    assert float((got_m[0] - st_m[0]).abs().max()) <= 1e-4 * float(st_m[0].abs().max())      # hash grads: atomic order
+    for g, r in zip(got_r, st_r):
+        assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
