@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
 #endif
 constexpr unsigned SCATTER_SEG = SCATTER_SEG_ENTRIES;
 constexpr int SCATTER_THREADS = 1024;
-constexpr int SCATTER_MAX_SEGMENTS = 640;      // above this (T >= 2^20) the per-segment point sweeps dominate
+constexpr int SCATTER_MAX_SEGMENTS = 2048;     // T = 2^21: ~1300 segments
 constexpr int64_t SCATTER_MIN_POINTS = 4096;
 
 struct ScatterPlan {

@@ -180,9 +180,9 @@ def test_field_backward_matches_autograd_of_oracle(clamp, n):
     assert m.GBV.params.grad is None
 
 
-@pytest.mark.parametrize("name,n", [("office0", 2000), ("office0", 12000), ("scene0000", 12000)])
+@pytest.mark.parametrize("name,n", [("office0", 2000), ("office0", 12000), ("scene0000", 12000), ("cafeteria", 9000)])
 def test_grid_encode_backward_standalone(name, n):
-    """n < 4096: direct atomics; n >= 4096: LDS-privatised scatter (T = 2^16: <= 4 segments / level, 2^19: 32)."""
+    """n < 4096: direct atomics; n >= 4096: LDS-privatised scatter (T = 2^16: <= 4 segments / level, 2^19: 32, 2^21: 128)."""
     cfg, m = _model(name, gbv_fill=False)
     fp = _oracle_params(cfg, m)
     x = _points(n, seed=2, lo=-0.05, hi=1.05)           # a few points outside the unit cube: dense levels wrap
