@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
 #endif
 constexpr unsigned SCATTER_SEG = SCATTER_SEG_ENTRIES;
 constexpr int SCATTER_THREADS = 1024;
-constexpr int SCATTER_MAX_SEGMENTS = 2048;     // T = 2^21: ~1300 segments
+#ifndef SCATTER_MAX_SEGMENTS_N
+#define SCATTER_MAX_SEGMENTS_N 2048
+#endif
+constexpr int SCATTER_MAX_SEGMENTS = SCATTER_MAX_SEGMENTS_N;     // T = 2^21: ~1300 segments
 constexpr int64_t SCATTER_MIN_POINTS = 4096;
 
 struct ScatterPlan {
