@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
 #ifndef SCATTER_SEG_ENTRIES
 #define SCATTER_SEG_ENTRIES 16384
 #endif
+#ifndef SCATTER_BATCH
+#define SCATTER_BATCH 4
+#endif
 #ifndef SCATTER_TARGET_BLOCKS
 #define SCATTER_TARGET_BLOCKS 512
 #endif
@@ -250,15 +253,16 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     extern __shared__ float acc[];
     int l = 0;
     while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
+    const int seg = blockIdx.x - plan.seg_start[l], chunk = blockIdx.y;
     const Level lv = get_level(g, l);
-    const unsigned base = (blockIdx.x - plan.seg_start[l]) * SCATTER_SEG;
+    const unsigned base = (unsigned)seg * SCATTER_SEG;
     const unsigned cnt = min(SCATTER_SEG, lv.size - base);
     for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) acc[i] = 0.f;
     __syncthreads();
     const int64_t slots = plan.slots;
     const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
     const float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
-    int64_t s = (int64_t)blockIdx.y * plan.K * SCATTER_THREADS + threadIdx.x;
+    int64_t s = (int64_t)chunk * plan.K * SCATTER_THREADS + threadIdx.x;
 
     Cell cur;                       // cell of the running register accumulation
     bool open = false;
@@ -279,32 +283,70 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #endif
         }
     };
-    // software-pipelined: the loads of point i+1 are in flight while point i is processed
-    float2 gv_n = gvp[s];
-    float xn[3] = {xs[s], xs[slots + s], xs[2 * slots + s]};
-    for (int i = 0; i < plan.K; ++i) {
-        const float2 gv = gv_n;
-        const float x[3] = {xn[0], xn[1], xn[2]};
-        s += SCATTER_THREADS;
-        if (i + 1 < plan.K) {
-            gv_n = gvp[s];
-            xn[0] = xs[s]; xn[1] = xs[slots + s]; xn[2] = xs[2 * slots + s];
-        }
-        if (gv.x == 0.f && gv.y == 0.f) continue;
-        const Cell c = locate(lv, x);
-        const bool same = open && c.g[0] == cur.g[0] && c.g[1] == cur.g[1] && c.g[2] == cur.g[2];
-        if (!same) {
-            if (open) flush();
-            cur = c;
-            open = true;
+    // The loop is bound by the latency of its streaming loads (16 waves per CU, one 128 KB block), so the points are
+    // taken SCATTER_BATCH at a time with the next batch's loads already in flight while this one is processed.
+    constexpr int NB = SCATTER_BATCH;
+    float2 gv_n[NB];
+    float xn[NB][3];
+    auto fetch = [&](int i0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+        for (int j = 0; j < NB; ++j) {
+            const bool live = i0 + j < plan.K;
+            const int64_t sj = s + (int64_t)j * SCATTER_THREADS;
+            gv_n[j] = live ? gvp[sj] : make_float2(0.f, 0.f);
+            xn[j][0] = live ? xs[sj] : 0.5f; xn[j][1] = live ? xs[slots + sj] : 0.5f; xn[j][2] = live ? xs[2 * slots + sj] : 0.5f;
+        }
+        s += (int64_t)NB * SCATTER_THREADS;
+    };
+    fetch(0);
+    for (int i = 0; i < plan.K; i += NB) {
+        float2 gvb[NB];
+        float xb[NB][3];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { gvb[j] = gv_n[j]; xb[j][0] = xn[j][0]; xb[j][1] = xn[j][1]; xb[j][2] = xn[j][2]; }
+        if (i + NB < plan.K) fetch(i + NB);
+        if (lv.hashed && lv.size >= 16u * SCATTER_SEG) {
+            // big hashed level (>= 16 segments): nearly every corner falls into another segment, so test segment
+            // membership first and add only the corners that land here, without the register run accumulation
+            // (measured: 1.25-1.6x faster at 128 segments, neutral at 32, slower at 4)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float2 gv = gvb[j];
+                if (gv.x == 0.f && gv.y == 0.f) continue;
+                const Cell c = locate(lv, xb[j]);
+                unsigned idx8[8];
+                corner_indices(lv, c, idx8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned r = idx8[k] - base;
+                    if (r < cnt) {
+                        const float w = corner_weight(c, k);
+                        atomicAdd(&acc[2 * r], w * gv.x);
+                        atomicAdd(&acc[2 * r + 1], w * gv.y);
+                    }
+                }
+            }
+            continue;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float w = corner_weight(c, k);
-            a0[k] += w * gv.x;
-            a1[k] += w * gv.y;
+        for (int j = 0; j < NB; ++j) {
+            const float2 gv = gvb[j];
+            if (gv.x == 0.f && gv.y == 0.f) continue;
+            const Cell c = locate(lv, xb[j]);
+            const bool same = open && c.g[0] == cur.g[0] && c.g[1] == cur.g[1] && c.g[2] == cur.g[2];
+            if (!same) {
+                if (open) flush();
+                cur = c;
+                open = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = corner_weight(c, k);
+                a0[k] += w * gv.x;
+                a1[k] += w * gv.y;
+            }
         }
     }
     if (open) flush();
@@ -359,6 +401,8 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // (an XCD-aware block order -- all segments of one (level, chunk) on one XCD's L2 -- was measured: no gain at
+    // T = 2^16 / 2^19 and a loss at 2^21, the levels' costs differ too much to be dealt out per XCD)
     hipLaunchKernelGGL(grid_scatter_lds_kernel, dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan, g.n_levels,
                        scratch, dtable);
     return RFX_OK;
