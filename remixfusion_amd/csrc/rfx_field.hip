@@ -214,6 +214,12 @@ static size_t scatter_scratch_floats(int64_t n, int n_levels) {
     return slots * (size_t)(2 * n_levels + 3);
 }
 
+// LDS slot of table entry r of a segment.  On the dense levels the vertices of neighbouring cells are res or res^2
+// entries apart -- multiples of 16 for res = 16, 20, 24, 36, ... -- so points that differ only in y or z (a TV lattice,
+// rays along an axis) would all hit ONE bank; XOR-ing the low four bits with the next three nibbles spreads them
+// (a permutation inside every aligned group of 16 entries).
+__device__ __forceinline__ unsigned lds_slot(unsigned r) { return r ^ (((r >> 4) ^ (r >> 8) ^ (r >> 12)) & 15u); }
+
 // slot (chunk c, iteration i, thread t) <- point c*K*1024 + t*K + i.  Planes: L x float2[slots], then x,y,z.
 // The point list is the concatenation of up to two sources (e.g. the ray samples and the TV lattice), so
 // that one sweep over the table segments serves both.
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     const Level lv = get_level(g, l);
     const unsigned base = (unsigned)seg * SCATTER_SEG;
     const unsigned cnt = min(SCATTER_SEG, lv.size - base);
-    for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) acc[i] = 0.f;
+    for (unsigned i = threadIdx.x; i < ((cnt + 15u) & ~15u) * 2; i += SCATTER_THREADS) acc[i] = 0.f;
     __syncthreads();
     const int64_t slots = plan.slots;
     const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
@@ -274,11 +280,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
         for (int k = 0; k < 8; ++k) {
             const unsigned r = idx8[k] - base;
 #if defined(SCATTER_DBG) && SCATTER_DBG == 2
-            if (r < cnt) { acc[2 * r] = a0[k]; acc[2 * r + 1] = a1[k]; }
+            if (r < cnt) { acc[2 * lds_slot(r)] = a0[k]; acc[2 * lds_slot(r) + 1] = a1[k]; }
 #else
             if (r < cnt) {
-                atomicAdd(&acc[2 * r], a0[k]);
-                atomicAdd(&acc[2 * r + 1], a1[k]);
+                atomicAdd(&acc[2 * lds_slot(r)], a0[k]);
+                atomicAdd(&acc[2 * lds_slot(r) + 1], a1[k]);
             }
 #endif
         }
@@ -321,8 +327,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
                     const unsigned r = idx8[k] - base;
                     if (r < cnt) {
                         const float w = corner_weight(c, k);
-                        atomicAdd(&acc[2 * r], w * gv.x);
-                        atomicAdd(&acc[2 * r + 1], w * gv.y);
+                        atomicAdd(&acc[2 * lds_slot(r)], w * gv.x);
+                        atomicAdd(&acc[2 * lds_slot(r) + 1], w * gv.y);
                     }
                 }
             }
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     __syncthreads();
     float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
     for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) {
-        const float v = acc[i];
+        const float v = acc[2 * lds_slot(i >> 1) + (i & 1)];
 #if defined(SCATTER_DBG) && SCATTER_DBG == 1
         if (v == 12345.f) out[i] = v;
 #elif defined(SCATTER_DBG) && SCATTER_DBG == 3

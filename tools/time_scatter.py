@@ -42,3 +42,8 @@ lat = torch.stack(torch.meshgrid(*[torch.arange(P, device="cuda") * 0.004 + 0.3]
 x, n = lat, lat.shape[0]
 dfeat = torch.randn((n, 32), device="cuda", generator=g); ws = torch.empty(int(lib.rfx_grid_encode_backward_workspace_bytes(n, 16)) // 4, device="cuda")
 print("TV lattice points", n, "direct", run(False), "lds", run(True))
+# both point sets in one launch (what the merged scatter of the BA iteration sees)
+xa = torch.cat([(o + d * t).clamp(0.001, 0.999).reshape(-1, 3), lat], 0).contiguous()
+x, n = xa, xa.shape[0]
+dfeat = torch.randn((n, 32), device="cuda", generator=g); ws = torch.empty(int(lib.rfx_grid_encode_backward_workspace_bytes(n, 16)) // 4, device="cuda")
+print("concatenated points", n, "direct", run(False), "lds", run(True))

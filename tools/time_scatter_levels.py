@@ -46,9 +46,11 @@ def run(x, k, use_ws, reps=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 print("sizes", list(enc.desc.size)[:16])
-for label, x in (("TV lattice", pts), ("ray samples", rays)):
+pts_in = pts.clone(); pts_in[:, 2] = pts_in[:, 2].clamp(0.0, 0.999)
+pts_mod = pts.clone(); pts_mod[:, 2] = pts_mod[:, 2] - torch.floor(pts_mod[:, 2])
+for label, x in (("TV lattice", pts), ("TV z clamped", pts_in), ("TV z mod 1", pts_mod)):
     prev_l = prev_d = 0.0
-    for k in range(1, 17):
+    for k in (4, 8, 12, 16):
         a, b = run(x, k, True), run(x, k, False)
         print(f"{label:12s} levels 0..{k-1:2d}: lds {a:7.3f} ms (+{a - prev_l:6.3f})   direct {b:7.3f} ms (+{b - prev_d:6.3f})")
         prev_l, prev_d = a, b
