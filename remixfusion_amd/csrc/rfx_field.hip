@@ -198,13 +198,22 @@ struct ScatterPlan {
     int64_t slots;       // chunks * K * SCATTER_THREADS
 };
 
+// How many slices to cut the point list into.  One block per CU (128 KB of LDS), so the launch runs in
+// ceil(segments * chunks / 256) rounds of blocks that each cost (points / chunks) * t_point + t_fixed (zeroing and
+// flushing the segment).  Pick the chunk count that minimises rounds * block cost: it keeps the last round from
+// running nearly empty (317 segments at T = 2^19 would otherwise take two full-length rounds).
 static void scatter_shape(int64_t n, int total_segments, int* chunks, int* K) {
-    int c = total_segments > 0 ? SCATTER_TARGET_BLOCKS / total_segments : 1;
-    const int64_t max_chunks = (n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS;
-    if (c > max_chunks) c = (int)max_chunks;
-    if (c < 1) c = 1;
-    const int64_t per = (n + c - 1) / c;
-    *chunks = c;
+    const int64_t max_chunks = std::max<int64_t>(1, std::min<int64_t>(64, (n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS));
+    const double t_point = 6.4e-3, t_fixed = 12.0;      // microseconds; measured on MI355X (only the ratio matters)
+    int best = 1;
+    double best_t = 1e300;
+    for (int c = 1; c <= (int)max_chunks; ++c) {
+        const int rounds = (total_segments * c + 255) / 256;
+        const double t = rounds * ((double)n / c * t_point + t_fixed);
+        if (t < best_t * 0.97) { best_t = t; best = c; }          // prefer fewer chunks unless clearly better
+    }
+    const int64_t per = (n + best - 1) / best;
+    *chunks = best;
     *K = (int)((per + SCATTER_THREADS - 1) / SCATTER_THREADS);
 }
 
