@@ -210,3 +210,48 @@ def test_direct_iterations_equal_autograd_iterations():
     assert float((got_m[0] - st_m[0]).abs().max()) <= 1e-4 * float(st_m[0].abs().max())      # hash grads: atomic order
     for g, r in zip(got_r, st_r):
         assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
+
+
+def test_error_statuses_of_the_round_one_entry_points():
+    """every entry point returns a status instead of faulting on bad arguments (include/rfx.h: error behaviour)."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    st = L.stream_ptr(torch.device("cuda"))
+    f = torch.zeros(64, device="cuda")
+    i64 = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -3, -4
+    # ray batch: more samples than rays in the population
+    assert lib.rfx_gather_rays(L.ptr(f), 4, 1, i64.data_ptr(), 5, L.ptr(f), 4, 8, 0, 1, 2, L.ptr(f), 1, L.ptr(f), L.ptr(f), L.ptr(f),
+                               L.ptr(f), L.ptr(f), i64.data_ptr(), st) == ERR_ARG
+    assert lib.rfx_gather_rays(None, 0, 0, None, 5, None, 0, 0, 0, 1, 2, L.ptr(f), 1, L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f),
+                               i64.data_ptr(), st) == 0                                  # empty batch is fine
+    # pose MLP: only the reference width is implemented
+    prm = L.RbaParams(*([L.ptr(f)] * 8), 128)
+    assert lib.rfx_rba_forward(C.byref(prm), L.ptr(f), L.ptr(f), i64.data_ptr(), 2, 4, 0.01, L.ptr(f), L.ptr(f), st) == ERR_UNSUPPORTED
+    prm = L.RbaParams(*([L.ptr(f)] * 8), 256)
+    assert lib.rfx_rba_forward(C.byref(prm), L.ptr(f), L.ptr(f), i64.data_ptr(), 0, 4, 0.01, L.ptr(f), L.ptr(f), st) == 0    # K = 0
+    # marching cubes needs at least one cell
+    assert lib.rfx_mc_count(L.ptr(f), None, 1, 4, 4, 0.0, i64.data_ptr(), i64.data_ptr(), st) == ERR_ARG
+    # TV lattice
+    assert lib.rfx_tv_lattice(L.ptr(f), 0, 0.1, 0.05, L.farr(L._D6, [0, 1, 0, 1, 0, 1]), 1, 1, L.ptr(f), st) == ERR_ARG
+    # one-call BA iteration: undersized / misaligned workspace, missing outputs
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.scene_rep import JointEncoding
+    import numpy as np
+    cfg = synthetic_config("office0")
+    m = JointEncoding(cfg, torch.from_numpy(np.array(cfg["mapping"]["bound"])), num_kf=4).cuda()
+    d = L.BaDesc()
+    d.field, d.sampler = m._field_desc(False), m._sampler_desc()
+    d.n_kf_samples, d.n_cur, d.tv_P, d.K, d.hash_entries = 8, 8, 4, 1, 16
+    big = torch.zeros(1 << 20, device="cuda")
+    for name in ("d_hash", "d_w", "u6", "poses16", "loss_w_dev"):
+        setattr(d, name, L.ptr(big))
+    need = lib.rfx_ba_workspace_bytes(16, 59, 4, 32, 16)
+    assert need > 0 and lib.rfx_ba_workspace_bytes(0, 59, 4, 32, 16) == 0
+    base = (big.data_ptr() + 255) // 256 * 256
+    assert lib.rfx_ba_forward_backward(C.byref(d), base, need - 1, st) == ERR_WORKSPACE
+    assert lib.rfx_ba_forward_backward(C.byref(d), base + 4, need, st) == ERR_ARG
+    d.d_hash = None
+    assert lib.rfx_ba_forward_backward(C.byref(d), base, need, st) == ERR_ARG
+    torch.cuda.synchronize()
