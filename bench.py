@@ -24,6 +24,12 @@ import os
 import sys
 import time
 
+# The host side of the frame loop is a handful of tiny numpy / torch-CPU ops per frame.  On a box that exposes 256 cores
+# through a 16-CPU quota, default-sized BLAS / OpenMP pools (256 spinning threads) burn the quota and get the whole process
+# throttled (cpu.stat nr_throttled), which shows up as 2x swings in frames/s.  Small pools, set before numpy/torch load.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 import torch
 
