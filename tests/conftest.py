@@ -1,6 +1,11 @@
 import os
 import sys
 
+# bounded BLAS / OpenMP pools (the CPU oracle is the only heavy host work here): on a box that shows hundreds of cores behind
+# a small CPU quota, default-sized pools get the test process throttled
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "16")
+
 import numpy as np
 import pytest
 
