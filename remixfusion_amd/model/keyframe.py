@@ -23,6 +23,9 @@ class KeyFrameDatabase(object):
         self.rays = torch.zeros((num_kf, num_rays_to_save, 7), device=device)
         self.num_rays_to_save = num_rays_to_save
         self.frame_ids = None
+        # device twin of frame_ids, pre-sized: appended to with scalar fills, so adding a keyframe neither copies
+        # host memory to the device nor drains the stream
+        self.frame_ids_dev = torch.zeros((num_kf,), dtype=torch.int64, device=device)
         self.H, self.W = H, W
         self.kf_poses = torch.zeros((num_kf, 4, 4))
         self.kf_fuse_poses = torch.zeros((num_kf, 4, 4))
@@ -66,8 +69,10 @@ class KeyFrameDatabase(object):
         return rays_valid[idx_t, :]
 
     def attach_ids(self, frame_ids):
+        n0 = 0 if self.frame_ids is None else len(self.frame_ids)
         self.frame_ids = frame_ids if self.frame_ids is None else torch.cat([self.frame_ids, frame_ids], dim=0)
-        self.frame_ids_dev = self.frame_ids.to(self.device)      # device twin: no H2D copy per sampling call
+        for j, v in enumerate(frame_ids.tolist()):
+            self.frame_ids_dev[n0 + j].fill_(int(v))
 
     def add_keyframe(self, batch, filter_depth=False):
         first = bool(batch["frame_id"] == 0)

@@ -88,14 +88,14 @@ def rotation_matrix_to_angle_axis(R: torch.Tensor) -> torch.Tensor:
     scale = torch.where(small, 1.0 + theta * theta / 6.0, theta / s.clamp_min(1e-12))
     aa = v * scale[:, None]
     near_pi = small & (c < 0)
-    if bool(near_pi.any()):
-        d = torch.stack([m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]], -1)
-        axis = torch.sqrt(torch.clamp((d + 1.0) / 2.0, min=0.0))          # |w_i| from R = 2 w w^T - I at theta = pi
-        k = axis.argmax(-1)
-        sign = torch.sign(torch.gather(m, 1, k[:, None, None].expand(-1, 1, 3)).squeeze(1) + 1e-20)   # row k fixes the signs
-        axis = axis * sign
-        axis = axis / axis.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-        aa = torch.where(near_pi[:, None], axis * theta[:, None], aa)
+    # evaluated for every row and selected with where(): a host-side `if near_pi.any()` would synchronise the stream
+    d = torch.stack([m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]], -1)
+    axis = torch.sqrt(torch.clamp((d + 1.0) / 2.0, min=0.0))          # |w_i| from R = 2 w w^T - I at theta = pi
+    k = axis.argmax(-1)
+    sign = torch.sign(torch.gather(m, 1, k[:, None, None].expand(-1, 1, 3)).squeeze(1) + 1e-20)   # row k fixes the signs
+    axis = axis * sign
+    axis = axis / axis.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    aa = torch.where(near_pi[:, None], axis * theta[:, None], aa)
     return aa
 
 

@@ -64,6 +64,7 @@ class MappingPipeline:
         for i in ids:
             b = self.dataset[i]
             b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
+            b["c2w_dev"] = b["c2w"].to(self.device)     # a pageable H2D copy in the frame loop would drain the stream
             out[i] = b
         return out
 
@@ -72,7 +73,7 @@ class MappingPipeline:
         self.track_frame(0, batch0)
         if self.mapper is not None:
             n = self.config["mapping"]["first_iters"] if first_iters is None else first_iters
-            self.mapper.first_frame_mapping({k: v for k, v in batch0.items() if k != "rgb255"}, n)
+            self.mapper.first_frame_mapping({k: v for k, v in batch0.items() if k not in ("rgb255", "c2w_dev")}, n)
 
     def track_frame(self, i: int, batch: Dict):
         """tracker side with GT pose: follow the camera with the volume, then integrate
@@ -82,7 +83,7 @@ class MappingPipeline:
                 self.slam.est_c2w_data[0] = batch["c2w"].to(self.device)
                 self.slam.RO_c2w_data[0] = batch["c2w"].to(self.device)
             else:
-                self.tracker.tracking({k: v for k, v in batch.items() if k != "rgb255"}, i)
+                self.tracker.tracking({k: v for k, v in batch.items() if k not in ("rgb255", "c2w_dev")}, i)
                 self.slam.tracking_idx[0] = i
             return
         c2w = batch["c2w"]
@@ -94,12 +95,15 @@ class MappingPipeline:
             rgb255 = torch.floor(batch["rgb"] * 255.0 + 0.5)
         self.mv.integrate(rgb255, batch["depth"], self.K, pose_np, self.mv.vol_bnds)
         if self.slam is not None:
-            self.slam.est_c2w_data[i] = c2w.to(self.device)
+            c2w_dev = batch.get("c2w_dev")
+            if c2w_dev is None:
+                c2w_dev = c2w.to(self.device)
+            self.slam.est_c2w_data[i] = c2w_dev
             ke = self.config["mapping"]["keyframe_every"]
             if i % ke != 0:     # relative pose to the last keyframe, like the tracker stores it
                 kf = self.slam.est_c2w_data[(i // ke) * ke]
                 # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop
-                self.slam.est_c2w_data_rel[i] = c2w.to(self.device) @ torch.linalg.inv_ex(kf).inverse
+                self.slam.est_c2w_data_rel[i] = c2w_dev @ torch.linalg.inv_ex(kf).inverse
             self.slam.tracking_idx[0] = i
 
     def step(self, i: int, batch: Dict):
