@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--first-iters", type=int, default=None, help="override mapping.first_iters (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-frames", type=int, default=3)
+    ap.add_argument("--unused-gradients", action="store_true",
+                    help="pose iterations also compute the map gradients the reference's backward produces and then zeroes "
+                         "(mapping.unused_gradients); results are the same, only slower")
     return ap.parse_args()
 
 
@@ -186,6 +189,7 @@ def main():
     cfg = synthetic_config(args.config)
     if args.first_iters is not None:
         cfg["mapping"]["first_iters"] = args.first_iters
+    cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
     n_frames = 1 + args.warmup + args.steps
     shard = make_shard(cfg, rank, world, dist) if world > 1 else None
     if shard is not None:
@@ -363,6 +367,9 @@ def main():
                                f"{'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
                                f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
                                f"{cfg['mapping']['iters']} map + {cfg['mapping']['BA_iters']} pose iters every {cfg['mapping']['map_every']} frames, poses initialised from the ground-truth trajectory and refined by the RBA pose MLP",
+                   "unused_gradients": bool(args.unused_gradients),
+                   "note": "pose iterations step only the pose MLP (reference mapper.py:494-499); the map gradients its backward also "
+                           "produces and zeroes are computed only with --unused-gradients (same parameters and poses either way)",
                    "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},
         "render_rays_per_s": round(render, 1) if render else None,
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,

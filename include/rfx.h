@@ -389,8 +389,11 @@ typedef struct rfx_ba_desc {
     const float*  u_z;                  /* dev [n,S] uniforms of the sampler jitter, or NULL                 */
     const float*  u6;                   /* dev [6] uniforms of the TV lattice                                */
     int64_t       hash_entries;         /* entries (of n_feat floats) of the hash table = size of d_hash     */
-    float*        d_hash;               /* out dev: hash-table gradient (zeroed here)                        */
-    float*        d_w;                  /* out dev [5312]: dW1 | dW2 | dW3 | dW4 (zeroed here)               */
+    float*        d_hash;               /* out dev: hash-table gradient (zeroed here); d_hash and d_w both NULL: */
+    float*        d_w;                  /* out dev [5312]: dW1 | dW2 | dW3 | dW4 (zeroed here)  | no map gradients */
+                                        /* (pose phase of global_pose, where no optimizer consumes them, mapper.py:494-499:
+                                         * the weight-gradient, table-scatter and TV-gradient stages are not run; d_poses16
+                                         * is then required, and the TV term is evaluated only if tv_sum is given)         */
     float*        d_poses16;            /* out dev [K,16] or NULL (poses fixed: no ray gradients computed)   */
     float*        losses8;              /* out dev [8] or NULL: the four losses, then their coefficients     */
     double*       tv_sum;               /* out dev [1] or NULL: un-normalised TV sum                         */

@@ -65,7 +65,7 @@ _BASE: Dict[str, Any] = {   # values of configs/Replica/replica.yaml
                 "keyframe_every": 5, "map_every": 5, "n_pixels": 0.05, "first_iters": 200, "optim_cur": False,
                 "min_pixels_cur": 100, "map_accum_step": 1, "pose_accum_step": 1, "map_wait_step": 0,
                 "filter_depth": False, "opt_pose": True, "clamp": 1.0, "pose_scale": 0.01, "save_ckpt": False,
-                "device_sampling": True, "direct_iterations": True,
+                "device_sampling": True, "direct_iterations": True, "unused_gradients": False,
                 "bound": [[-3, 3], [-4, 2.5], [-2, 2.5]],
                 "marching_cubes_bound": [[-2.2, 2.6], [-3.4, 2.1], [-1.4, 2.0]]},
     "grid": {"enc": "HashGrid", "tcnn_encoding": True, "hash_size": 16, "voxel_color": 0.08, "voxel_sdf": 0.02},

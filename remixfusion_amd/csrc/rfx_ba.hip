@@ -93,8 +93,11 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const int64_t n = b->n_kf_samples + b->n_cur;
     const int S = b->sampler.n_range_d + b->sampler.n_samples_d, P = b->tv_P;
     const int L = b->field.hash.n_levels, F = b->field.hash.n_feat;
-    if (n <= 0 || S <= 0 || P <= 0 || !b->d_hash || !b->d_w || !b->u6 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0)
-        return RFX_ERR_ARG;
+    if (n <= 0 || S <= 0 || P <= 0 || !b->u6 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0) return RFX_ERR_ARG;
+    // map gradients are optional as a pair: without them (pose phase, where no optimizer consumes them) only the
+    // ray/pose gradients are produced, so there must be somewhere to put those
+    const bool map_grads = b->d_hash != nullptr;
+    if ((b->d_hash != nullptr) != (b->d_w != nullptr) || (!map_grads && !b->d_poses16)) return RFX_ERR_ARG;
     if ((uintptr_t)workspace & 255) return RFX_ERR_ARG;
     if (workspace_bytes < rfx_ba_workspace_bytes(n, S, P, L * F, L)) return RFX_ERR_WORKSPACE;
     const BaWs w = carve_ba(workspace, n, S, P, L * F, L);
@@ -112,17 +115,22 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const float trunc_loss = b->trunc * b->sc_factor;
     RFX_TRY(rfx_mapping_loss_forward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, trunc_loss, b->depth_trunc, b->rgb_missing_on,
                                      w.sums, w.lc, w.lc + 4, stream));
-    RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
-    RFX_TRY(rfx_grid_encode_forward(&b->field.hash, b->field.hash_table, w.pts, nt, w.feat, stream));
-    if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));
+    // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
+    if (map_grads || b->tv_sum) {
+        RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
+        RFX_TRY(rfx_grid_encode_forward(&b->field.hash, b->field.hash_table, w.pts, nt, w.feat, stream));
+        if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));
+    }
     // ---- backward
     RFX_TRY(rfx_mapping_loss_backward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
                                       b->depth_trunc, b->rgb_missing_on, w.lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
-    RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
-    RFX_HIP_TRY(hipMemsetAsync(b->d_w, 0, (size_t)(32 * 81 + 16 * 32 + 32 * 66 + 3 * 32) * sizeof(float), st));
     RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
-    RFX_TRY(rfx_field_backward_weights(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    if (map_grads) {
+        RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
+        RFX_HIP_TRY(hipMemsetAsync(b->d_w, 0, (size_t)(32 * 81 + 16 * 32 + 32 * 66 + 3 * 32) * sizeof(float), st));
+        float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
+        RFX_TRY(rfx_field_backward_weights(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    }
     if (b->d_poses16) {
         RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));
         RFX_TRY(rfx_field_backward_dx(&b->field, w.x01, nS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
@@ -131,11 +139,13 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
         RFX_LAUNCH_CHECK();
         RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
     }
-    hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, st, w.ones);
-    RFX_LAUNCH_CHECK();
-    RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, w.ones, w.dfeat, stream));
-    RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
-                                              w.scat_bytes, stream));
+    if (map_grads) {
+        hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, st, w.ones);
+        RFX_LAUNCH_CHECK();
+        RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, w.ones, w.dfeat, stream));
+        RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
+                                                  w.scat_bytes, stream));
+    }
     if (b->losses8) RFX_HIP_TRY(hipMemcpyAsync(b->losses8, w.lc, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return RFX_OK;
 }

@@ -98,6 +98,9 @@ class DirectIterations:
         self.lib = _lib.load()
         self._cache = {}
         self.stagewise_every = 0        # bench.py: issue every k-th iteration stage by stage (timed per entry point)
+        # mapping.unused_gradients: also compute, in the pose phase, the map gradients that no optimizer consumes
+        # (what the reference's loss.backward() does); off by default, results are identical either way
+        self.unused_gradients = bool(mapper.config["mapping"].get("unused_gradients", False))
         self._count = 0
 
     def _stagewise_now(self) -> bool:
@@ -129,7 +132,7 @@ class DirectIterations:
         m = self.mp.config["mapping"]
         return int(m["sample"]) + int(max(m["sample"] // len(self.mp.keyframe.frame_ids), m["min_pixels_cur"]))
 
-    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st):
+    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True):
         """fill the descriptor of this iteration and launch it (forward + backward)."""
         lib, model, mp = self.lib, self.model, self.mp
         cfg = model.config
@@ -161,6 +164,8 @@ class DirectIterations:
         enc = model.embed_res_fn
         d.hash_entries = enc.params.numel() // int(enc.desc.n_feat)
         d.d_hash, d.d_w, d.d_poses16, d.losses8, d.tv_sum = p.dt, p.dw_flat, d_poses_ptr, p.lc, p.tv_acc
+        if not map_grads:               # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
+            d.d_hash = d.d_w = d.tv_sum = None
         check(lib.rfx_ba_forward_backward(C.byref(d), p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
 
     # ------------------------------------------------------------------ stage-by-stage issue (instrumentation / cross-check)
@@ -177,7 +182,7 @@ class DirectIterations:
                                   poses_ptr, K, p.o, p.d, p.tgt, p.td, p.d_cam, p.pidx, st), "rfx_gather_rays")
 
 
-    def _forward_backward(self, B, S, P, clamp, want_ray_grads, st):
+    def _forward_backward(self, B, S, P, clamp, want_ray_grads, st, map_grads=True):
         """mapping objective + TV term on the rays in B: forward, then backward into B.dt / B.dws (and, for
         want_ray_grads, d rays_o / d rays_d, returned)."""
         lib, model = self.lib, self.model
@@ -206,28 +211,32 @@ class DirectIterations:
         enc = model.embed_res_fn
         table_ptr = enc.params.data_ptr()
         t.u6.uniform_()                                   # the draw torch.rand(6) makes
-        check(lib.rfx_tv_lattice(p.u6, P, float(tr["smooth_vox"]), float(tr["smooth_margin"]), model._bbox6, model._bbox_f64,
-                                 1 if cfg["grid"]["tcnn_encoding"] else 0, p.pts, st), "rfx_tv_lattice")
         n_tv = P * P * P
-        check(lib.rfx_grid_encode_forward(enc.desc, table_ptr, p.pts, n_tv, p.feat, st), "rfx_grid_encode_forward")
-        check(lib.rfx_tv_forward(p.feat, P, enc.n_output_dims, p.tv_acc, st), "rfx_tv_forward")
+        if map_grads:
+            check(lib.rfx_tv_lattice(p.u6, P, float(tr["smooth_vox"]), float(tr["smooth_margin"]), model._bbox6, model._bbox_f64,
+                                     1 if cfg["grid"]["tcnn_encoding"] else 0, p.pts, st), "rfx_tv_lattice")
+            check(lib.rfx_grid_encode_forward(enc.desc, table_ptr, p.pts, n_tv, p.feat, st), "rfx_grid_encode_forward")
+            check(lib.rfx_tv_forward(p.feat, P, enc.n_output_dims, p.tv_acc, st), "rfx_tv_forward")
         # ---- backward: d(total)/d(loss_i) = training weights; d(total)/d(TV) = smooth_weight
         wvec = model._loss_weights(dev)
         check(lib.rfx_mapping_loss_backward(p.raw, p.z, p.rgb_map, p.depth_map, p.tgt, p.td, n, S, trunc, sc, trunc * sc, depth_trunc,
                                             rgb_on, p.lc + 16, wvec.data_ptr(), None, None, p.d_raw, st), "rfx_mapping_loss_backward")
-        t.dt.zero_()
-        t.dw_flat.zero_()
         ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
         wsp, wb = ws.data_ptr(), ws.numel() * 4
         check(lib.rfx_field_backward_chain(dref, p.x01, n * S, p.d_raw, wsp, wb, st), "rfx_field_backward_chain")
-        dws = p.dws
-        check(lib.rfx_field_backward_weights(n * S, p.d_raw, dws[0], dws[1], dws[2], dws[3], wsp, wb, st), "rfx_field_backward_weights")
+        if map_grads:
+            t.dt.zero_()
+            t.dw_flat.zero_()
+            dws = p.dws
+            check(lib.rfx_field_backward_weights(n * S, p.d_raw, dws[0], dws[1], dws[2], dws[3], wsp, wb, st), "rfx_field_backward_weights")
         go = gd = None
         if want_ray_grads:
             check(lib.rfx_field_backward_scatter(dref, p.x01, n * S, None, p.dx, wsp, wb, st), "rfx_field_backward_scatter")
             check(lib.rfx_field_backward_dx(dref, p.x01, n * S, p.d_raw, p.dx, wsp, wb, st), "rfx_field_backward_dx")
             dp = t.dx.view(n, S, 3) / model._extent_on(dev)
             go, gd = dp.sum(1), (dp * t.z[..., None]).sum(1)
+        if not map_grads:
+            return go, gd
         # TV backward; its hash gradient and the field's are scattered by ONE sweep over the table segments
         scale = float(tr["smooth_weight"]) / float(int(tr["smooth_pts"]) ** 3)
         check(lib.rfx_tv_backward(p.feat, P, enc.n_output_dims, scale, p.ones, p.dfeat, st), "rfx_tv_backward")
@@ -236,7 +245,7 @@ class DirectIterations:
         return go, gd
 
 
-    def _run_stagewise(self, current_rays, poses_ptr, K, clamp, want_pose_grads, dev, st):
+    def _run_stagewise(self, current_rays, poses_ptr, K, clamp, want_pose_grads, dev, st, map_grads=True):
         tr = self.model.config["training"]
         enc = self.model.embed_res_fn
         n = self._n_rays()
@@ -247,7 +256,7 @@ class DirectIterations:
             B = self._cache[key] = _StageBuffers(self.lib, dev, n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
                                                  self.model.decoder_res.fused_weights(), K)
         self._rays(B, current_rays, poses_ptr, K, st)
-        go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st)
+        go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st, map_grads)
         return B, go, gd
 
     def _set_map_grads(self, B):
@@ -278,14 +287,18 @@ class DirectIterations:
 
     def pose_iteration(self, current_rays, idx):
         """one trip of the loop of Mapper.global_pose with opt_pose: poses = RBA(idx), pose-MLP step."""
-        lc = self.pose_gradients(current_rays, idx)
+        lc = self.pose_gradients(current_rays, idx, map_grads=self.unused_gradients)
         self.mp.rba_optimizer.step()
         self.mp.map_optimizer.zero_grad()
         self.mp.rba_optimizer.zero_grad()
         return lc
 
-    def pose_gradients(self, current_rays, idx):
-        """forward + backward of one global_pose iteration: pose-MLP (and map) gradients in .grad."""
+    def pose_gradients(self, current_rays, idx, map_grads=True):
+        """forward + backward of one global_pose iteration: pose-MLP (and, with map_grads, map) gradients in .grad.
+
+        The reference's loss.backward() also fills the map parameters' .grad in this phase, but only the pose
+        optimizer steps before both are zeroed (mp_slam/mapper.py:494-499): with map_grads=False those stages
+        (weight gradients, table scatter, TV term) are not run; poses and parameters come out the same."""
         lib, rba = self.lib, self.model.rba
         dev = idx.device
         K = idx.shape[0]
@@ -297,12 +310,13 @@ class DirectIterations:
         check(lib.rfx_rba_forward(C.byref(prm), rba.init_r.data_ptr(), rba.init_t.data_ptr(), idx.data_ptr(), K, rba.num_cams,
                                   float(rba.scale), p.poses, p.acts, st), "rfx_rba_forward")
         if self._stagewise_now():
-            B, go, gd = self._run_stagewise(current_rays, p.poses, K, True, True, dev, st)
+            B, go, gd = self._run_stagewise(current_rays, p.poses, K, True, True, dev, st, map_grads)
             check(lib.rfx_pose_grad(go.data_ptr(), gd.data_ptr(), B.p.d_cam, B.p.pidx, B.t.o.shape[0], K, p.dposes, st), "rfx_pose_grad")
         else:
             B = R
-            self._run(B, current_rays, p.poses, K, True, p.dposes, st)
-        self._set_map_grads(B)                       # produced by the reference's backward too; no optimizer consumes them
+            self._run(B, current_rays, p.poses, K, True, p.dposes, st, map_grads)
+        if map_grads:
+            self._set_map_grads(B)                   # produced by the reference's backward too; no optimizer consumes them
         grads = [torch.empty_like(w) for w in params]
         gdesc = _lib.RbaGrads(*[g.data_ptr() for g in grads])
         check(lib.rfx_rba_backward(C.byref(prm), p.acts, K, p.dposes, float(rba.scale), C.byref(gdesc), p.wsr, st), "rfx_rba_backward")

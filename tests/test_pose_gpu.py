@@ -210,6 +210,47 @@ def test_direct_iterations_equal_autograd_iterations():
     assert float((got_m[0] - st_m[0]).abs().max()) <= 1e-4 * float(st_m[0].abs().max())      # hash grads: atomic order
     for g, r in zip(got_r, st_r):
         assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
+    # ---- pose phase without the map gradients nobody consumes (the default of Mapper.global_pose): same pose-MLP
+    #      gradients, map parameters untouched; both ways of issuing it
+    for every in (0, 1):
+        direct.stagewise_every = every
+        reset()
+        direct.pose_gradients(cur, all_index.reshape(-1).contiguous(), map_grads=False)
+        assert all(p.grad is None for p in params)
+        for g, r in zip(grads_of(rba_params), got_r):
+            assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
+    direct.stagewise_every = 0
+
+
+def test_pose_phase_without_unused_gradients_gives_the_same_run():
+    """mapping.unused_gradients only decides whether the pose phase also computes the map gradients that the
+    reference's backward produces and then zeroes (mp_slam/mapper.py:494-499): parameters and poses after a
+    few frames agree to the run-to-run noise of the atomic hash-gradient sums."""
+    import random
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+
+    def run(flag):
+        random.seed(5); torch.manual_seed(5)
+        cfg = synthetic_config("office0")
+        cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+        cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+        cfg["mapping"].update({"first_iters": 5, "sample": 512, "iters": 2, "BA_iters": 2, "unused_gradients": flag})
+        cfg["training"].update({"smooth_pts": 16})
+        pipe = MappingPipeline(cfg, n_frames=30, seed=1)
+        frames = pipe.prefetch(list(range(12)))
+        pipe.start(frames[0])
+        for i in range(1, 11):
+            pipe.step(i, frames[i])
+        assert pipe.mapper._direct_iterations().unused_gradients == flag
+        w = [p.detach().clone() for p in pipe.model.decoder_res.fused_weights()] + [pipe.model.embed_res_fn.params.detach().clone()]
+        return w, pipe.slam.est_c2w_data[:11].detach().clone(), [p.detach().clone() for p in pipe.model.rba.parameters()]
+
+    (w0, p0, r0), (w1, p1, r1), (w2, p2, r2) = run(True), run(False), run(True)
+    noise = max(float((a - b).abs().max()) for a, b in zip(w0 + [p0] + r0, w2 + [p2] + r2))      # full vs full
+    diff = max(float((a - b).abs().max()) for a, b in zip(w0 + [p0] + r0, w1 + [p1] + r1))       # full vs lean
+    assert diff <= 10 * noise + 1e-6, (diff, noise)
+    assert float((p0 - p1).abs().max()) <= 10 * float((p0 - p2).abs().max()) + 1e-5
 
 
 def test_error_statuses_of_the_round_one_entry_points():
@@ -252,6 +293,8 @@ def test_error_statuses_of_the_round_one_entry_points():
     base = (big.data_ptr() + 255) // 256 * 256
     assert lib.rfx_ba_forward_backward(C.byref(d), base, need - 1, st) == ERR_WORKSPACE
     assert lib.rfx_ba_forward_backward(C.byref(d), base + 4, need, st) == ERR_ARG
-    d.d_hash = None
+    d.d_hash = None                             # d_hash and d_w come as a pair
+    assert lib.rfx_ba_forward_backward(C.byref(d), base, need, st) == ERR_ARG
+    d.d_w = None                                # neither: only allowed with somewhere to put the pose gradients
     assert lib.rfx_ba_forward_backward(C.byref(d), base, need, st) == ERR_ARG
     torch.cuda.synchronize()
