@@ -180,7 +180,7 @@ def main():
 
     lib = _lib.load()
     timer = KernelTimer()
-    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_weights",
+    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_weights",
                  "rfx_field_backward_scatter", "rfx_field_backward_scatter_merged", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
                  "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
                  "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):

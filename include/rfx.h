@@ -194,6 +194,10 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
  * All take the same workspace; _chain must run first. */
 int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                              void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* _chain for callers that want input gradients only (pose phase: map frozen): stages just the dX1 rows, which is all
+ * _scatter (with dx01) and _dx read; _weights and the d_hash part of _scatter must not follow it. */
+int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                    void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,

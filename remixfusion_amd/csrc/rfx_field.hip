@@ -516,7 +516,9 @@ __device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16&
 }
 
 // ---------------------------------------------------------------- backward kernel A (MFMA chain)
-template <bool POS16>
+// ROWS: also stage the per-point rows the weight-gradient kernel reads (X1, H1, dH1pre, G, dY2, H3, dH3pre); without them
+// only dX1 is written, which is all the input-gradient stages (_scatter with dx01, _dx) need.
+template <bool POS16, bool ROWS>
 __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                              const float* __restrict__ draw4, BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -536,16 +538,18 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
         // ---- stage X1 (emb part inside the forward; pos/cin after the forward has used them)
         float* x1row = ws.x1 + p * LD_X1;
         Mlp m;
-        mlp_forward_123<true, POS16>(f, x, wl, lane, e, m, x1row, valid);    // stages emb and pos itself
-        if (valid) {
+        mlp_forward_123<ROWS, POS16>(f, x, wl, lane, e, m, x1row, valid);    // stages emb and pos itself
+        if (ROWS && valid) {
             st4(x1row, 80, e.cin, 0.f, 0.f, 0.f);
             st4(x1row, 84, 0.f, 0.f, 0.f, 0.f); st4(x1row, 88, 0.f, 0.f, 0.f, 0.f); st4(x1row, 92, 0.f, 0.f, 0.f, 0.f);
         }
         const unsigned mask1 = positive_mask(m.h1[0], m.h1[1]);
         const unsigned mask3 = positive_mask(m.h3[0], m.h3[1]);
-        store_tiles_as_rows(m.h1[0], m.h1[1], ws.h1 + p * LD_H, 0, true, valid);
-        store_tiles_as_rows(m.h3[0], m.h3[1], ws.h3 + p * LD_H, 0, true, valid);
-        {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
+        if (ROWS) {
+            store_tiles_as_rows(m.h1[0], m.h1[1], ws.h1 + p * LD_H, 0, true, valid);
+            store_tiles_as_rows(m.h3[0], m.h3[1], ws.h3 + p * LD_H, 0, true, valid);
+        }
+        if (ROWS) {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
             float o[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             d3[0][r] = ((mask3 >> r) & 1u) ? d3[0][r] : 0.f;
             d3[1][r] = ((mask3 >> (16 + r)) & 1u) ? d3[1][r] : 0.f;
         }
-        store_tiles_as_rows(d3[0], d3[1], ws.dh3 + p * LD_H, 0, false, valid);
+        if (ROWS) store_tiles_as_rows(d3[0], d3[1], ws.dh3 + p * LD_H, 0, false, valid);
 
         // ---- dX3 = W3^T dH3pre, M-tile 1 first (rows 32..63: d_pos[32..47], d_geo[0..14], d_ex_r)
         f32x16 gx1[2] = {zero16(), zero16()};
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             d1[0][r] = ((mask1 >> r) & 1u) ? d1[0][r] : 0.f;
             d1[1][r] = ((mask1 >> (16 + r)) & 1u) ? d1[1][r] : 0.f;
         }
-        store_tiles_as_rows(d1[0], d1[1], ws.dh1 + p * LD_H, 0, false, valid);
+        if (ROWS) store_tiles_as_rows(d1[0], d1[1], ws.dh1 + p * LD_H, 0, false, valid);
         // own-point rows of gx1: rows q=0..15 -> d_pos[32..47] (colour path), q=16..30 -> d_geo, q=31 -> d_ex_r
         float gq[32];
 #pragma unroll
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             swap32(a, b);
             gq[krow(r, 0)] = a; gq[krow(r, 1)] = b;
         }
-        if (valid) {
+        if (ROWS && valid) {
             float* yrow = ws.dy2 + p * LD_DY2;
             st4(yrow, 0, dr.w, gq[16], gq[17], gq[18]); st4(yrow, 4, gq[19], gq[20], gq[21], gq[22]);
             st4(yrow, 8, gq[23], gq[24], gq[25], gq[26]); st4(yrow, 12, gq[27], gq[28], gq[29], gq[30]);
@@ -963,8 +967,8 @@ size_t rfx_field_backward_workspace_bytes(int64_t n) {
 }
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
-int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
-                             void* workspace, size_t workspace_bytes, rfx_stream stream) {
+static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
+                                 size_t workspace_bytes, rfx_stream stream, bool rows) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
@@ -976,18 +980,34 @@ int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t 
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
     static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
     if (!attr_set) {
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true>),
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false>),
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (k.pos_fp16)
-        hipLaunchKernelGGL(field_backward_kernel<true>, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
-    else
-        hipLaunchKernelGGL(field_backward_kernel<false>, dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
+    const dim3 grid(wave_grid(n, 256 * 2)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (k.pos_fp16 && rows)       hipLaunchKernelGGL((field_backward_kernel<true, true>), grid, block, lds, st, k, x01, n, draw4, ws);
+    else if (k.pos_fp16)          hipLaunchKernelGGL((field_backward_kernel<true, false>), grid, block, lds, st, k, x01, n, draw4, ws);
+    else if (rows)                hipLaunchKernelGGL((field_backward_kernel<false, true>), grid, block, lds, st, k, x01, n, draw4, ws);
+    else                          hipLaunchKernelGGL((field_backward_kernel<false, false>), grid, block, lds, st, k, x01, n, draw4, ws);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                             void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true);
+}
+
+int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                    void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, false);
 }
 
 int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
