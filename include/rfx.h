@@ -407,6 +407,25 @@ size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total,
 /* workspace: dev, 256-byte aligned, >= rfx_ba_workspace_bytes(n_kf_samples + n_cur, S, tv_P, L*F, L). */
 int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream);
 
+/* ---- optimizer step (M1) ------------------------------------------------------------------------------------
+ * torch.optim.Adam as the reference builds it (mp_slam/slam.py:271-286; betas (0.9, 0.99), per-group lr / eps /
+ * L2 weight decay, no amsgrad) and steps it (mp_slam/mapper.py:416-418, 497-499): all tensors of one optimizer in
+ * one launch.  The caller keeps the state (exp_avg, exp_avg_sq, step count) and passes the step-dependent scalars:
+ *   neg_step_size = -lr / (1 - beta1^step), bias_correction2_sqrt = sqrt(1 - beta2^step).                          */
+#define RFX_ADAM_MAX_TENSORS 16
+typedef struct rfx_adam_tensor {
+    float*       param;                 /* dev [n], updated in place                                         */
+    const float* grad;                  /* dev [n]                                                           */
+    float*       exp_avg;               /* dev [n]                                                           */
+    float*       exp_avg_sq;            /* dev [n]                                                           */
+    int64_t      n;
+    float        beta1, beta2, one_minus_beta1, one_minus_beta2;
+    float        eps, weight_decay, neg_step_size, bias_correction2_sqrt;
+} rfx_adam_tensor;
+size_t rfx_adam_tensor_bytes(void);      /* sizeof(rfx_adam_tensor), for foreign bindings                     */
+/* tensors: host array of `count` <= RFX_ADAM_MAX_TENSORS descriptors (read before the call returns). */
+int rfx_adam_step(const rfx_adam_tensor* tensors, int count, rfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,15 @@ class SamplerDesc(C.Structure):
                 ("n_range_d", C.c_int32), ("n_samples_d", C.c_int32), ("perturb", C.c_float)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("neg_step_size", C.c_float), ("bias_correction2_sqrt", C.c_float)]
+
+
+ADAM_MAX_TENSORS = 16
+
+
 class BaDesc(C.Structure):
     _fields_ = [("field", FieldDesc), ("sampler", SamplerDesc), ("bbox", C.c_double * 6), ("bbox_f64", C.c_int32),
                 ("sc_factor", C.c_float), ("depth_trunc", C.c_float), ("trunc", C.c_float), ("rgb_missing_on", C.c_int32),
@@ -113,6 +122,8 @@ PROTOTYPES = {
     "rfx_gather_rays": (_i, [_P, _l, _l, _P, _i, _P, _l, _l, _l, C.c_uint64, C.c_uint64, _P, _i, _P, _P, _P, _P, _P, _P, _P]),
     "rfx_pose_grad": (_i, [_P, _P, _P, _P, _l, _i, _P, _P]),
     "rfx_ba_desc_bytes": (C.c_size_t, []),
+    "rfx_adam_tensor_bytes": (C.c_size_t, []),
+    "rfx_adam_step": (_i, [C.POINTER(AdamTensor), C.c_int, _P]),
     "rfx_ba_workspace_bytes": (C.c_size_t, [_l, _i, _i, _i, _i]),
     "rfx_ba_forward_backward": (_i, [C.POINTER(BaDesc), _P, C.c_size_t, _P]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),
@@ -143,6 +154,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.rfx_abi_version() != 1:
         raise RfxError("librfx.so ABI version mismatch")
+    if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
+        raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")
     if lib.rfx_ba_desc_bytes() != C.sizeof(BaDesc):
         raise RfxError("rfx_ba_desc layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
     _lib = lib

@@ -15,7 +15,7 @@ from typing import List
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librfx.so")
-SOURCES = ["rfx_tsdf.hip", "rfx_field.hip", "rfx_render.hip", "rfx_tracker.hip", "rfx_mesh.hip", "rfx_pose.hip", "rfx_ba.hip"]
+SOURCES = ["rfx_tsdf.hip", "rfx_field.hip", "rfx_render.hip", "rfx_tracker.hip", "rfx_mesh.hip", "rfx_pose.hip", "rfx_ba.hip", "rfx_optim.hip"]
 HEADERS = ["rfx_common.h", "rfx_field_device.h", "rfx_field_mlp.h", os.path.join("..", "..", "include", "rfx.h")]
 
 FLAGS = [

@@ -203,11 +203,15 @@ class SLAM:
             {"params": list(self.model.embed_res_fn.parameters()), "eps": 1e-15, "lr": m["lr_embed_res"]},
         ]
         rba = [{"params": list(self.model.rba.parameters()), "weight_decay": 1e-6, "eps": 1e-15, "lr": m["lr_pose"]}]
-        # same Adam as the reference (torch.optim.Adam, betas (0.9, 0.99)); on the device the single-kernel
-        # implementation is selected (one launch per step instead of ~10 foreach passes over the hash table)
-        fused = all(p.is_cuda for g in trainable + rba for p in g["params"]) if self.config["mapping"].get("fused_adam", True) else False
-        self.map_optimizer = optim.Adam(trainable, betas=(0.9, 0.99), fused=fused)
-        self.rba_optimizer = optim.Adam(rba, betas=(0.9, 0.99), fused=fused)
+        # same Adam as the reference (torch.optim.Adam, betas (0.9, 0.99)); on the device its step is one librfx launch
+        # over all tensors of the optimizer (remixfusion_amd/optim.py); mapping.fused_adam=False keeps torch's own step
+        if self.config["mapping"].get("fused_adam", True) and all(p.is_cuda for g in trainable + rba for p in g["params"]):
+            from ..optim import Adam
+            self.map_optimizer = Adam(trainable, betas=(0.9, 0.99))
+            self.rba_optimizer = Adam(rba, betas=(0.9, 0.99))
+        else:
+            self.map_optimizer = optim.Adam(trainable, betas=(0.9, 0.99))
+            self.rba_optimizer = optim.Adam(rba, betas=(0.9, 0.99))
 
     @torch.no_grad()
     # ---- mesh export (reference slam.py:348-414; marching cubes runs on the device, see mesh.py)
