@@ -24,12 +24,15 @@ from .._lib import check, stream_ptr
 
 
 class _Buffers:
-    """device buffers of one iteration for a given (rays, samples, lattice, cameras) shape + their pointers."""
+    """device buffers of one iteration, sized for UP TO n rays and K cameras, + their pointers.  The ray count of an
+    iteration shrinks as keyframes accumulate (sample // num_kf current-frame rays) and the camera count grows:
+    allocating per shape would hit the allocator (hundreds of MB of workspace) on every mapper step."""
 
     def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K):
         f32 = dict(dtype=torch.float32, device=dev)
         t = self.t = SimpleNamespace()
-        t.u = torch.empty((n, S), **f32)
+        self.cap_n, self.cap_K, self._u_views = n, K, {}
+        t.u = torch.empty(n * S, **f32)
         t.u6 = torch.empty(6, **f32)
         t.lc = torch.empty(8, **f32)
         t.tv_acc = torch.empty(1, dtype=torch.float64, device=dev)
@@ -50,46 +53,69 @@ class _Buffers:
         self.p.ws = (self.p.ws + 255) // 256 * 256           # the library wants a 256-byte aligned workspace
         self.n, self.S, self.P = n, S, P
 
+    def u_view(self, n):
+        """[n, S] prefix of the jitter buffer: uniform_() on it makes the draw torch.rand((n, S)) makes"""
+        v = self._u_views.get(n)
+        if v is None:
+            v = self._u_views[n] = self.t.u[:n * self.S].view(n, self.S)
+        return v
+
 
 class _StageBuffers:
-    """buffers of the stage-by-stage issue (every intermediate is a torch tensor the host can look at)."""
+    """buffers of the stage-by-stage issue (every intermediate is a torch tensor the host can look at): views of one
+    arena sized for up to cap_n rays / cap_K cameras, re-bound when the shape of the iteration changes."""
 
-    def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K):
+    def __init__(self, lib, dev, cap_n, S, P, n_feat, n_levels, table, weights, cap_K):
+        self.lib, self.dev, self.cap_n, self.cap_K = lib, dev, cap_n, cap_K
+        self.S, self.P, self.n_feat, self.n_levels = S, P, n_feat, n_levels
         f32 = dict(dtype=torch.float32, device=dev)
-        t = self.t = SimpleNamespace()
-        t.o, t.d, t.tgt, t.d_cam = (torch.empty((n, 3), **f32) for _ in range(4))
-        t.td = torch.empty(n, **f32)
-        t.pidx = torch.empty(n, dtype=torch.int32, device=dev)
-        t.u = torch.empty((n, S), **f32)
-        t.z = torch.empty((n, S), **f32)
-        t.x01 = torch.empty((n * S, 3), **f32)
-        t.raw = torch.empty((n * S, 4), **f32)
-        t.rgb_map, t.depth_map = torch.empty((n, 3), **f32), torch.empty(n, **f32)
-        t.sums = torch.empty(8, dtype=torch.float64, device=dev)
-        t.lc = torch.empty(8, **f32)
-        t.u6 = torch.empty(6, **f32)
-        t.pts = torch.empty((P * P * P, 3), **f32)
-        t.feat = torch.empty((P * P * P, n_feat), **f32)
-        t.tv_acc = torch.empty(1, dtype=torch.float64, device=dev)
-        t.d_raw = torch.empty((n * S, 4), **f32)
-        t.dx = torch.empty((n * S, 3), **f32)
-        t.dfeat = torch.empty((P * P * P, n_feat), **f32)
-        t.ws2 = torch.empty(int(lib.rfx_grid_encode_backward_workspace_bytes(n * S + P * P * P, n_levels)) // 4, **f32)
-        t.dt = torch.empty_like(table)
-        t.dw_flat = torch.empty(sum(w.numel() for w in weights), **f32)
-        t.ones = torch.ones(1, **f32)
+        self.arena = torch.empty(sum(-(-fl // 64) * 64 for _, _, _, fl in self._layout(cap_n, cap_K)), **f32)
+        self.dt = torch.empty_like(table)
+        self.dw_flat = torch.empty(sum(w.numel() for w in weights), **f32)
+        self.ones = torch.ones(1, **f32)
         self.dws, off = [], 0
         for w in weights:
-            self.dws.append(t.dw_flat[off:off + w.numel()].view_as(w))
+            self.dws.append(self.dw_flat[off:off + w.numel()].view_as(w))
             off += w.numel()
+        self.shape = None
+        self.bind(cap_n, cap_K)
+
+    def _layout(self, n, K):
+        """(name, shape, dtype, fp32 words)"""
+        S, nt, F = self.S, self.P ** 3, self.n_feat
+        f, i32, f64 = torch.float32, torch.int32, torch.float64
+        lay = [("o", (n, 3), f), ("d", (n, 3), f), ("tgt", (n, 3), f), ("d_cam", (n, 3), f), ("td", (n,), f), ("pidx", (n,), i32),
+               ("u", (n, S), f), ("z", (n, S), f), ("x01", (n * S, 3), f), ("raw", (n * S, 4), f), ("rgb_map", (n, 3), f),
+               ("depth_map", (n,), f), ("sums", (8,), f64), ("lc", (8,), f), ("u6", (6,), f), ("pts", (nt, 3), f), ("feat", (nt, F), f),
+               ("tv_acc", (1,), f64), ("d_raw", (n * S, 4), f), ("dx", (n * S, 3), f), ("dfeat", (nt, F), f),
+               ("ws2", (int(self.lib.rfx_grid_encode_backward_workspace_bytes(n * S + nt, self.n_levels)) // 4,), f)]
         if K:
-            t.poses = torch.empty((K, 4, 4), **f32)
-            t.acts = torch.empty(int(lib.rfx_rba_acts_floats(K)), **f32)
-            t.dposes = torch.empty((K, 4, 4), **f32)
-            t.wsr = torch.empty(int(lib.rfx_rba_grads_floats(K)), **f32)
+            lay += [("poses", (K, 4, 4), f), ("acts", (int(self.lib.rfx_rba_acts_floats(K)),), f), ("dposes", (K, 4, 4), f),
+                    ("wsr", (int(self.lib.rfx_rba_grads_floats(K)),), f)]
+        out = []
+        for name, shape, dt in lay:
+            numel = 1
+            for v in shape:
+                numel *= v
+            out.append((name, shape, dt, numel * (2 if dt == f64 else 1)))
+        return out
+
+    def bind(self, n, K):
+        if self.shape == (n, K):
+            return self
+        assert n <= self.cap_n and K <= self.cap_K
+        t = self.t = SimpleNamespace()
+        off = 0
+        for name, shape, dt, fl in self._layout(n, K):
+            chunk = self.arena[off:off + fl]
+            setattr(t, name, (chunk if dt == torch.float32 else chunk.view(dt)).view(shape))
+            off += -(-fl // 64) * 64
+        t.dt, t.dw_flat, t.ones = self.dt, self.dw_flat, self.ones
         self.p = SimpleNamespace(**{k: v.data_ptr() for k, v in vars(t).items()})
         self.p.dws = [g.data_ptr() for g in self.dws]
         self.ws2_bytes = t.ws2.numel() * 4
+        self.shape = (n, K)
+        return self
 
 
 class DirectIterations:
@@ -119,14 +145,20 @@ class DirectIterations:
         tr = self.model.config["training"]
         enc = self.model.embed_res_fn
         S, P = int(tr["n_range_d"]) + int(tr["n_samples_d"]), int(tr["smooth_pts"]) - 1
-        key = (n, S, P, K, str(dev), enc.params.data_ptr())
+        key = (S, P, str(dev), enc.params.data_ptr())
         b = self._cache.get(key)
-        if b is None:
-            if len(self._cache) > 8:            # shapes change with the number of keyframes: keep the cache small
-                self._cache.clear()
-            b = self._cache[key] = _Buffers(self.lib, dev, n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                            self.model.decoder_res.fused_weights(), K)
+        if b is None or b.cap_n < n or b.cap_K < K:
+            cap_n, cap_K = self._capacity(n, K, b)
+            b = self._cache[key] = _Buffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
+                                            self.model.decoder_res.fused_weights(), cap_K)
+        b.n = n
         return b
+
+    def _capacity(self, n, K, old):
+        """most rays an iteration can have (one keyframe: sample + sample current-frame rays) and all cameras"""
+        m = self.mp.config["mapping"]
+        return (max(n, int(m["sample"]) + max(int(m["sample"]), int(m["min_pixels_cur"])), old.cap_n if old else 0),
+                max(K, int(self.model.rba.num_cams) + 1, old.cap_K if old else 0))
 
     def _n_rays(self):
         m = self.mp.config["mapping"]
@@ -139,6 +171,7 @@ class DirectIterations:
         tr, m = cfg["training"], cfg["mapping"]
         t, p = B.t, B.p
         dev = t.u.device
+        n = B.n
         d = _lib.BaDesc()
         d.field = model._field_desc(clamp)
         d.sampler = model._sampler_desc()
@@ -157,7 +190,7 @@ class DirectIterations:
         d.seed_kf, d.seed_cur = random.getrandbits(64), random.getrandbits(64)     # same draw order as the autograd path
         d.poses16, d.K = poses_ptr, K
         if tr["perturb"] > 0.0:
-            t.u.uniform_()                               # the draw torch.rand((n, S)) makes
+            B.u_view(n).uniform_()                       # the draw torch.rand((n, S)) makes
             d.u_z = p.u
         t.u6.uniform_()                                   # the draw torch.rand(6) makes
         d.u6 = p.u6
@@ -251,11 +284,13 @@ class DirectIterations:
         enc = self.model.embed_res_fn
         n = self._n_rays()
         S, P = int(tr["n_range_d"]) + int(tr["n_samples_d"]), int(tr["smooth_pts"]) - 1
-        key = ("stage", n, S, P, K, str(dev), enc.params.data_ptr())
+        key = ("stage", S, P, str(dev), enc.params.data_ptr())
         B = self._cache.get(key)
-        if B is None:
-            B = self._cache[key] = _StageBuffers(self.lib, dev, n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                                 self.model.decoder_res.fused_weights(), K)
+        if B is None or B.cap_n < n or B.cap_K < K:
+            cap_n, cap_K = self._capacity(n, K, B)
+            B = self._cache[key] = _StageBuffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
+                                                 self.model.decoder_res.fused_weights(), cap_K)
+        B.bind(n, K)
         self._rays(B, current_rays, poses_ptr, K, st)
         go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st, map_grads)
         return B, go, gd

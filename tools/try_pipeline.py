@@ -19,8 +19,10 @@ torch.cuda.synchronize(); print("first frame mapping s", round(time.time() - t0,
 t0 = time.time()
 for i in range(1, nf):
     pipe.step(i, frames[i])
+host = time.time() - t0
 torch.cuda.synchronize()
 dt = time.time() - t0
+print(f"host enqueue {host:.3f}s of {dt:.3f}s (GPU trailing {dt - host:.3f}s)")
 print(f"{nf - 1} frames in {dt:.3f}s -> {(nf - 1) / dt:.1f} fps; mapping_idx {int(pipe.slam.mapping_idx[0]) if pipe.slam else None}")
 if pipe.slam is None:
     print("tsdf-only: updated voxels", int((pipe.mv.weight_vol_gpu > 0).sum())); sys.exit(0)
