@@ -334,7 +334,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
-                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel",)),
+                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel<true, true>", "rfx::field_backward_kernel<false, true>")),
                         ("field_backward_weights", ("rfx::field_dw_partial_kernel", "rfx::field_dw_reduce_kernel")),
                         ("render_rays", ("rfx::render_rays_kernel",)), ("tsdf_integrate", ("rfx::mv_integrate_kernel", "rfx::mv_prepass_kernel"))):
             keys = [k for k in pmc if any(kn in k for kn in kns)]

@@ -8,8 +8,8 @@ handed to the (PyTorch) optimizers here.  Same kernels, same order, same random 
 ``Mapper.global_mapping / global_pose``: what is gone is the graph bookkeeping (four Function nodes, the engine's
 worker thread, AccumulateGrad) and ~20 foreign calls per iteration; the TV term's hash gradient is scattered
 together with the field's (one sweep over the table).  ``tests/test_pose_gpu.py`` checks both formulations give the
-same gradients.  Nothing is pruned: the pose phase still produces the (unused) map gradients the reference's
-backward produces.
+same gradients.  The pose phase computes the map gradients that the reference's backward also produces there, and
+that no optimizer consumes, only with ``mapping.unused_gradients``.
 """
 from __future__ import annotations
 
