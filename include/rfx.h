@@ -370,7 +370,8 @@ int rfx_rba_backward(const rfx_rba_params* p, const float* acts, int64_t K, cons
  * -> rfx_mapping_loss_backward -> rfx_field_backward_chain/_weights[/_scatter(dx)/_dx -> ray gradients -> rfx_pose_grad]
  * -> rfx_tv_backward -> rfx_field_backward_scatter_merged.  Optimizers and random draws stay with the caller. */
 typedef struct rfx_ba_desc {
-    rfx_field_desc   field;             /* clamp mode of this phase; `staged` current                       */
+    rfx_field_desc   field;             /* clamp mode of this phase; `staged`, if set, is refreshed from     */
+                                        /* w1..w4 at the start of the call (rfx_field_stage_weights)         */
     rfx_sampler_desc sampler;
     double        bbox[6];
     int32_t       bbox_f64;

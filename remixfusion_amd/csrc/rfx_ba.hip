@@ -103,6 +103,8 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const BaWs w = carve_ba(workspace, n, S, P, L * F, L);
     hipStream_t st = as_stream(stream);
     const int64_t nS = n * S, nt = (int64_t)P * P * P;
+    // ---- decoder weights -> MFMA operand image (the optimizers update the weights in place between calls)
+    if (b->field.staged) RFX_TRY(rfx_field_stage_weights(&b->field, const_cast<float*>(b->field.staged), stream));
     // ---- ray batch
     RFX_TRY(rfx_gather_rays(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                             b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, w.o, w.d, w.tgt, w.td, w.d_cam,

@@ -122,7 +122,10 @@ class DirectIterations:
     def __init__(self, mapper):
         self.mp, self.model, self.slam = mapper, mapper.model, mapper.slam
         self.lib = _lib.load()
-        self._cache = {}
+        self._cache, self._descs = {}, {}
+        self._weights = tuple(self.model.decoder_res.fused_weights())          # the Parameters themselves: stable objects
+        self._rba_params = [w for m in self.model.rba._linears() for w in (m.weight, m.bias)]
+        self._rba_grads = None
         self.stagewise_every = 0        # bench.py: issue every k-th iteration stage by stage (timed per entry point)
         # mapping.unused_gradients: also compute, in the pose phase, the map gradients that no optimizer consumes
         # (what the reference's loss.backward() does); off by default, results are identical either way
@@ -150,7 +153,7 @@ class DirectIterations:
         if b is None or b.cap_n < n or b.cap_K < K:
             cap_n, cap_K = self._capacity(n, K, b)
             b = self._cache[key] = _Buffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                            self.model.decoder_res.fused_weights(), cap_K)
+                                            self._weights, cap_K)
         b.n = n
         return b
 
@@ -164,42 +167,58 @@ class DirectIterations:
         m = self.mp.config["mapping"]
         return int(m["sample"]) + int(max(m["sample"] // len(self.mp.keyframe.frame_ids), m["min_pixels_cur"]))
 
-    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True):
-        """fill the descriptor of this iteration and launch it (forward + backward)."""
-        lib, model, mp = self.lib, self.model, self.mp
+    def _descriptor(self, B, clamp, dev):
+        """rfx_ba_desc of one phase with everything that does not change between iterations filled in; rebuilt when a
+        tensor it points to is re-allocated."""
+        model, mp = self.model, self.mp
+        enc, kf = model.embed_res_fn, mp.keyframe
+        ws = self._weights
+        key = (id(B), enc.params.data_ptr(), ws[0].data_ptr(), ws[3].data_ptr(), model.GBV.params.data_ptr(), kf.rays.data_ptr(),
+               kf.frame_ids_dev.data_ptr())
+        c = self._descs.get(clamp)
+        if c is not None and c[0] == key:
+            return c[1]
         cfg = model.config
         tr, m = cfg["training"], cfg["mapping"]
-        t, p = B.t, B.p
-        dev = t.u.device
-        n = B.n
         d = _lib.BaDesc()
-        d.field = model._field_desc(clamp)
+        d.field = model._field_desc(clamp)              # .staged set: rfx_ba_forward_backward refreshes the image itself
         d.sampler = model._sampler_desc()
         d.bbox, d.bbox_f64 = model._bbox6, model._bbox_f64
         d.sc_factor, d.depth_trunc, d.trunc = float(cfg["data"]["sc_factor"]), float(cfg["cam"]["depth_trunc"]), float(tr["trunc"])
         d.rgb_missing_on = int(tr["rgb_missing"] > 0)
-        d.loss_w_dev = model._loss_weights(dev).data_ptr()
         d.tv_P, d.tv_voxel, d.tv_margin = B.P, float(tr["smooth_vox"]), float(tr["smooth_margin"])
         d.tv_scale = float(tr["smooth_weight"]) / float(int(tr["smooth_pts"]) ** 3)
         d.tv_normalise = 1 if cfg["grid"]["tcnn_encoding"] else 0
-        kf = mp.keyframe
-        d.kf_rays, d.rays_per_kf, d.num_kf = kf.rays.data_ptr(), kf.num_rays_to_save, len(kf)
+        d.kf_rays, d.rays_per_kf = kf.rays.data_ptr(), kf.num_rays_to_save
         d.kf_frame_ids, d.keyframe_every = kf.frame_ids_dev.data_ptr(), int(m["keyframe_every"])
+        d.n_kf_samples = int(m["sample"])
+        d.u6, d.losses8 = B.p.u6, B.p.lc
+        d.hash_entries = enc.params.numel() // int(enc.desc.n_feat)
+        self._descs[clamp] = (key, d, C.byref(d))
+        self._perturb = tr["perturb"] > 0.0
+        return d
+
+    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True):
+        """fill in what changes per iteration and launch it (forward + backward)."""
+        t, p = B.t, B.p
+        n = B.n
+        d = self._descriptor(B, clamp, t.u.device)
+        d.loss_w_dev = self.model._loss_weights(t.u.device).data_ptr()
+        d.num_kf = len(self.mp.keyframe)
         d.cur_rays, d.cur_population = current_rays.data_ptr(), current_rays.shape[0]
-        d.n_kf_samples, d.n_cur = int(m["sample"]), B.n - int(m["sample"])
+        d.n_cur = n - d.n_kf_samples
         d.seed_kf, d.seed_cur = random.getrandbits(64), random.getrandbits(64)     # same draw order as the autograd path
         d.poses16, d.K = poses_ptr, K
-        if tr["perturb"] > 0.0:
+        if self._perturb:
             B.u_view(n).uniform_()                       # the draw torch.rand((n, S)) makes
             d.u_z = p.u
         t.u6.uniform_()                                   # the draw torch.rand(6) makes
-        d.u6 = p.u6
-        enc = model.embed_res_fn
-        d.hash_entries = enc.params.numel() // int(enc.desc.n_feat)
-        d.d_hash, d.d_w, d.d_poses16, d.losses8, d.tv_sum = p.dt, p.dw_flat, d_poses_ptr, p.lc, p.tv_acc
-        if not map_grads:               # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
+        d.d_poses16 = d_poses_ptr
+        if map_grads:
+            d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, p.tv_acc
+        else:                           # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
             d.d_hash = d.d_w = d.tv_sum = None
-        check(lib.rfx_ba_forward_backward(C.byref(d), p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
+        check(self.lib.rfx_ba_forward_backward(self._descs[clamp][2], p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
 
     # ------------------------------------------------------------------ stage-by-stage issue (instrumentation / cross-check)
     # The same iteration as rfx_ba_forward_backward, one foreign call per stage, so that bench.py can put HIP events
@@ -289,7 +308,7 @@ class DirectIterations:
         if B is None or B.cap_n < n or B.cap_K < K:
             cap_n, cap_K = self._capacity(n, K, B)
             B = self._cache[key] = _StageBuffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                                 self.model.decoder_res.fused_weights(), cap_K)
+                                                 self._weights, cap_K)
         B.bind(n, K)
         self._rays(B, current_rays, poses_ptr, K, st)
         go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st, map_grads)
@@ -297,7 +316,7 @@ class DirectIterations:
 
     def _set_map_grads(self, B):
         self.model.embed_res_fn.params.grad = B.t.dt
-        for prm, g in zip(self.model.decoder_res.fused_weights(), B.dws):
+        for prm, g in zip(self._weights, B.dws):
             prm.grad = g
 
     # ------------------------------------------------------------------ the two phases
@@ -317,17 +336,23 @@ class DirectIterations:
         """one trip of the loop of Mapper.global_mapping (map parameters step; poses fixed)."""
         lc = self.map_gradients(current_rays, poses_all)
         self.mp.map_optimizer.step()
-        self.mp.map_optimizer.zero_grad()
-        self.mp.rba_optimizer.zero_grad()
+        self._drop_grads()
         return lc
 
     def pose_iteration(self, current_rays, idx):
         """one trip of the loop of Mapper.global_pose with opt_pose: poses = RBA(idx), pose-MLP step."""
         lc = self.pose_gradients(current_rays, idx, map_grads=self.unused_gradients)
         self.mp.rba_optimizer.step()
-        self.mp.map_optimizer.zero_grad()
-        self.mp.rba_optimizer.zero_grad()
+        self._drop_grads()
         return lc
+
+    def _drop_grads(self):
+        """map_optimizer.zero_grad() + rba_optimizer.zero_grad() (set_to_none) for the parameters these iterations touch"""
+        self.model.embed_res_fn.params.grad = None
+        for w in self._weights:
+            w.grad = None
+        for w in self._rba_params:
+            w.grad = None
 
     def pose_gradients(self, current_rays, idx, map_grads=True):
         """forward + backward of one global_pose iteration: pose-MLP (and, with map_grads, map) gradients in .grad.
@@ -341,8 +366,12 @@ class DirectIterations:
         st = stream_ptr(dev)
         R = self._buffers(self._n_rays(), K, dev)     # owns the RBA buffers in both modes
         p = R.p
-        params = [w for m in rba._linears() for w in (m.weight, m.bias)]
-        prm = _lib.RbaParams(*[w.data_ptr() for w in params], 256)
+        params = self._rba_params
+        if self._rba_grads is None or self._rba_grads[0] != params[0].data_ptr():
+            grads = [torch.empty_like(w) for w in params]      # overwritten by every rfx_rba_backward
+            self._rba_grads = (params[0].data_ptr(), grads, _lib.RbaParams(*[w.data_ptr() for w in params], 256),
+                               _lib.RbaGrads(*[g.data_ptr() for g in grads]))
+        _, grads, prm, gdesc = self._rba_grads
         check(lib.rfx_rba_forward(C.byref(prm), rba.init_r.data_ptr(), rba.init_t.data_ptr(), idx.data_ptr(), K, rba.num_cams,
                                   float(rba.scale), p.poses, p.acts, st), "rfx_rba_forward")
         if self._stagewise_now():
@@ -353,8 +382,6 @@ class DirectIterations:
             self._run(B, current_rays, p.poses, K, True, p.dposes, st, map_grads)
         if map_grads:
             self._set_map_grads(B)                   # produced by the reference's backward too; no optimizer consumes them
-        grads = [torch.empty_like(w) for w in params]
-        gdesc = _lib.RbaGrads(*[g.data_ptr() for g in grads])
         check(lib.rfx_rba_backward(C.byref(prm), p.acts, K, p.dposes, float(rba.scale), C.byref(gdesc), p.wsr, st), "rfx_rba_backward")
         for w, g in zip(params, grads):
             w.grad = g
