@@ -265,7 +265,7 @@ int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const floa
 
 /* TV1: total variation of lattice features feat dev [P,P,P,C] (mp_slam/slam.py:211-215):
  * *sum1 (dev double) = sum of squared forward differences along x, y, z.  Backward writes
- * dfeat = gscale_dev[0] * scale * d(sum)/d feat. */
+ * dfeat = gscale_dev[0] * scale * d(sum)/d feat (gscale_dev NULL: 1). */
 int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream stream);
 int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream);
 /* the lattice itself (mp_slam/slam.py:198-207): pts dev [P^3,3] = ((ijk + u6[3:6]) * voxel + lo + u6[0:3] * offset_max
@@ -401,7 +401,8 @@ typedef struct rfx_ba_desc {
                                          * is then required, and the TV term is evaluated only if tv_sum is given)         */
     float*        d_poses16;            /* out dev [K,16] or NULL (poses fixed: no ray gradients computed)   */
     float*        losses8;              /* out dev [8] or NULL: the four losses, then their coefficients     */
-    double*       tv_sum;               /* out dev [1] or NULL: un-normalised TV sum                         */
+    double*       tv_sum;               /* out dev [1] or NULL: un-normalised TV sum (only its gradient enters the
+                                         * update, so the value is evaluated just when asked for)            */
 } rfx_ba_desc;
 size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign binding verify its mirror of the struct */
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);

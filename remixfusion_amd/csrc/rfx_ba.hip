@@ -67,8 +67,6 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     return w;
 }
 
-__global__ void set_one_kernel(float* p) { p[0] = 1.0f; }
-
 }  // namespace rfx
 
 using namespace rfx;
@@ -115,8 +113,9 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     RFX_TRY(rfx_field_forward(&b->field, w.x01, nS, w.raw, stream));
     RFX_TRY(rfx_composite_forward(w.raw, w.z, n, S, b->trunc, b->sc_factor, w.rgb_map, w.depth_map, nullptr, stream));
     const float trunc_loss = b->trunc * b->sc_factor;
+    float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
     RFX_TRY(rfx_mapping_loss_forward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, trunc_loss, b->depth_trunc, b->rgb_missing_on,
-                                     w.sums, w.lc, w.lc + 4, stream));
+                                     w.sums, lc, lc + 4, stream));
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (map_grads || b->tv_sum) {
         RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
@@ -125,7 +124,7 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     }
     // ---- backward
     RFX_TRY(rfx_mapping_loss_backward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
-                                      b->depth_trunc, b->rgb_missing_on, w.lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
+                                      b->depth_trunc, b->rgb_missing_on, lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
     if (map_grads) RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else RFX_TRY(rfx_field_backward_chain_inputs(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     if (map_grads) {
@@ -143,13 +142,10 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
         RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
     }
     if (map_grads) {
-        hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, st, w.ones);
-        RFX_LAUNCH_CHECK();
-        RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, w.ones, w.dfeat, stream));
+        RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, nullptr, w.dfeat, stream));
         RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
                                                   w.scat_bytes, stream));
     }
-    if (b->losses8) RFX_HIP_TRY(hipMemcpyAsync(b->losses8, w.lc, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return RFX_OK;
 }
 

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void tv_forward_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restrict__ feat, int P, int Cn, float scale,
                                                           const float* __restrict__ gscale, float* __restrict__ dfeat) {
     const int64_t total = (int64_t)P * P * P * Cn;
-    const float k = 2.0f * scale * gscale[0];
+    const float k = 2.0f * scale * (gscale ? gscale[0] : 1.0f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t cell = i / Cn;
         const int z = (int)(cell % P), y = (int)((cell / P) % P), x = (int)(cell / ((int64_t)P * P));
@@ -764,7 +764,7 @@ int rfx_tv_forward(const float* feat, int P, int C, double* sum1, rfx_stream str
 }
 
 int rfx_tv_backward(const float* feat, int P, int C, float scale, const float* gscale_dev, float* dfeat, rfx_stream stream) {
-    if (!feat || !gscale_dev || !dfeat || P <= 0 || C <= 0) return RFX_ERR_ARG;
+    if (!feat || !dfeat || P <= 0 || C <= 0) return RFX_ERR_ARG;
     const int64_t total = (int64_t)P * P * P * C;
     hipLaunchKernelGGL(tv_backward_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0,
                        as_stream(stream), feat, P, C, scale, gscale_dev, dfeat);

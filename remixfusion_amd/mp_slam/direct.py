@@ -130,6 +130,8 @@ class DirectIterations:
         # mapping.unused_gradients: also compute, in the pose phase, the map gradients that no optimizer consumes
         # (what the reference's loss.backward() does); off by default, results are identical either way
         self.unused_gradients = bool(mapper.config["mapping"].get("unused_gradients", False))
+        # the TV value itself (SLAM.smoothness's return) only matters through its gradient: evaluated on request
+        self.report_tv = bool(mapper.config["mapping"].get("report_tv", False))
         self._count = 0
 
     def _stagewise_now(self) -> bool:
@@ -215,7 +217,7 @@ class DirectIterations:
         t.u6.uniform_()                                   # the draw torch.rand(6) makes
         d.d_poses16 = d_poses_ptr
         if map_grads:
-            d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, p.tv_acc
+            d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, (p.tv_acc if self.report_tv else None)
         else:                           # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
             d.d_hash = d.d_w = d.tv_sum = None
         check(self.lib.rfx_ba_forward_backward(self._descs[clamp][2], p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
@@ -268,7 +270,8 @@ class DirectIterations:
             check(lib.rfx_tv_lattice(p.u6, P, float(tr["smooth_vox"]), float(tr["smooth_margin"]), model._bbox6, model._bbox_f64,
                                      1 if cfg["grid"]["tcnn_encoding"] else 0, p.pts, st), "rfx_tv_lattice")
             check(lib.rfx_grid_encode_forward(enc.desc, table_ptr, p.pts, n_tv, p.feat, st), "rfx_grid_encode_forward")
-            check(lib.rfx_tv_forward(p.feat, P, enc.n_output_dims, p.tv_acc, st), "rfx_tv_forward")
+            if self.report_tv:
+                check(lib.rfx_tv_forward(p.feat, P, enc.n_output_dims, p.tv_acc, st), "rfx_tv_forward")
         # ---- backward: d(total)/d(loss_i) = training weights; d(total)/d(TV) = smooth_weight
         wvec = model._loss_weights(dev)
         check(lib.rfx_mapping_loss_backward(p.raw, p.z, p.rgb_map, p.depth_map, p.tgt, p.td, n, S, trunc, sc, trunc * sc, depth_trunc,
