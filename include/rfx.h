@@ -248,9 +248,11 @@ int rfx_composite_backward(const float* raw4, const float* z_vals, int64_t n_ray
                            rfx_stream stream);
 
 /* L1 fused: the four mapping losses of JointEncoding.mapping (model/scene_rep.py:493-527 with
- * model/utils.py:170-256) from raw/z and the rendered maps.  sums8 dev double[8] (scratch),
+ * model/utils.py:170-256) from raw/z and the rendered maps.  sums8 dev double[RFX_LOSS_WS_DOUBLES] (scratch,
+ * need not be initialised: per-block partial sums, added in a fixed order),
  * losses4 dev float[4] = (rgb, depth, sdf, fs), coef4 dev float[4] (kept for the backward).
  * trunc_loss = training.trunc * data.sc_factor; rgb_missing_on = (training.rgb_missing > 0). */
+#define RFX_LOSS_WS_DOUBLES 2048
 int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
                              const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
                              float depth_trunc, int rgb_missing_on, double* sums8, float* losses4, float* coef4,

@@ -43,6 +43,7 @@ class AdamTensor(C.Structure):
 
 
 ADAM_MAX_TENSORS = 16
+LOSS_WS_DOUBLES = 2048      # RFX_LOSS_WS_DOUBLES
 
 
 class BaDesc(C.Structure):

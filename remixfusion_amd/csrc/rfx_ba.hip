@@ -56,7 +56,7 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     w.td = (float*)take(n * 4); w.pidx = (int*)take(n * 4);
     w.z = (float*)take(nS * 4); w.x01 = (float*)take(nS * 12); w.raw = (float*)take(nS * 16);
     w.rgb_map = (float*)take(n * 12); w.depth_map = (float*)take(n * 4);
-    w.sums = (double*)take(8 * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
+    w.sums = (double*)take(RFX_LOSS_WS_DOUBLES * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
     w.pts = (float*)take(nt * 12); w.feat = (float*)take(nt * n_feat * 4); w.dfeat = (float*)take(nt * n_feat * 4);
     w.d_raw = (float*)take(nS * 16); w.dx = (float*)take(nS * 12); w.go = (float*)take(n * 12); w.gd = (float*)take(n * 12);
     w.bwd_bytes = rfx_field_backward_workspace_bytes((int64_t)nS);

@@ -304,24 +304,31 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// sum `v` over the block's 4 waves; result valid in thread 0.  red: 4 doubles of LDS per value.
+// sum `v` over the block's waves (fixed order); result valid in every thread.  red: one double of LDS per wave.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     v = wave_sum_d(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const double r = red[0] + red[1] + red[2] + red[3];
+    double r = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += red[w];
     __syncthreads();
     return r;
 }
 
-__global__ __launch_bounds__(256) void mapping_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
+constexpr int LOSS_BLOCKS = 256, LOSS_THREADS = 256;      // 256 x 8 partial sums = RFX_LOSS_WS_DOUBLES; a ray costs a
+                                                          // wave two dependent memory latencies, so many short waves
+static_assert(LOSS_BLOCKS * 8 == RFX_LOSS_WS_DOUBLES, "loss workspace");
+
+// per-block partial sums, plain stores: no atomics (one address sustains ~90 of them per us), no zero-fill before,
+// and the finalize kernel adds the partials in a fixed order
+__global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
                                                                    const float* __restrict__ zv, const float* __restrict__ rgb_map,
                                                                    const float* __restrict__ depth_map,
                                                                    const float* __restrict__ tgt_rgb, const float* __restrict__ tgt_d,
                                                                    int64_t n_rays, int S, double* __restrict__ sums) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
-    for (int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * 4) {
+    for (int64_t ray = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * wpb) {
         const float d = tgt_d[ray];
         const bool valid = (d > 0.0f) && (d < L.depth_trunc);
         if (lane == 0) {
@@ -346,21 +353,34 @@ __global__ __launch_bounds__(256) void mapping_loss_forward_kernel(LossK L, cons
             }
         }
     }
-    // one atomic per block and value: a single address only sustains ~90 atomics/us
-    __shared__ double red[4];
+    __shared__ double red[LOSS_THREADS / 64];
     a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
     a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
     a_nsdf = block_sum_d(a_nsdf, red);
     if (threadIdx.x == 0) {
-        atomicAdd(sums + 0, a_rgb); atomicAdd(sums + 1, a_dep); atomicAdd(sums + 2, a_val); atomicAdd(sums + 3, a_fs);
-        atomicAdd(sums + 4, a_sdf); atomicAdd(sums + 5, a_nfs); atomicAdd(sums + 6, a_nsdf);
+        double* o = sums + (size_t)blockIdx.x * 8;
+        o[0] = a_rgb; o[1] = a_dep; o[2] = a_val; o[3] = a_fs; o[4] = a_sdf; o[5] = a_nfs; o[6] = a_nsdf; o[7] = 0.0;
     }
 }
 
 // losses[4] = (rgb, depth, sdf, fs) ; coef[4] = d loss_i / d (its squared-error sum)
-__global__ void mapping_loss_finalize_kernel(const double* __restrict__ sums, int64_t n_rays, int S, float* __restrict__ losses,
-                                             float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void mapping_loss_finalize_kernel(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S,
+                                             float* __restrict__ losses, float* __restrict__ coef) {
+    __shared__ double part[32][8], sums[8];
+    {   // thread = (value v, slice q): partials q, q + 32, ... in order, then the 32 slices in order
+        const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
+        double a = 0.0;
+        for (int k = q; k < n_partials; k += 32) a += partial[k * 8 + v];
+        part[q][v] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double a = 0.0;
+        for (int q = 0; q < 32; ++q) a += part[q][threadIdx.x];
+        sums[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double ns = (double)n_rays * (double)S;
     const double tot = sums[5] + sums[6];
     const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
@@ -726,12 +746,12 @@ int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float
     if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums8 || !losses4 || !coef4) return RFX_ERR_ARG;
     if (n_rays < 0 || S <= 0) return RFX_ERR_ARG;
     hipStream_t st = as_stream(stream);
-    RFX_HIP_TRY(hipMemsetAsync(sums8, 0, 8 * sizeof(double), st));
     LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
-    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(std::min(ray_grid(n_rays), 128)), dim3(256), 0, st, L,
+    const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_BLOCKS);
+    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, st, L,
                        reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, sums8);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums8, n_rays, S, losses4, coef4);
+    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(256), 0, st, sums8, blocks, n_rays, S, losses4, coef4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -154,7 +154,7 @@ class _MappingFn(torch.autograd.Function):
         trunc, sc = float(tr["trunc"]), float(cfg["data"]["sc_factor"])
         check(lib.rfx_composite_forward(ptr(raw), ptr(z), n, S, trunc, sc, ptr(rgb_map), ptr(depth_map), None, st),
               "rfx_composite_forward")
-        sums = torch.empty(8, dtype=torch.float64, device=dev)
+        sums = torch.empty(_lib.LOSS_WS_DOUBLES, dtype=torch.float64, device=dev)
         lc = torch.empty(8, dtype=torch.float32, device=dev)            # losses[4] | coef[4]
         check(lib.rfx_mapping_loss_forward(ptr(raw), ptr(z), ptr(rgb_map), ptr(depth_map), ptr(tgt), ptr(td), n, S,
                                            trunc * sc, float(cfg["cam"]["depth_trunc"]), int(tr["rgb_missing"] > 0),

@@ -86,7 +86,7 @@ class _StageBuffers:
         f, i32, f64 = torch.float32, torch.int32, torch.float64
         lay = [("o", (n, 3), f), ("d", (n, 3), f), ("tgt", (n, 3), f), ("d_cam", (n, 3), f), ("td", (n,), f), ("pidx", (n,), i32),
                ("u", (n, S), f), ("z", (n, S), f), ("x01", (n * S, 3), f), ("raw", (n * S, 4), f), ("rgb_map", (n, 3), f),
-               ("depth_map", (n,), f), ("sums", (8,), f64), ("lc", (8,), f), ("u6", (6,), f), ("pts", (nt, 3), f), ("feat", (nt, F), f),
+               ("depth_map", (n,), f), ("sums", (_lib.LOSS_WS_DOUBLES,), f64), ("lc", (8,), f), ("u6", (6,), f), ("pts", (nt, 3), f), ("feat", (nt, F), f),
                ("tv_acc", (1,), f64), ("d_raw", (n * S, 4), f), ("dx", (n * S, 3), f), ("dfeat", (nt, F), f),
                ("ws2", (int(self.lib.rfx_grid_encode_backward_workspace_bytes(n * S + nt, self.n_levels)) // 4,), f)]
         if K:
