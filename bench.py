@@ -225,6 +225,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- V1 alone: in the timed region it runs on its own stream and shares the GPU with the mapper's kernels, which
+    #      stretches its launches; time the same call on an otherwise idle GPU as well (after the timed region)
+    v1_alone_ms = None
+    if getattr(pipe, "mv_stream", None) is not None:
+        f = frames[n_frames - 1]
+        pose_np = f["c2w"].numpy().astype(np.float64)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pipe.mv.integrate(f["rgb255"], f["depth"], pipe.K, pose_np, pipe.mv.vol_bnds)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        v1_alone_ms = float(np.median([a.elapsed_time(b) for a, b in evs[2:]]))
+
     # ---- rays/s of the fused full-frame renderer (second headline number)
     render = None
     if pipe.model is not None and args.render_frames > 0:
@@ -329,6 +346,12 @@ def main():
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                  "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
                                                  "algorithmic_bytes": int(nbytes), "avg_ms": round(ms, 4)}
+            if v1_alone_ms:
+                extra_rooflines["tsdf_integrate"].update({
+                    "note": "avg_ms is measured in the timed region, where V1 runs on its own stream concurrently with the "
+                            "mapper's kernels; *_alone: the same call on an otherwise idle GPU, after the timed region",
+                    "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
+                    "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
     # summarised by tools/summarize_pmc.py into profiles/r1_pmc_traffic.json); raw counter bytes.
     try:
@@ -368,6 +391,7 @@ def main():
                                f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
                                f"{cfg['mapping']['iters']} map + {cfg['mapping']['BA_iters']} pose iters every {cfg['mapping']['map_every']} frames, poses initialised from the ground-truth trajectory and refined by the RBA pose MLP",
                    "unused_gradients": bool(args.unused_gradients),
+                   "streams": "V1 on its own HIP stream, concurrent with the mapper" if getattr(pipe, "mv_stream", None) is not None else "one stream",
                    "note": "pose iterations step only the pose MLP (reference mapper.py:494-499); the map gradients its backward also "
                            "produces and zeroes are computed only with --unused-gradients (same parameters and poses either way)",
                    "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},

@@ -55,6 +55,15 @@ class MappingPipeline:
                                    s.tracking_idx, s.mapping_idx, s.tracking_stop_flag, s.pose_gt, s.update_local_MV,
                                    s.keyframeDatabase.all_fuse_pose, self.device)
             self.mv = self.tracker.RO_Tracker.MV
+        # The moving volume and the residual field touch disjoint memory (the reference runs them in two processes,
+        # run.py:56-60): with ground-truth poses the per-frame V1 (and the volume moves) go on their own HIP stream and
+        # overlap the mapper's iterations, which are latency- rather than bandwidth-bound.  pipeline.mv_stream: False
+        # keeps everything on the current stream.
+        self.mv_stream = None
+        if self.tracker is None and self.slam is not None and self.device.type == "cuda" and \
+                config.get("pipeline", {}).get("mv_stream", True):
+            self.mv_stream = torch.cuda.Stream(device=self.device)
+            self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
         self.frames_done = 0
 
     # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
@@ -66,6 +75,8 @@ class MappingPipeline:
             b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
             b["c2w_dev"] = b["c2w"].to(self.device)     # a pageable H2D copy in the frame loop would drain the stream
             out[i] = b
+        if self.mv_stream is not None:                  # the frames above were produced on the current stream
+            self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))
         return out
 
     def start(self, batch0: Dict, first_iters: Optional[int] = None):
@@ -88,12 +99,14 @@ class MappingPipeline:
             return
         c2w = batch["c2w"]
         pose_np = c2w.numpy().astype(np.float64) if not c2w.is_cuda else c2w.cpu().numpy().astype(np.float64)
-        if i > 0:
-            self.mv.check_move_volume_new(i, pose_np, self.traj, version=self.config["volume"]["version"])
         rgb255 = batch.get("rgb255")
-        if rgb255 is None:
-            rgb255 = torch.floor(batch["rgb"] * 255.0 + 0.5)
-        self.mv.integrate(rgb255, batch["depth"], self.K, pose_np, self.mv.vol_bnds)
+        if self.mv_stream is None:
+            self._integrate(i, batch, rgb255, pose_np)
+        else:
+            if rgb255 is None:                          # not prefetched: the frame was just produced on the current stream
+                self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.mv_stream):
+                self._integrate(i, batch, rgb255, pose_np)
         if self.slam is not None:
             c2w_dev = batch.get("c2w_dev")
             if c2w_dev is None:
@@ -105,6 +118,18 @@ class MappingPipeline:
                 # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop
                 self.slam.est_c2w_data_rel[i] = c2w_dev @ torch.linalg.inv_ex(kf).inverse
             self.slam.tracking_idx[0] = i
+
+    def _integrate(self, i, batch, rgb255, pose_np):
+        if i > 0:
+            self.mv.check_move_volume_new(i, pose_np, self.traj, version=self.config["volume"]["version"])
+        if rgb255 is None:
+            rgb255 = torch.floor(batch["rgb"] * 255.0 + 0.5)
+        self.mv.integrate(rgb255, batch["depth"], self.K, pose_np, self.mv.vol_bnds)
+
+    def sync_volume(self):
+        """make the current stream wait for the moving volume's stream (before reading the volume from it)"""
+        if self.mv_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.mv_stream)
 
     def step(self, i: int, batch: Dict):
         """one frame of the stream: V1 always; mapper step when the reference's loop would fire."""
