@@ -334,3 +334,35 @@ def test_integrate_full_size_800x800x600_bit_exact():
     assert u > 1e6
     for g, r, nm in ((v.w, ow, "weight"), (v.t, ot, "tsdf"), (v.c, oc, "colour")):
         _assert_bit_equal(g.cpu().numpy(), r, nm)
+
+
+def test_pipeline_volume_stream_gives_the_same_volume():
+    """MappingPipeline integrates the moving volume on its own HIP stream, overlapping the mapper (pipeline.mv_stream);
+    the volume after a stretch of frames must be bit-identical to the one-stream run."""
+    import torch
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+
+    def run(side_stream):
+        cfg = synthetic_config("office0")
+        cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+        cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+        cfg["mapping"].update({"first_iters": 5, "sample": 512, "iters": 2, "BA_iters": 2})
+        cfg["training"].update({"smooth_pts": 16})
+        cfg["pipeline"] = {"mv_stream": side_stream}
+        pipe = MappingPipeline(cfg, n_frames=40, seed=1)
+        assert (pipe.mv_stream is not None) == side_stream
+        frames = pipe.prefetch(list(range(31)))
+        pipe.start(frames[0])
+        for i in range(1, 31):
+            pipe.step(i, frames[i])
+        torch.cuda.synchronize()
+        return [v.copy() for v in pipe.mv.get_volume_all()], np.array(pipe.mv.vol_bnds, copy=True)
+
+    (t0, w0, c0), b0 = run(False)
+    (t1, w1, c1), b1 = run(True)
+    assert np.array_equal(b0, b1)
+    assert float((w0 > 0).mean()) > 0.01
+    _assert_bit_equal(t1, t0, "tsdf")
+    _assert_bit_equal(w1, w0, "weight")
+    _assert_bit_equal(c1, c0, "colour")
