@@ -180,7 +180,7 @@ def main():
 
     lib = _lib.load()
     timer = KernelTimer()
-    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_weights",
+    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights", "rfx_field_backward_weights",
                  "rfx_field_backward_scatter", "rfx_field_backward_scatter_merged", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
                  "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
                  "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):
@@ -293,9 +293,11 @@ def main():
 
     if "rfx_field_forward" in summ:
         extra_rooflines["field_forward"] = mfma_roofline("rfx_field_forward", MLP_FLOP_PER_POINT, 2)
-    if "rfx_field_backward_chain" in summ:
-        # recompute-forward + dX chain: 2 x forward FLOPs of algorithmic work (dX); dW is the _weights stage
-        extra_rooflines["field_backward_chain"] = mfma_roofline("rfx_field_backward_chain", MLP_FLOP_PER_POINT, 2)
+    chain_name = next((k for k in ("rfx_field_backward_chain_weights", "rfx_field_backward_chain") if k in summ), None)
+    if chain_name:
+        # recompute-forward + dX chain (the map phase runs the _weights variant: of dX1 only d_emb); counted as one
+        # forward's FLOPs of algorithmic work; dW is the _weights stage
+        extra_rooflines["field_backward_chain"] = mfma_roofline(chain_name, MLP_FLOP_PER_POINT, 2)
     if "rfx_field_backward_weights" in summ:
         extra_rooflines["field_backward_weights"] = mfma_roofline("rfx_field_backward_weights", MLP_FLOP_PER_POINT, 0)
     scat = "rfx_field_backward_scatter_merged" if "rfx_field_backward_scatter_merged" in summ else "rfx_field_backward_scatter"
@@ -357,7 +359,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
-                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel<true, true>", "rfx::field_backward_kernel<false, true>")),
+                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel<true, true, false>", "rfx::field_backward_kernel<false, true, false>")),
                         ("field_backward_weights", ("rfx::field_dw_partial_kernel", "rfx::field_dw_reduce_kernel")),
                         ("render_rays", ("rfx::render_rays_kernel",)), ("tsdf_integrate", ("rfx::mv_integrate_kernel", "rfx::mv_prepass_kernel"))):
             keys = [k for k in pmc if any(kn in k for kn in kns)]
@@ -367,6 +369,7 @@ def main():
     except Exception:
         pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
+           "rfx_field_backward_chain_weights": "field_backward_chain",
            "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
            "rfx_field_backward_scatter_merged": "field_backward_scatter",
            "rfx_tsdf_integrate": "tsdf_integrate"}.get(dominant)

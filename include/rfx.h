@@ -198,6 +198,11 @@ int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t 
  * _scatter (with dx01) and _dx read; _weights and the d_hash part of _scatter must not follow it. */
 int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                                     void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* _chain for callers that want parameter gradients only (map phase: poses fixed): everything _weights reads, and of
+ * dX1 just d_emb, which is all the d_hash part of _scatter(_merged) reads; _dx and the dx01 output of _scatter must
+ * not follow it. */
+int rfx_field_backward_chain_weights(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "rfx_field_backward": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rfx_field_backward_chain": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
     "rfx_field_backward_chain_inputs": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_chain_weights": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
     "rfx_field_backward_weights": (_i, [_l, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rfx_field_backward_scatter": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),
     "rfx_field_backward_dx": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),

@@ -125,7 +125,9 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     // ---- backward
     RFX_TRY(rfx_mapping_loss_backward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
                                       b->depth_trunc, b->rgb_missing_on, lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
-    if (map_grads) RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    // the chain variant that produces exactly what the following stages read
+    if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else RFX_TRY(rfx_field_backward_chain_inputs(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     if (map_grads) {
         RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));

@@ -518,7 +518,9 @@ __device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16&
 // ---------------------------------------------------------------- backward kernel A (MFMA chain)
 // ROWS: also stage the per-point rows the weight-gradient kernel reads (X1, H1, dH1pre, G, dY2, H3, dH3pre); without them
 // only dX1 is written, which is all the input-gradient stages (_scatter with dx01, _dx) need.
-template <bool POS16, bool ROWS>
+// DXFULL: all of dX1 (d_emb, d_pos, d_cin, d_ex_rgb); without it only d_emb (columns 0..31, what the table scatter
+// reads) is computed and stored: two of the three dX1 M-tiles and two dX3 M-tiles of matrix work and 256 B/point less.
+template <bool POS16, bool ROWS, bool DXFULL>
 __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                              const float* __restrict__ draw4, BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             store_tiles_as_rows(t[0], t[1], dxrow, 0, false, valid);
         }
         // ---- d_pos[0..31] = dX1 M-tile 1 + dX3 M-tile 0
-        {
+        if (DXFULL) {
             f32x16 t[2] = {zero16(), zero16()};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
         }
         // ---- dX1 M-tile 2: rows 64..79 = d_pos[32..47] (+ colour path gq[0..15]), row 80 = d_cin
         //      dX3 M-tile 2: rows 64,65 = d_ex_g, d_ex_b
-        {
+        if (DXFULL) {
             f32x16 t[2] = {zero16(), zero16()}, c[2] = {zero16(), zero16()};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -968,7 +970,7 @@ size_t rfx_field_backward_workspace_bytes(int64_t n) {
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
-                                 size_t workspace_bytes, rfx_stream stream, bool rows) {
+                                 size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
@@ -978,36 +980,37 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
     if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
     BwdWs ws = carve(workspace, n);
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
+    using Kern = void (*)(FieldK, const float*, int64_t, const float*, BwdWs);
+    // [pos_fp16][variant]: 0 = rows + full dX1 (_chain), 1 = full dX1 only (_chain_inputs), 2 = rows + d_emb (_chain_weights)
+    static const Kern kern[2][3] = {
+        {field_backward_kernel<false, true, true>, field_backward_kernel<false, false, true>, field_backward_kernel<false, true, false>},
+        {field_backward_kernel<true, true, true>, field_backward_kernel<true, false, true>, field_backward_kernel<true, true, false>}};
     static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
     if (!attr_set) {
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<true, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_backward_kernel<false, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int a = 0; a < 2; ++a)
+            for (int v = 0; v < 3; ++v)
+                RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const dim3 grid(wave_grid(n, 256 * 2)), block(256);
-    hipStream_t st = as_stream(stream);
-    if (k.pos_fp16 && rows)       hipLaunchKernelGGL((field_backward_kernel<true, true>), grid, block, lds, st, k, x01, n, draw4, ws);
-    else if (k.pos_fp16)          hipLaunchKernelGGL((field_backward_kernel<true, false>), grid, block, lds, st, k, x01, n, draw4, ws);
-    else if (rows)                hipLaunchKernelGGL((field_backward_kernel<false, true>), grid, block, lds, st, k, x01, n, draw4, ws);
-    else                          hipLaunchKernelGGL((field_backward_kernel<false, false>), grid, block, lds, st, k, x01, n, draw4, ws);
+    const int variant = rows ? (dxfull ? 0 : 2) : 1;
+    hipLaunchKernelGGL(kern[k.pos_fp16 ? 1 : 0][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
 
 int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                              void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true);
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, true);
 }
 
 int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                                     void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, false);
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, false, true);
+}
+
+int rfx_field_backward_chain_weights(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, false);
 }
 
 int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,

@@ -278,7 +278,8 @@ class DirectIterations:
                                             rgb_on, p.lc + 16, wvec.data_ptr(), None, None, p.d_raw, st), "rfx_mapping_loss_backward")
         ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
         wsp, wb = ws.data_ptr(), ws.numel() * 4
-        chain = lib.rfx_field_backward_chain if map_grads else lib.rfx_field_backward_chain_inputs
+        chain = (lib.rfx_field_backward_chain_inputs if not map_grads else
+                 lib.rfx_field_backward_chain if want_ray_grads else lib.rfx_field_backward_chain_weights)
         check(chain(dref, p.x01, n * S, p.d_raw, wsp, wb, st), "rfx_field_backward_chain")
         if map_grads:
             t.dt.zero_()
