@@ -732,11 +732,13 @@ __global__ __launch_bounds__(256, 2) void field_dw_partial_kernel(BwdWs ws, cons
         a4 = mfma32(dy4, h3, a4);
         (void)gg;
     }
-    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  The four waves of the block are
-    // summed in LDS in a fixed order (wave 0 stores, waves 1..3 add in turn), then the block writes ONE partial.
-    __shared__ float acc[DW_TOTAL];
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wv == turn) {
+    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  The four waves of the block are summed in
+    // LDS in a fixed order -- waves 0 and 1 store into two images, waves 2 and 3 add to them, the write-out adds the two
+    // images -- then the block writes ONE partial.
+    __shared__ float acc2[2][DW_TOTAL];
+    for (int turn = 0; turn < 2; ++turn) {
+        if ((wv >> 1) == turn) {
+            float* acc = acc2[wv & 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = krow(r, h);
@@ -753,19 +755,22 @@ __global__ __launch_bounds__(256, 2) void field_dw_partial_kernel(BwdWs ws, cons
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * DW_TOTAL;
-    for (int i = threadIdx.x; i < DW_TOTAL; i += 256) out[i] = acc[i];
+    for (int i = threadIdx.x; i < DW_TOTAL; i += 256) out[i] = acc2[0][i] + acc2[1][i];
 }
 
-// deterministic second stage: block = 16 consecutive outputs x 16 slices of the partial list
-__global__ __launch_bounds__(256) void field_dw_reduce_kernel(const float* __restrict__ partial, int n_partials,
-                                                              float* __restrict__ dw1, float* __restrict__ dw2,
-                                                              float* __restrict__ dw3, float* __restrict__ dw4) {
-    __shared__ float red[16][16];
-    const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col;
+// deterministic second stage: block = 64 consecutive outputs x 16 slices of the partial list (a wave reads 256
+// contiguous bytes of one partial row); slices are added in a fixed order
+__global__ __launch_bounds__(1024) void field_dw_reduce_kernel(const float* __restrict__ partial, int n_partials,
+                                                               float* __restrict__ dw1, float* __restrict__ dw2,
+                                                               float* __restrict__ dw3, float* __restrict__ dw4) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     float s = 0.f;
-    if (i < DW_TOTAL)
+    if (i < DW_TOTAL) {
+#pragma unroll 8
         for (int k = slice; k < n_partials; k += 16) s += partial[(size_t)k * DW_TOTAL + i];
+    }
     red[slice][col] = s;
     __syncthreads();
     if (slice != 0 || i >= DW_TOTAL) return;
@@ -1022,7 +1027,7 @@ int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float*
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 15) / 16), dim3(256), 0, st, ws.partial, DW_BLOCKS,
+    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS,
                        dw1, dw2, dw3, dw4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

@@ -21,9 +21,11 @@ for n_rays in (256, 512, 1024, 2148, 4096, 8192, 16384):
     draw = torch.randn((n, 4), device="cuda", generator=g)
     ws = torch.empty(int(lib.rfx_field_backward_workspace_bytes(n)) // 4 + 16, device="cuda")
     desc = m._field_desc(False)
+    dw = torch.zeros(5312, device="cuda")
     res = []
     for name, fn in (("forward", lambda: lib.rfx_field_forward(C.byref(desc), L.ptr(x), n, L.ptr(raw), st)),
                      ("chain", lambda: lib.rfx_field_backward_chain(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st)),
+                     ("dW", lambda: lib.rfx_field_backward_weights(n, L.ptr(draw), L.ptr(dw), L.ptr(dw) + 4 * 2592, L.ptr(dw) + 4 * 3104, L.ptr(dw) + 4 * 5216, L.ptr(ws), ws.numel() * 4, st)),
                      ("chain_inputs", lambda: lib.rfx_field_backward_chain_inputs(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st))):
         for _ in range(3): fn()
         evs = []
