@@ -197,11 +197,11 @@ def main():
     pipe = MappingPipeline(cfg, device=device, n_frames=n_frames + 8, seed=rank, shard=shard)
     frames = pipe.prefetch(list(range(n_frames)))
     pipe.start(frames[0])
-    # The BA iterations are normally issued by one library call each (rfx_ba_forward_backward); every 4th one is issued
+    # The BA iterations are normally issued by one library call each (rfx_ba_forward_backward); every 8th one is issued
     # stage by stage instead (same kernels, same order) so that the HIP events of KernelTimer see the individual calls.
     direct = pipe.mapper._direct_iterations() if pipe.mapper is not None else None
     if direct is not None:
-        direct.stagewise_every = 4
+        direct.stagewise_every = 8
         timer.every = 1
     for i in range(1, 1 + args.warmup):
         pipe.step(i, frames[i])
