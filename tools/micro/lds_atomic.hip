@@ -68,6 +68,7 @@ int main() {
                    ms * 1e-3 * 2.1e9 / (16.0 * iters), 1024.0 * iters / (km + 1) / (ms * 1e-3 * 2.1e9));
         }
     };
+    bench_int(ki<float>, "f32 (typed kernel)");
     bench_int(ki<unsigned>, "u32");
     bench_int(ki<unsigned long long>, "u64");
     bench_int(ki<double>, "f64");
