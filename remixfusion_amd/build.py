@@ -21,7 +21,7 @@ HEADERS = ["rfx_common.h", "rfx_field_device.h", "rfx_field_mlp.h", os.path.join
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function", "-DHASH_GROUP=4", "-DFWD_WAVES=3", "-DBWD_WAVES=2",
+    "-Wall", "-Wno-unused-function", "-DHASH_GROUP=4", "-DFWD_WAVES=2", "-DRENDER_WAVES=3", "-DBWD_WAVES=2",
 ]
 
 

@@ -14,6 +14,9 @@ namespace rfx {
 #ifndef FWD_WAVES
 #define FWD_WAVES 2
 #endif
+#ifndef RENDER_WAVES
+#define RENDER_WAVES FWD_WAVES      // the fused renderer (millions of points: throughput) may want more waves per SIMD than
+#endif                              // the point-batch forward (1e5 points: latency, and no spills at 2 waves)
 #ifndef BWD_WAVES
 #define BWD_WAVES 2
 #endif

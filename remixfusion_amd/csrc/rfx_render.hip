@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float4* _
 // ------------------------------------------------------------------ fused eval renderer
 // one wave per ray; lanes = samples; S1 + points + Q1 (encode + MFMA MLP) + R1, all in registers.
 template <bool POS16>
-__global__ __launch_bounds__(256, FWD_WAVES) void render_rays_kernel(FieldK f, SamplerK s, BoxK box,
+__global__ __launch_bounds__(256, RENDER_WAVES) void render_rays_kernel(FieldK f, SamplerK s, BoxK box,
                                                                     const float* __restrict__ rays_o,
                                                                     const float* __restrict__ rays_d,
                                                                     const float* __restrict__ target_d,
