@@ -99,6 +99,56 @@ __global__ __launch_bounds__(256) void grid_encode_forward_kernel(rfx_grid_desc 
     }
 }
 
+// Level-parallel forms for F = 2: thread = (point, level), the LP lanes of a point next to each other (LP = levels
+// rounded up to a power of two).  A thread that walks all levels of its point strings 16 dependent gather round trips
+// together (26 us for the 3e4-point TV lattice, whatever the point count); here each thread makes one, and the level
+// loop becomes parallelism across waves.  A point's features are written as one contiguous 8 * L byte run.
+__global__ __launch_bounds__(256) void grid_encode_forward_lp_kernel(rfx_grid_desc g, const float* __restrict__ table,
+                                                                     const float* __restrict__ x01, int64_t n, int lp_shift,
+                                                                     float* __restrict__ feat) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = gid >> lp_shift;
+    const int l = (int)(gid & ((1 << lp_shift) - 1));
+    if (p >= n || l >= g.n_levels) return;
+    const float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+    reinterpret_cast<float2*>(feat + p * (int64_t)(g.n_levels * 2))[l] = lookup2(table, get_level(g, l), x);
+}
+
+// dL/dx01 through the grid (no table gradient): per-level contributions summed over the LP lanes of the point
+__global__ __launch_bounds__(256) void grid_encode_dx_lp_kernel(rfx_grid_desc g, const float* __restrict__ table,
+                                                                const float* __restrict__ x01, int64_t n,
+                                                                const float* __restrict__ dfeat, int ld, int lp_shift,
+                                                                float* __restrict__ dx01) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = gid >> lp_shift;
+    const int l = (int)(gid & ((1 << lp_shift) - 1));
+    float dx[3] = {0.f, 0.f, 0.f};
+    if (p < n && l < g.n_levels) {
+        const float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+        const float2 gv = reinterpret_cast<const float2*>(dfeat + p * (int64_t)ld)[l];
+        const float gg[2] = {gv.x, gv.y};
+        lookup_dx<2>(table, get_level(g, l), x, gg, dx);
+    }
+    for (int o = 1; o < (1 << lp_shift); o <<= 1) {          // whole waves reach this (no early return above)
+        dx[0] += __shfl_xor(dx[0], o); dx[1] += __shfl_xor(dx[1], o); dx[2] += __shfl_xor(dx[2], o);
+    }
+    if (p < n && l == 0) { dx01[p * 3] = dx[0]; dx01[p * 3 + 1] = dx[1]; dx01[p * 3 + 2] = dx[2]; }
+}
+
+static inline int lp_shift_of(int n_levels) {
+    int s = 0;
+    while ((1 << s) < n_levels) ++s;
+    return s;
+}
+
+static void launch_encode_dx(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat, int ld,
+                             float* dx01, hipStream_t st) {
+    const int sh = lp_shift_of(g.n_levels);
+    const int64_t threads = n << sh;
+    hipLaunchKernelGGL(grid_encode_dx_lp_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, g, table, x01, n, dfeat, ld,
+                       sh, dx01);
+}
+
 // dfeat rows have stride `ld` floats (>= L*F) so that the field backward can point it at its workspace.
 // Hash-grid gradient scatter.  Scattered fp32 atomics are the bottleneck on MI355X (one 64-B memory-
 // side request per lane, ~2e10/s chip-wide), so contributions are first reduced inside the wave:
@@ -882,8 +932,14 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
     if (g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_ARG;
     if (g->n_feat != 1 && g->n_feat != 2 && g->n_feat != 4) return RFX_ERR_UNSUPPORTED;
     if (n == 0) return RFX_OK;
-    hipLaunchKernelGGL(grid_encode_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
-                       table, x01, n, feat);
+    if (g->n_feat == 2 && (n << 4) < (int64_t)0x7fffffff * 256) {
+        const int sh = lp_shift_of(g->n_levels);
+        hipLaunchKernelGGL(grid_encode_forward_lp_kernel, dim3((unsigned)(((n << sh) + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
+                           table, x01, n, sh, feat);
+    } else {
+        hipLaunchKernelGGL(grid_encode_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
+                           table, x01, n, feat);
+    }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -909,8 +965,7 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
         RFX_LAUNCH_CHECK();
     }
     if (dx01) {
-        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), *g,
-                           table, x01, n, dfeat, g->n_levels * 2, (float*)nullptr, dx01, 0);
+        launch_encode_dx(*g, table, x01, n, dfeat, g->n_levels * 2, dx01, as_stream(stream));
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;
@@ -1048,8 +1103,7 @@ int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_
         RFX_LAUNCH_CHECK();
     }
     if (dx01) {
-        hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k.hash,
-                           k.table, x01, n, ws.dx1, LD_DX1, (float*)nullptr, dx01, 0);
+        launch_encode_dx(k.hash, k.table, x01, n, ws.dx1, LD_DX1, dx01, as_stream(stream));
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;
