@@ -64,6 +64,7 @@ class MappingPipeline:
                 config.get("pipeline", {}).get("mv_stream", True):
             self.mv_stream = torch.cuda.Stream(device=self.device)
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
+        self._kf_inv = (-1, None)       # inverse pose of the newest keyframe, reused by the frames that follow it
         self.frames_done = 0
 
     # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
@@ -114,9 +115,12 @@ class MappingPipeline:
             self.slam.est_c2w_data[i] = c2w_dev
             ke = self.config["mapping"]["keyframe_every"]
             if i % ke != 0:     # relative pose to the last keyframe, like the tracker stores it
-                kf = self.slam.est_c2w_data[(i // ke) * ke]
-                # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop
-                self.slam.est_c2w_data_rel[i] = c2w_dev @ torch.linalg.inv_ex(kf).inverse
+                k = (i // ke) * ke
+                if self._kf_inv[0] != k:
+                    # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop.  The newest keyframe's
+                    # pose only changes in a mapper step that refines the current frame (mapping.optim_cur), see step()
+                    self._kf_inv = (k, torch.linalg.inv_ex(self.slam.est_c2w_data[k]).inverse)
+                self.slam.est_c2w_data_rel[i] = c2w_dev @ self._kf_inv[1]
             self.slam.tracking_idx[0] = i
 
     def _integrate(self, i, batch, rgb255, pose_np):
@@ -140,4 +144,6 @@ class MappingPipeline:
             # the reference's mapper wakes when tracking_idx > mapping_idx + map_every (mapper.py:879)
             if i > int(self.slam.mapping_idx[0]) + m["map_every"] and cur < len(self.dataset):
                 self.mapper.step(cur)
+                if m["optim_cur"]:
+                    self._kf_inv = (-1, None)
         self.frames_done += 1
