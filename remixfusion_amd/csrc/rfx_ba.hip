@@ -104,18 +104,15 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     // ---- decoder weights -> MFMA operand image (the optimizers update the weights in place between calls)
     if (b->field.staged) RFX_TRY(rfx_field_stage_weights(&b->field, const_cast<float*>(b->field.staged), stream));
     // ---- ray batch
-    RFX_TRY(rfx_gather_rays(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
-                            b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, w.o, w.d, w.tgt, w.td, w.d_cam,
-                            w.pidx, stream));
+    RFX_TRY(ray_batch_setup(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
+                            b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->bbox,
+                            b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, stream));     // rays, S1, points
     // ---- forward
-    RFX_TRY(rfx_sample_z(&b->sampler, w.td, b->u_z, n, w.z, stream));
-    RFX_TRY(rfx_ray_points(w.o, w.d, w.z, n, S, b->bbox, b->bbox_f64, w.x01, stream));
     RFX_TRY(rfx_field_forward(&b->field, w.x01, nS, w.raw, stream));
-    RFX_TRY(rfx_composite_forward(w.raw, w.z, n, S, b->trunc, b->sc_factor, w.rgb_map, w.depth_map, nullptr, stream));
     const float trunc_loss = b->trunc * b->sc_factor;
     float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
-    RFX_TRY(rfx_mapping_loss_forward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, trunc_loss, b->depth_trunc, b->rgb_missing_on,
-                                     w.sums, lc, lc + 4, stream));
+    RFX_TRY(composite_loss_forward(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc,
+                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, lc, lc + 4, stream));        // R1 + L1
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (map_grads || b->tv_sum) {
         RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));

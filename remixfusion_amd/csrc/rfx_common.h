@@ -33,4 +33,14 @@ __device__ __forceinline__ float madd(float a, float b, float c) { return fmaf(a
 // CUDA __float2int_rn: round-half-even.
 __device__ __forceinline__ int f2i_rn(float v) { return (int)rintf(v); }
 
+// fused forms of public entry points, used by rfx_ba_forward_backward (defined in rfx_render.hip)
+int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                    uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01,
+                    const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
+                    float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, rfx_stream stream);
+int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
+                           int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
+                           float* rgb_map, float* depth_map, double* sums, float* losses4, float* coef4, rfx_stream stream);
+
 }  // namespace rfx

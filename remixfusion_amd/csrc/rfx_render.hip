@@ -363,6 +363,73 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_forward_kernel(Loss
     }
 }
 
+// composite_forward_kernel + mapping_loss_forward_kernel in one launch (same ray-to-wave dealing and the same
+// expressions as the loss kernel, fed from registers instead of the maps just written: bit-identical partial sums)
+__global__ __launch_bounds__(LOSS_THREADS) void composite_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
+                                                                              const float* __restrict__ zv,
+                                                                              const float* __restrict__ tgt_rgb,
+                                                                              const float* __restrict__ tgt_d, int64_t n_rays, int S,
+                                                                              float trunc, float sc, float* __restrict__ rgb_map,
+                                                                              float* __restrict__ depth_map, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
+    for (int64_t ray = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * wpb) {
+        float s[2], z[2];
+        float4 rv[2];
+        bool vs[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = lane + 64 * c;
+            vs[c] = j < S;
+            rv[c] = vs[c] ? raw[ray * S + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            z[c] = vs[c] ? zv[ray * S + j] : 0.f;
+            s[c] = rv[c].w;
+        }
+        const RayW rw = ray_weights(s, z, vs, S, lane, trunc, sc);
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, md = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            m0 += rw.w[c] * rv[c].x; m1 += rw.w[c] * rv[c].y; m2 += rw.w[c] * rv[c].z; md += rw.w[c] * z[c];
+        }
+        m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); md = wave_sum(md);
+        const float d = tgt_d[ray];
+        const bool valid = (d > 0.0f) && (d < L.depth_trunc);
+        if (lane == 0) {
+            rgb_map[ray * 3] = m0; rgb_map[ray * 3 + 1] = m1; rgb_map[ray * 3 + 2] = m2; depth_map[ray] = md;
+            const float w = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
+            const float mm[3] = {m0, m1, m2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float e = mm[c] * w - tgt_rgb[ray * 3 + c] * w;
+                a_rgb += (double)(e * e);
+            }
+            if (valid) { const float e = md - d; a_dep += (double)(e * e); a_val += 1.0; }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!vs[c]) continue;
+            const float zz = z[c], ss = s[c];
+            const float front = (zz < (d - L.trunc_loss)) ? 1.0f : 0.0f;
+            const float back = (zz > (d + L.trunc_loss)) ? 1.0f : 0.0f;
+            const float sm = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
+            a_nfs += front; a_nsdf += sm;
+            if (valid) {
+                const float ef = ss * front - front;
+                const float es = (zz + ss * L.trunc_loss) * sm - d * sm;
+                a_fs += (double)(ef * ef); a_sdf += (double)(es * es);
+            }
+        }
+    }
+    __shared__ double red[LOSS_THREADS / 64];
+    a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
+    a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
+    a_nsdf = block_sum_d(a_nsdf, red);
+    if (threadIdx.x == 0) {
+        double* o = sums + (size_t)blockIdx.x * 8;
+        o[0] = a_rgb; o[1] = a_dep; o[2] = a_val; o[3] = a_fs; o[4] = a_sdf; o[5] = a_nfs; o[6] = a_nsdf; o[7] = 0.0;
+    }
+}
+
 // losses[4] = (rgb, depth, sdf, fs) ; coef[4] = d loss_i / d (its squared-error sum)
 __global__ void mapping_loss_finalize_kernel(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S,
                                              float* __restrict__ losses, float* __restrict__ coef) {
@@ -608,6 +675,63 @@ __global__ __launch_bounds__(256) void gather_rays_kernel(GatherK g, float* __re
     pose_idx[i] = k;
 }
 
+// gather_rays_kernel + sample_z_kernel + ray_points_kernel in one launch, wave = ray (the three stages of a BA
+// iteration's ray batch are each a few microseconds of launch-bound work).  Same expressions, so the outputs are
+// bit-identical to the three separate launches.
+__global__ __launch_bounds__(256) void ray_setup_kernel(GatherK g, SamplerK s, BoxK box, const float* __restrict__ u01,
+                                                        float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                        float* __restrict__ tgt_rgb, float* __restrict__ tgt_d,
+                                                        float* __restrict__ d_cam, int* __restrict__ pose_idx,
+                                                        float* __restrict__ z_vals, float* __restrict__ x01) {
+    __shared__ float zsh[4][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int S = s.n_range_d + s.n_samples_d;
+    float* zs = zsh[wv];
+    const int64_t n = g.n_kf + g.n_cur;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += (int64_t)gridDim.x * 4) {
+        const float* ray;
+        int k;
+        if (i < g.n_kf) {
+            const int64_t idx = feistel_index(g.seed_kf, i, g.kf_population, g.hb_kf);
+            ray = g.kf_rays + idx * 7;
+            k = (int)(g.kf_frame_ids[idx / g.rays_per_kf] / g.keyframe_every);
+            k = ((k % g.K) + g.K) % g.K;
+        } else {
+            const int64_t idx = feistel_index(g.seed_cur, i - g.n_kf, g.cur_population, g.hb_cur);
+            ray = g.cur_rays + idx * 7;
+            k = g.K - 1;
+        }
+        const float dc[3] = {ray[0], ray[1], ray[2]};
+        const float td = ray[6];
+        const float* __restrict__ P = g.poses + (size_t)k * 16;
+        float o[3], d[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            d[r] = P[4 * r] * dc[0] + P[4 * r + 1] * dc[1] + P[4 * r + 2] * dc[2];
+            o[r] = P[4 * r + 3];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                rays_d[i * 3 + r] = d[r]; rays_o[i * 3 + r] = o[r]; tgt_rgb[i * 3 + r] = ray[3 + r]; d_cam[i * 3 + r] = dc[r];
+            }
+            tgt_d[i] = td;
+            pose_idx[i] = k;
+        }
+        sample_ray(s, td, zs, lane);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to it
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < S; j += 64) {
+            float z = zs[j];
+            if (s.perturb > 0.0f && u01) z = jitter(zs, j, S, u01[i * S + j]);
+            z_vals[i * S + j] = z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x01[(i * S + j) * 3 + c] = normalise(box, c, o[c] + d[c] * z);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // dL/dposes[k] (rows 0..2): rotation part += g_d (x) d_cam, translation column += g_o; block = pose,
 // fixed-order block reduction (deterministic).
 __global__ __launch_bounds__(256) void pose_grad_kernel(const float* __restrict__ g_o, const float* __restrict__ g_d,
@@ -815,15 +939,10 @@ int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out
     return RFX_OK;
 }
 
-int rfx_gather_rays(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
-                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
-                    uint64_t seed_cur, const float* poses16, int K, float* rays_o, float* rays_d, float* target_rgb,
-                    float* target_d, float* d_cam, int32_t* pose_idx, rfx_stream stream) {
-    const int64_t n = n_kf_samples + n_cur;
-    if (n == 0) return RFX_OK;
-    if (n_kf_samples < 0 || n_cur < 0 || K <= 0 || keyframe_every <= 0 || !poses16 || !rays_o || !rays_d || !target_rgb ||
-        !target_d || !d_cam || !pose_idx)
-        return RFX_ERR_ARG;
+static int make_gather(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                       const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                       uint64_t seed_cur, const float* poses16, int K, GatherK* out) {
+    if (n_kf_samples < 0 || n_cur < 0 || K <= 0 || keyframe_every <= 0 || !poses16) return RFX_ERR_ARG;
     GatherK g{};
     g.kf_rays = kf_rays; g.rays_per_kf = rays_per_kf; g.kf_population = rays_per_kf * num_kf; g.kf_frame_ids = kf_frame_ids;
     g.keyframe_every = keyframe_every; g.cur_rays = cur_rays; g.cur_population = cur_population;
@@ -838,6 +957,21 @@ int rfx_gather_rays(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, c
         g.hb_cur = feistel_half_bits(cur_population);
         if (g.hb_cur > 31) return RFX_ERR_UNSUPPORTED;
     }
+    *out = g;
+    return RFX_OK;
+}
+
+int rfx_gather_rays(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                    uint64_t seed_cur, const float* poses16, int K, float* rays_o, float* rays_d, float* target_rgb,
+                    float* target_d, float* d_cam, int32_t* pose_idx, rfx_stream stream) {
+    const int64_t n = n_kf_samples + n_cur;
+    if (n == 0) return RFX_OK;
+    if (!rays_o || !rays_d || !target_rgb || !target_d || !d_cam || !pose_idx) return RFX_ERR_ARG;
+    GatherK g;
+    const int rc = make_gather(kf_rays, rays_per_kf, num_kf, kf_frame_ids, keyframe_every, cur_rays, cur_population, n_kf_samples,
+                               n_cur, seed_kf, seed_cur, poses16, K, &g);
+    if (rc) return rc;
     hipLaunchKernelGGL(gather_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), g, rays_o, rays_d,
                        target_rgb, target_d, d_cam, pose_idx);
     RFX_LAUNCH_CHECK();
@@ -854,3 +988,49 @@ int rfx_pose_grad(const float* g_o, const float* g_d, const float* d_cam, const 
 }
 
 }  // extern "C"
+
+// ---- fused forms used by rfx_ba_forward_backward (internal: declared in rfx_common.h) --------------------------------
+namespace rfx {
+
+// rfx_gather_rays + rfx_sample_z + rfx_ray_points
+int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                    uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01,
+                    const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
+                    float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, rfx_stream stream) {
+    const int64_t n = n_kf_samples + n_cur;
+    if (n == 0) return RFX_OK;
+    if (!rays_o || !rays_d || !target_rgb || !target_d || !d_cam || !pose_idx || !z_vals || !x01 || !bbox) return RFX_ERR_ARG;
+    GatherK g;
+    int rc = make_gather(kf_rays, rays_per_kf, num_kf, kf_frame_ids, keyframe_every, cur_rays, cur_population, n_kf_samples, n_cur,
+                         seed_kf, seed_cur, poses16, K, &g);
+    if (rc) return rc;
+    SamplerK k;
+    rc = make_sampler(sampler, &k);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ray_setup_kernel, dim3(ray_grid(n)), dim3(256), 0, as_stream(stream), g, k, make_box(bbox, bbox_f64), u01,
+                       rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// rfx_composite_forward + rfx_mapping_loss_forward
+int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
+                           int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
+                           float* rgb_map, float* depth_map, double* sums, float* losses4, float* coef4, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !losses4 || !coef4) return RFX_ERR_ARG;
+    if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
+    if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
+    const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_BLOCKS);
+    hipLaunchKernelGGL(composite_loss_forward_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, st, L, reinterpret_cast<const float4*>(raw4),
+                       z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map, sums);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(256), 0, st, sums, blocks, n_rays, S, losses4, coef4);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+}  // namespace rfx
