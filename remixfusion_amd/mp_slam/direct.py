@@ -127,6 +127,8 @@ class DirectIterations:
         self._rba_params = [w for m in self.model.rba._linears() for w in (m.weight, m.bias)]
         self._rba_grads = None
         self.stagewise_every = 0        # bench.py: issue every k-th iteration stage by stage (timed per entry point)
+        self.before_stagewise = None    # bench.py: callable run first in such an iteration (waits for the volume's stream, so
+                                        # that the per-call timings are not stretched by V1 running beside them)
         # mapping.unused_gradients: also compute, in the pose phase, the map gradients that no optimizer consumes
         # (what the reference's loss.backward() does); off by default, results are identical either way
         self.unused_gradients = bool(mapper.config["mapping"].get("unused_gradients", False))
@@ -314,6 +316,8 @@ class DirectIterations:
             B = self._cache[key] = _StageBuffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
                                                  self._weights, cap_K)
         B.bind(n, K)
+        if self.before_stagewise is not None:
+            self.before_stagewise()
         self._rays(B, current_rays, poses_ptr, K, st)
         go, gd = self._forward_backward(B, S, P, clamp, want_pose_grads, st, map_grads)
         return B, go, gd
