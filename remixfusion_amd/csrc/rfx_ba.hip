@@ -111,8 +111,9 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     RFX_TRY(rfx_field_forward(&b->field, w.x01, nS, w.raw, stream));
     const float trunc_loss = b->trunc * b->sc_factor;
     float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
+    int n_partials = 0;
     RFX_TRY(composite_loss_forward(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc,
-                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, lc, lc + 4, stream));        // R1 + L1
+                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, &n_partials, stream));       // R1 + L1 sums
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (map_grads || b->tv_sum) {
         RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
@@ -120,17 +121,17 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
         if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));
     }
     // ---- backward
-    RFX_TRY(rfx_mapping_loss_backward(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
-                                      b->depth_trunc, b->rgb_missing_on, lc + 4, b->loss_w_dev, nullptr, nullptr, w.d_raw, stream));
+    RFX_TRY(loss_backward_from_partials(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
+                                        b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw,
+                                        stream));                                                                   // L1 finish + backward
     // the chain variant that produces exactly what the following stages read
     if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else RFX_TRY(rfx_field_backward_chain_inputs(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     if (map_grads) {
         RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
-        RFX_HIP_TRY(hipMemsetAsync(b->d_w, 0, (size_t)(32 * 81 + 16 * 32 + 32 * 66 + 3 * 32) * sizeof(float), st));
         float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
-        RFX_TRY(rfx_field_backward_weights(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
     }
     if (b->d_poses16) {
         RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));

@@ -39,8 +39,14 @@ int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, c
                     uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01,
                     const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                     float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, rfx_stream stream);
+int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
                            int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, float* losses4, float* coef4, rfx_stream stream);
+                           float* rgb_map, float* depth_map, double* sums, int* n_partials, rfx_stream stream);
+int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                                const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
+                                float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
+                                const float* gout4, float* lc8, float* d_raw4, rfx_stream stream);
 
 }  // namespace rfx

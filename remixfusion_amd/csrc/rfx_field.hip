@@ -810,6 +810,7 @@ __global__ __launch_bounds__(256, 2) void field_dw_partial_kernel(BwdWs ws, cons
 
 // deterministic second stage: block = 64 consecutive outputs x 16 slices of the partial list (a wave reads 256
 // contiguous bytes of one partial row); slices are added in a fixed order
+template <bool OVERWRITE>
 __global__ __launch_bounds__(1024) void field_dw_reduce_kernel(const float* __restrict__ partial, int n_partials,
                                                                float* __restrict__ dw1, float* __restrict__ dw2,
                                                                float* __restrict__ dw3, float* __restrict__ dw4) {
@@ -827,10 +828,9 @@ __global__ __launch_bounds__(1024) void field_dw_reduce_kernel(const float* __re
 #pragma unroll
     for (int k = 1; k < 16; ++k) s += red[k][col];
     const int o1 = N_H * N_IN1, o2 = o1 + N_OUT2 * N_H, o3 = o2 + N_H * N_IN3;
-    if (i < o1) { if (dw1) dw1[i] += s; }
-    else if (i < o2) { if (dw2) dw2[i - o1] += s; }
-    else if (i < o3) { if (dw3) dw3[i - o2] += s; }
-    else { if (dw4) dw4[i - o3] += s; }
+    float* d = i < o1 ? (dw1 ? dw1 + i : nullptr) : i < o2 ? (dw2 ? dw2 + (i - o1) : nullptr)
+             : i < o3 ? (dw3 ? dw3 + (i - o2) : nullptr) : (dw4 ? dw4 + (i - o3) : nullptr);
+    if (d) *d = OVERWRITE ? s : *d + s;
 }
 
 // ---------------------------------------------------------------- backward kernel C: dx through OneBlob + GBV
@@ -1073,19 +1073,35 @@ int rfx_field_backward_chain_weights(const rfx_field_desc* f, const float* x01, 
     return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, false);
 }
 
-int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
-                               void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    if (n == 0 || (!dw1 && !dw2 && !dw3 && !dw4)) return RFX_OK;
+static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                                   void* workspace, size_t workspace_bytes, rfx_stream stream, bool overwrite) {
+    if (!dw1 && !dw2 && !dw3 && !dw4) return RFX_OK;
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {           // nothing to add; the overwriting form still has to leave zeros
+        if (overwrite) {
+            if (dw1) RFX_HIP_TRY(hipMemsetAsync(dw1, 0, sizeof(float) * N_H * N_IN1, st));
+            if (dw2) RFX_HIP_TRY(hipMemsetAsync(dw2, 0, sizeof(float) * N_OUT2 * N_H, st));
+            if (dw3) RFX_HIP_TRY(hipMemsetAsync(dw3, 0, sizeof(float) * N_H * N_IN3, st));
+            if (dw4) RFX_HIP_TRY(hipMemsetAsync(dw4, 0, sizeof(float) * N_OUT4 * N_H, st));
+        }
+        return RFX_OK;
+    }
     if (!draw4 || n < 0) return RFX_ERR_ARG;
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
-    hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(field_dw_reduce_kernel, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS,
-                       dw1, dw2, dw3, dw4);
+    if (overwrite)
+        hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS, dw1, dw2, dw3, dw4);
+    else
+        hipLaunchKernelGGL(field_dw_reduce_kernel<false>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS, dw1, dw2, dw3, dw4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                               void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, false);
 }
 
 int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,
@@ -1157,3 +1173,11 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
 }
 
 }  // extern "C"
+
+namespace rfx {
+// rfx_field_backward_weights that OVERWRITES dw1..dw4 (no zero-fill needed before it); used by rfx_ba_forward_backward
+int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true);
+}
+}  // namespace rfx

@@ -430,9 +430,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void composite_loss_forward_kernel(Lo
     }
 }
 
-// losses[4] = (rgb, depth, sdf, fs) ; coef[4] = d loss_i / d (its squared-error sum)
-__global__ void mapping_loss_finalize_kernel(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S,
-                                             float* __restrict__ losses, float* __restrict__ coef) {
+// lc[0..3] = losses (rgb, depth, sdf, fs), lc[4..7] = coef: d loss_i / d (its squared-error sum), from the per-block
+// partial sums; for a 256-thread block, lc in LDS, valid for all threads on return.
+__device__ __forceinline__ void loss_finalize(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S, float* lc) {
     __shared__ double part[32][8], sums[8];
     {   // thread = (value v, slice q): partials q, q + 32, ... in order, then the 32 slices in order
         const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
@@ -447,18 +447,31 @@ __global__ void mapping_loss_finalize_kernel(const double* __restrict__ partial,
         sums[threadIdx.x] = a;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double ns = (double)n_rays * (double)S;
-    const double tot = sums[5] + sums[6];
-    const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
-    const float c_rgb = (float)(1.0 / (3.0 * (double)n_rays)), c_dep = (float)(1.0 / sums[2]);
-    const float c_sdf = (float)(1.0 / ns) * sdf_w, c_fs = (float)(1.0 / ns) * fs_w;
-    losses[0] = (float)sums[0] * c_rgb; losses[1] = (float)sums[1] * c_dep;
-    losses[2] = (float)sums[4] * c_sdf; losses[3] = (float)sums[3] * c_fs;
-    coef[0] = c_rgb; coef[1] = c_dep; coef[2] = c_sdf; coef[3] = c_fs;
+    if (threadIdx.x == 0) {
+        const double ns = (double)n_rays * (double)S;
+        const double tot = sums[5] + sums[6];
+        const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
+        const float c_rgb = (float)(1.0 / (3.0 * (double)n_rays)), c_dep = (float)(1.0 / sums[2]);
+        const float c_sdf = (float)(1.0 / ns) * sdf_w, c_fs = (float)(1.0 / ns) * fs_w;
+        lc[0] = (float)sums[0] * c_rgb; lc[1] = (float)sums[1] * c_dep;
+        lc[2] = (float)sums[4] * c_sdf; lc[3] = (float)sums[3] * c_fs;
+        lc[4] = c_rgb; lc[5] = c_dep; lc[6] = c_sdf; lc[7] = c_fs;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void mapping_loss_finalize_kernel(const double* __restrict__ partial, int n_partials, int64_t n_rays,
+                                                                    int S, float* __restrict__ losses, float* __restrict__ coef) {
+    __shared__ float lc[8];
+    loss_finalize(partial, n_partials, n_rays, S, lc);
+    if (threadIdx.x < 4) { losses[threadIdx.x] = lc[threadIdx.x]; coef[threadIdx.x] = lc[4 + threadIdx.x]; }
 }
 
 // d_raw4 = d(sum_i gout_i * loss_i)/d raw  (+ optional external grads on the maps), compositing included.
+// PARTIALS: the coefficients are not read from `coef` but derived (by every block, with the finalize kernel's own
+// arithmetic) from the forward's per-block partial sums, and block 0 writes losses + coefficients to lc_out[8]: the forward
+// then needs no finalize launch of its own.
+template <bool PARTIALS>
 __global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, const float4* __restrict__ raw,
                                                                     const float* __restrict__ zv, const float* __restrict__ rgb_map,
                                                                     const float* __restrict__ depth_map,
@@ -466,8 +479,16 @@ __global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, con
                                                                     int64_t n_rays, int S, float trunc, float sc,
                                                                     const float* __restrict__ coef, const float* __restrict__ gout,
                                                                     const float* __restrict__ g_rgb_map,
-                                                                    const float* __restrict__ g_depth_map, float4* __restrict__ d_raw) {
+                                                                    const float* __restrict__ g_depth_map, float4* __restrict__ d_raw,
+                                                                    const double* __restrict__ partial, int n_partials,
+                                                                    float* __restrict__ lc_out) {
     const int lane = threadIdx.x & 63;
+    __shared__ float lc[8];
+    if (PARTIALS) {
+        loss_finalize(partial, n_partials, n_rays, S, lc);
+        if (blockIdx.x == 0 && threadIdx.x < 8) lc_out[threadIdx.x] = lc[threadIdx.x];
+        coef = lc + 4;
+    }
     const float k_rgb = gout[0] * coef[0], k_dep = gout[1] * coef[1], k_sdf = gout[2] * coef[2], k_fs = gout[3] * coef[3];
     for (int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * 4) {
         float s[2], z[2];
@@ -890,9 +911,10 @@ int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const floa
     if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
     LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
-    hipLaunchKernelGGL(mapping_loss_backward_kernel, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
+    hipLaunchKernelGGL(mapping_loss_backward_kernel<false>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
                        reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
-                       sc_factor, coef4, gout4, g_rgb_map, g_depth_map, reinterpret_cast<float4*>(d_raw4));
+                       sc_factor, coef4, gout4, g_rgb_map, g_depth_map, reinterpret_cast<float4*>(d_raw4), (const double*)nullptr, 0,
+                       (float*)nullptr);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1014,12 +1036,14 @@ int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, c
     return RFX_OK;
 }
 
-// rfx_composite_forward + rfx_mapping_loss_forward
+// rfx_composite_forward + the summing half of rfx_mapping_loss_forward: leaves the per-block partial sums in `sums`
+// (*n_partials of them) for loss_backward_from_partials, which finishes them
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
                            int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, float* losses4, float* coef4, rfx_stream stream) {
+                           float* rgb_map, float* depth_map, double* sums, int* n_partials, rfx_stream stream) {
+    *n_partials = 0;
     if (n_rays == 0) return RFX_OK;
-    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !losses4 || !coef4) return RFX_ERR_ARG;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums) return RFX_ERR_ARG;
     if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
@@ -1028,7 +1052,24 @@ int composite_loss_forward(const float* raw4, const float* z_vals, const float* 
     hipLaunchKernelGGL(composite_loss_forward_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, st, L, reinterpret_cast<const float4*>(raw4),
                        z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map, sums);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(256), 0, st, sums, blocks, n_rays, S, losses4, coef4);
+    *n_partials = blocks;
+    return RFX_OK;
+}
+
+// rfx_mapping_loss_forward's finalize + rfx_mapping_loss_backward: lc8 <- losses | coefficients, d_raw4 <- gradient
+int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                                const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
+                                float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
+                                const float* gout4, float* lc8, float* d_raw4, rfx_stream stream) {
+    if (n_rays == 0) return RFX_OK;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !gout4 || !lc8 || !d_raw4) return RFX_ERR_ARG;
+    if (n_rays < 0 || S <= 0 || !(trunc > 0.f) || n_partials <= 0) return RFX_ERR_ARG;
+    if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
+    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
+    hipLaunchKernelGGL(mapping_loss_backward_kernel<true>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
+                       reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
+                       sc_factor, (const float*)nullptr, gout4, (const float*)nullptr, (const float*)nullptr,
+                       reinterpret_cast<float4*>(d_raw4), sums, n_partials, lc8);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
