@@ -229,7 +229,15 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
     const int y0 = (P.win_y0[wi] + t % P.win_wy[wi]) * TY;
 
     // ---- per-row conservative z interval (lane r < ROWS owns row r of the tile)
+    //      phase A (row lanes): frustum clip -> [lo, hi] and the coarse-tile box of the row's projection
+    //      phase B (all lanes, 64 / ROWS per row): max depth over that box -- the tile reads are dependent L2 round
+    //               trips, up to ~30 per row when one lane walks them alone
+    //      phase C (row lanes): far clip from that depth, integer interval
     int z0 = 0, z1 = 0;
+    float lo = 0.0f, hi = -1.0f, Az = 0.0f, Bz = 0.0f, eps = 0.0f;
+    bool row_live = false, want_tiles = false;
+    int tu0 = 0, tu1 = -1, tv0 = 0, tv1 = -1;
+    const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     {
         const int rx = x0 + lane / TY, ry = y0 + lane % TY;
         if (lane < ROWS && rx < P.dx && ry < P.dy) {
@@ -242,14 +250,15 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
                 const float wz = P.origin[2] - P.c2w[11];
                 const float Ax = P.c2w[0] * wx + P.c2w[4] * wy + P.c2w[8] * wz;
                 const float Ay = P.c2w[1] * wx + P.c2w[5] * wy + P.c2w[9] * wz;
-                const float Az = P.c2w[2] * wx + P.c2w[6] * wy + P.c2w[10] * wz;
-                const float Bx = P.c2w[8] * P.voxel, By = P.c2w[9] * P.voxel, Bz = P.c2w[10] * P.voxel;
+                Az = P.c2w[2] * wx + P.c2w[6] * wy + P.c2w[10] * wz;
+                const float Bx = P.c2w[8] * P.voxel, By = P.c2w[9] * P.voxel;
+                Bz = P.c2w[10] * P.voxel;
                 const float fx = P.K[0], fy = P.K[4], cx = P.K[2], cy = P.K[5];
                 const float m = 0.05f;   // pixel margin
                 const float mag = fabsf(Ax) + fabsf(Ay) + fabsf(Az) +
                                   (float)P.dz * (fabsf(Bx) + fabsf(By) + fabsf(Bz));
-                const float eps = 1e-4f * fmaxf(fx, fy) * mag + 1e-4f;
-                float lo = 0.0f, hi = (float)(P.dz - 1);
+                eps = 1e-4f * fmaxf(fx, fy) * mag + 1e-4f;
+                lo = 0.0f; hi = (float)(P.dz - 1);
                 bool empty = false;
                 auto clip = [&](float a, float b) {   // keep z with a + b z >= -eps
                     a += eps;
@@ -268,29 +277,52 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
                 if (!empty && lo <= hi) {
                     // The row is a straight line in the image: its pixels lie in the bounding box of the two
                     // end points.  No voxel of the row can update if it is deeper than the deepest pixel of the
-                    // coarse tiles that box touches (+ trunc): clip the far end again, per row.
-                    float u0, v0, u1, v1;
-                    {
-                        const float za = fmaxf(Az + lo * Bz, 1e-6f), zb = fmaxf(Az + hi * Bz, 1e-6f);
-                        const float ra = __builtin_amdgcn_rcpf(za), rb = __builtin_amdgcn_rcpf(zb);
-                        u0 = fx * (Ax + lo * Bx) * ra + cx; v0 = fy * (Ay + lo * By) * ra + cy;
-                        u1 = fx * (Ax + hi * Bx) * rb + cx; v1 = fy * (Ay + hi * By) * rb + cy;
-                    }
-                    const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
-                    const int tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)), tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
-                    const int tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)), tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
-                    float tm = 0.0f;
-                    for (int tv = tv0; tv <= tv1; ++tv)
-                        for (int tu = tu0; tu <= tu1; ++tu) tm = fmaxf(tm, __uint_as_float(dmax_bits[1 + tv * tw + tu]));
-                    if (!(tm > 0.0f)) empty = true;
-                    else clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz);
-                }
-                if (!empty && lo <= hi) {
-                    z0 = max(0, (int)floorf(lo) - 1);
-                    z1 = min(P.dz, (int)ceilf(hi) + 2);
-                    if (z1 < z0) z1 = z0;
+                    // coarse tiles that box touches (+ trunc): the far end is clipped again below, per row.
+                    const float za = fmaxf(Az + lo * Bz, 1e-6f), zb = fmaxf(Az + hi * Bz, 1e-6f);
+                    const float ra = __builtin_amdgcn_rcpf(za), rb = __builtin_amdgcn_rcpf(zb);
+                    const float u0 = fx * (Ax + lo * Bx) * ra + cx, v0 = fy * (Ay + lo * By) * ra + cy;
+                    const float u1 = fx * (Ax + hi * Bx) * rb + cx, v1 = fy * (Ay + hi * By) * rb + cy;
+                    tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)); tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
+                    tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)); tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
+                    row_live = true;
+                    want_tiles = tu1 >= tu0 && tv1 >= tv0;
                 }
             }
+        }
+    }
+    float tm = 0.0f;
+    {
+        constexpr int HELPERS = 64 / ROWS;                   // lanes that share one row's tile walk
+        static_assert(64 % ROWS == 0 && (HELPERS & (HELPERS - 1)) == 0, "tile shape");
+        const int row = lane / HELPERS, sub = lane % HELPERS;
+        const int bu0 = __shfl(tu0, row), bu1 = __shfl(tu1, row), bv0 = __shfl(tv0, row), bv1 = __shfl(tv1, row);
+        const bool need = __shfl((int)want_tiles, row) != 0;
+        float part = 0.0f;
+        if (need) {
+            const int ntx = bu1 - bu0 + 1, nt = ntx * (bv1 - bv0 + 1);
+            for (int t = sub; t < nt; t += HELPERS)
+                part = fmaxf(part, __uint_as_float(dmax_bits[1 + (bv0 + t / ntx) * tw + bu0 + t % ntx]));
+        }
+#pragma unroll
+        for (int o = 1; o < HELPERS; o <<= 1) part = fmaxf(part, __shfl_xor(part, o));
+        tm = __shfl(part, (lane % ROWS) * HELPERS);         // row lane r takes the result of its helper group
+    }
+    if (row_live) {
+        bool empty = false;
+        if (!(tm > 0.0f)) empty = true;
+        else {
+            // the same clip as in phase A (keep z with a + b z >= -eps), on the far side: cam_z <= deepest pixel + trunc
+            const float a = (tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az + eps;
+            const float bb = -Bz;
+            const float q = -a * __builtin_amdgcn_rcpf(bb);
+            if (bb > 0.0f)      lo = fmaxf(lo, q);
+            else if (bb < 0.0f) hi = fminf(hi, q);
+            else if (a < 0.0f)  empty = true;
+        }
+        if (!empty && lo <= hi) {
+            z0 = max(0, (int)floorf(lo) - 1);
+            z1 = min(P.dz, (int)ceilf(hi) + 2);
+            if (z1 < z0) z1 = z0;
         }
     }
 
