@@ -490,3 +490,45 @@ def test_prestaged_weight_image_equals_in_kernel_staging():
     raw = torch.empty((x.shape[0], 4), device="cuda")
     L.check(lib.rfx_field_forward(C.byref(d), L.ptr(x), x.shape[0], L.ptr(raw), L.stream_ptr(x.device)), "fwd")
     assert torch.equal(after, raw)
+
+
+@pytest.mark.parametrize("clamp", [False, True])
+def test_backward_chain_variants_agree_with_the_full_chain(clamp):
+    """rfx_field_backward_chain_weights (map phase: rows + d_emb) and rfx_field_backward_chain_inputs (pose phase: dX1
+    only) stage exactly what the stages that may follow them read: same dW / d_hash, resp. same dx01, as the full chain."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    cfg, m = _model(hash_scale=0.5)
+    n = 9001
+    x = _points(n, seed=5, lo=0.02, hi=0.98).cuda().contiguous()
+    draw = torch.randn((n, 4), generator=torch.Generator().manual_seed(11)).cuda().contiguous()
+    desc = m._field_desc(clamp)
+    st = L.stream_ptr(x.device)
+    nbytes = int(lib.rfx_field_backward_workspace_bytes(n))
+    table = m.embed_res_fn.params
+
+    def run(chain, want_w, want_hash, want_dx):
+        ws = torch.full((nbytes // 4 + 16,), float("nan"), device="cuda")       # a stage reading what was not staged shows
+        wsp = (ws.data_ptr() + 15) // 16 * 16
+        dws = [torch.zeros_like(w) for w in m.decoder_res.fused_weights()]
+        d_hash, dx = torch.zeros_like(table), torch.zeros((n, 3), device="cuda")
+        L.check(chain(C.byref(desc), L.ptr(x), n, L.ptr(draw), wsp, nbytes, st), "chain")
+        if want_w:
+            L.check(lib.rfx_field_backward_weights(n, L.ptr(draw), *[L.ptr(g) for g in dws], wsp, nbytes, st), "weights")
+        if want_hash or want_dx:
+            L.check(lib.rfx_field_backward_scatter(C.byref(desc), L.ptr(x), n, L.ptr(d_hash) if want_hash else None,
+                                                   L.ptr(dx) if want_dx else None, wsp, nbytes, st), "scatter")
+        if want_dx:
+            L.check(lib.rfx_field_backward_dx(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(dx), wsp, nbytes, st), "dx")
+        torch.cuda.synchronize()
+        return dws, d_hash, dx
+
+    fw, fh, fx = run(lib.rfx_field_backward_chain, True, True, True)
+    ww, wh, _ = run(lib.rfx_field_backward_chain_weights, True, True, False)
+    _, _, ix = run(lib.rfx_field_backward_chain_inputs, False, False, True)
+    for a, b in zip(fw, ww):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert bool(torch.isfinite(wh).all()) and float((fh - wh).abs().max()) <= 1e-5 * float(fh.abs().max())    # atomic order
+    assert float(fh.abs().max()) > 0
+    assert torch.equal(fx, ix) and bool(torch.isfinite(ix).all()) and float(ix.abs().max()) > 0
