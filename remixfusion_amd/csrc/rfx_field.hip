@@ -277,7 +277,9 @@ static size_t scatter_scratch_floats(int64_t n, int n_levels) {
 // entries apart -- multiples of 16 for res = 16, 20, 24, 36, ... -- so points that differ only in y or z (a TV lattice,
 // rays along an axis) would all hit ONE bank; XOR-ing the low four bits with the next three nibbles spreads them
 // (a permutation inside every aligned group of 16 entries).
-__device__ __forceinline__ unsigned lds_slot(unsigned r) { return r ^ (((r >> 4) ^ (r >> 8) ^ (r >> 12)) & 15u); }
+// Hashed levels scatter their entries anyway: the permutation (six instructions per corner on the flush path) is only
+// applied on dense levels (pm = 15) and is the identity otherwise (pm = 0); a block works on one level, so pm is uniform.
+__device__ __forceinline__ unsigned lds_slot(unsigned r, unsigned pm) { return r ^ (((r >> 4) ^ (r >> 8) ^ (r >> 12)) & pm); }
 
 // slot (chunk c, iteration i, thread t) <- point c*K*1024 + t*K + i.  Planes: L x float2[slots], then x,y,z.
 // The point list is the concatenation of up to two sources (e.g. the ray samples and the TV lattice), so
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
     const int seg = blockIdx.x - plan.seg_start[l], chunk = blockIdx.y;
     const Level lv = get_level(g, l);
+    const unsigned pm = lv.hashed ? 0u : 15u;
     const unsigned base = (unsigned)seg * SCATTER_SEG;
     const unsigned cnt = min(SCATTER_SEG, lv.size - base);
     for (unsigned i = threadIdx.x; i < ((cnt + 15u) & ~15u) * 2; i += SCATTER_THREADS) acc[i] = 0.f;
@@ -339,11 +342,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
         for (int k = 0; k < 8; ++k) {
             const unsigned r = idx8[k] - base;
 #if defined(SCATTER_DBG) && SCATTER_DBG == 2
-            if (r < cnt) { acc[2 * lds_slot(r)] = a0[k]; acc[2 * lds_slot(r) + 1] = a1[k]; }
+            if (r < cnt) { acc[2 * lds_slot(r, pm)] = a0[k]; acc[2 * lds_slot(r, pm) + 1] = a1[k]; }
 #else
             if (r < cnt) {
-                atomicAdd(&acc[2 * lds_slot(r)], a0[k]);
-                atomicAdd(&acc[2 * lds_slot(r) + 1], a1[k]);
+                atomicAdd(&acc[2 * lds_slot(r, pm)], a0[k]);
+                atomicAdd(&acc[2 * lds_slot(r, pm) + 1], a1[k]);
             }
 #endif
         }
@@ -386,8 +389,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
                     const unsigned r = idx8[k] - base;
                     if (r < cnt) {
                         const float w = corner_weight(c, k);
-                        atomicAdd(&acc[2 * lds_slot(r)], w * gv.x);
-                        atomicAdd(&acc[2 * lds_slot(r) + 1], w * gv.y);
+                        atomicAdd(&acc[2 * lds_slot(r, pm)], w * gv.x);
+                        atomicAdd(&acc[2 * lds_slot(r, pm) + 1], w * gv.y);
                     }
                 }
             }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     __syncthreads();
     float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
     for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) {
-        const float v = acc[2 * lds_slot(i >> 1) + (i & 1)];
+        const float v = acc[2 * lds_slot(i >> 1, pm) + (i & 1)];
 #if defined(SCATTER_DBG) && SCATTER_DBG == 1
         if (v == 12345.f) out[i] = v;
 #elif defined(SCATTER_DBG) && SCATTER_DBG == 3
