@@ -314,7 +314,15 @@ def main():
                                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                      "points_per_launch": int(pts), "avg_ms": round(ms, 4),
                                                      "note": "LDS-privatised: corner sums accumulate with ds_add_f32 per 128 KB table segment, then one contiguous "
-                                                             "global atomic per non-zero entry; bound by LDS atomic throughput, not HBM"}
+                                                             "global atomic per non-zero entry; bound by LDS atomic throughput, not HBM",
+                                                     # the binding resource: ds_add_f32 retires 0.38 lanes/clock/CU on gfx950, 2.03e11
+                                                     # lane-adds/s chip-wide (tools/micro/lds_atomic.hip, time-based); algorithmic adds =
+                                                     # points x 16 levels x 8 corners x 2 features -- the register run accumulation
+                                                     # merges some before they reach LDS, so the algorithmic rate may exceed that peak
+                                                     "lds_atomic": {"algorithmic_lane_adds": int(pts * 256),
+                                                                    "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
+                                                                    "peak_per_s_measured": 2.03e11,
+                                                                    "frac": round(pts * 256 / (ms * 1e-3) / 2.03e11, 3)}}
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]
         pts = float(evs[0][2][6]) * S
