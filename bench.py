@@ -313,15 +313,16 @@ def main():
                                                      "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                      "points_per_launch": int(pts), "avg_ms": round(ms, 4),
-                                                     "note": "LDS-privatised: corner sums accumulate with ds_add_f32 per 128 KB table segment, then one contiguous "
-                                                             "global atomic per non-zero entry; bound by LDS atomic throughput, not HBM",
-                                                     # the binding resource: ds_add_f32 retires 0.38 lanes/clock/CU on gfx950, 2.03e11
-                                                     # lane-adds/s chip-wide (tools/micro/lds_atomic.hip, time-based); algorithmic adds =
-                                                     # points x 16 levels x 8 corners x 2 features -- the register run accumulation
-                                                     # merges some before they reach LDS, so the algorithmic rate may exceed that peak
+                                                     "note": "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
+                                                             "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
+                                                             "non-zero entry; bound by LDS atomics / index arithmetic, not HBM",
+                                                     # for orientation: ds_add_f32 retires 0.38 lanes/clock/CU on gfx950, 2.03e11 lane-adds/s
+                                                     # chip-wide (tools/micro/lds_atomic.hip, time-based), which is what bounds the float
+                                                     # variant; algorithmic adds = points x 16 levels x 8 corners x 2 features (the register
+                                                     # run accumulation merges some before they reach LDS; the double variant issues ~9x faster)
                                                      "lds_atomic": {"algorithmic_lane_adds": int(pts * 256),
                                                                     "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
-                                                                    "peak_per_s_measured": 2.03e11,
+                                                                    "ds_add_f32_peak_per_s_measured": 2.03e11,
                                                                     "frac": round(pts * 256 / (ms * 1e-3) / 2.03e11, 3)}}
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]

@@ -314,18 +314,25 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
     }
 }
 
+// ACC / SEG: float accumulators over 16 384-entry segments, or double accumulators over 8 192-entry segments (both
+// 128 KB).  ds_add_f32 retires one lane per ~2.6 clocks per CU, ds_add_f64 a whole wave in 19 (tools/micro/lds_atomic.hip):
+// with doubles the atomics stop being the bound, but every point is visited by twice as many blocks, so the index
+// arithmetic doubles.  Measured (tools/time_scatter.py, merged ray + TV points): T = 2^16 0.23 -> 0.15 ms with doubles,
+// T = 2^19 0.93 -> 1.21 ms, T = 2^21 1.5 -> 2.6 ms: doubles are used while no level is cut into 16 or more float segments.
+template <typename ACC, unsigned SEG>
 __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_grid_desc g, ScatterPlan plan, int n_levels,
                                                                            const float* __restrict__ scratch,
                                                                            float* __restrict__ dtable) {
-    extern __shared__ float acc[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
+    ACC* acc = reinterpret_cast<ACC*>(acc_raw);
     int l = 0;
     while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
     const int seg = blockIdx.x - plan.seg_start[l], chunk = blockIdx.y;
     const Level lv = get_level(g, l);
     const unsigned pm = lv.hashed ? 0u : 15u;
-    const unsigned base = (unsigned)seg * SCATTER_SEG;
-    const unsigned cnt = min(SCATTER_SEG, lv.size - base);
-    for (unsigned i = threadIdx.x; i < ((cnt + 15u) & ~15u) * 2; i += SCATTER_THREADS) acc[i] = 0.f;
+    const unsigned base = (unsigned)seg * SEG;
+    const unsigned cnt = min(SEG, lv.size - base);
+    for (unsigned i = threadIdx.x; i < ((cnt + 15u) & ~15u) * 2; i += SCATTER_THREADS) acc[i] = (ACC)0;
     __syncthreads();
     const int64_t slots = plan.slots;
     const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
@@ -345,8 +352,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
             if (r < cnt) { acc[2 * lds_slot(r, pm)] = a0[k]; acc[2 * lds_slot(r, pm) + 1] = a1[k]; }
 #else
             if (r < cnt) {
-                atomicAdd(&acc[2 * lds_slot(r, pm)], a0[k]);
-                atomicAdd(&acc[2 * lds_slot(r, pm) + 1], a1[k]);
+                atomicAdd(&acc[2 * lds_slot(r, pm)], (ACC)a0[k]);
+                atomicAdd(&acc[2 * lds_slot(r, pm) + 1], (ACC)a1[k]);
             }
 #endif
         }
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #pragma unroll
         for (int j = 0; j < NB; ++j) { gvb[j] = gv_n[j]; xb[j][0] = xn[j][0]; xb[j][1] = xn[j][1]; xb[j][2] = xn[j][2]; }
         if (i + NB < plan.K) fetch(i + NB);
-        if (lv.hashed && lv.size >= 16u * SCATTER_SEG) {
+        if (lv.hashed && lv.size >= 16u * SEG) {
             // big hashed level (>= 16 segments): nearly every corner falls into another segment, so test segment
             // membership first and add only the corners that land here, without the register run accumulation
             // (measured: 1.25-1.6x faster at 128 segments, neutral at 32, slower at 4)
@@ -389,8 +396,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
                     const unsigned r = idx8[k] - base;
                     if (r < cnt) {
                         const float w = corner_weight(c, k);
-                        atomicAdd(&acc[2 * lds_slot(r, pm)], w * gv.x);
-                        atomicAdd(&acc[2 * lds_slot(r, pm) + 1], w * gv.y);
+                        atomicAdd(&acc[2 * lds_slot(r, pm)], (ACC)(w * gv.x));
+                        atomicAdd(&acc[2 * lds_slot(r, pm) + 1], (ACC)(w * gv.y));
                     }
                 }
             }
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     __syncthreads();
     float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
     for (unsigned i = threadIdx.x; i < cnt * 2; i += SCATTER_THREADS) {
-        const float v = acc[2 * lds_slot(i >> 1, pm) + (i & 1)];
+        const float v = (float)acc[2 * lds_slot(i >> 1, pm) + (i & 1)];
 #if defined(SCATTER_DBG) && SCATTER_DBG == 1
         if (v == 12345.f) out[i] = v;
 #elif defined(SCATTER_DBG) && SCATTER_DBG == 3
@@ -438,10 +445,14 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
                                const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0) {
     ScatterPlan plan;
+    unsigned largest = 0;
+    for (int l = 0; l < g.n_levels; ++l) largest = std::max(largest, g.size[l]);
+    const bool f64 = largest < 16u * SCATTER_SEG;           // see grid_scatter_lds_kernel
+    const unsigned seg_entries = f64 ? SCATTER_SEG / 2 : SCATTER_SEG;
     int total = 0;
     for (int l = 0; l < g.n_levels; ++l) {
         plan.seg_start[l] = total;
-        total += (int)((g.size[l] + SCATTER_SEG - 1) / SCATTER_SEG);
+        total += (int)((g.size[l] + seg_entries - 1) / seg_entries);
     }
     for (int l = g.n_levels; l <= RFX_MAX_LEVELS; ++l) plan.seg_start[l] = total;
     const int64_t n_all = n + n_b;
@@ -465,14 +476,20 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel),
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<float, SCATTER_SEG>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<double, SCATTER_SEG / 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     // (an XCD-aware block order -- all segments of one (level, chunk) on one XCD's L2 -- was measured: no gain at
     // T = 2^16 / 2^19 and a loss at 2^21, the levels' costs differ too much to be dealt out per XCD)
-    hipLaunchKernelGGL(grid_scatter_lds_kernel, dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan, g.n_levels,
-                       scratch, dtable);
+    if (f64)
+        hipLaunchKernelGGL((grid_scatter_lds_kernel<double, SCATTER_SEG / 2>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g,
+                           plan, g.n_levels, scratch, dtable);
+    else
+        hipLaunchKernelGGL((grid_scatter_lds_kernel<float, SCATTER_SEG>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan,
+                           g.n_levels, scratch, dtable);
     return RFX_OK;
 }
 
