@@ -380,9 +380,10 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #pragma unroll
         for (int j = 0; j < NB; ++j) { gvb[j] = gv_n[j]; xb[j][0] = xn[j][0]; xb[j][1] = xn[j][1]; xb[j][2] = xn[j][2]; }
         if (i + NB < plan.K) fetch(i + NB);
-        if (lv.hashed && lv.size >= 16u * SEG) {
-            // big hashed level (>= 16 segments): nearly every corner falls into another segment, so test segment
-            // membership first and add only the corners that land here, without the register run accumulation
+        if (lv.hashed && lv.size >= (sizeof(ACC) == 8 ? 8u : 16u) * SEG) {
+            // hashed level cut into many segments (>= 16 with float accumulators, >= 8 with double ones, whose atomics are
+            // cheap enough that merging runs in registers no longer pays): nearly every corner falls into another
+            // segment, so test segment membership first and add only the corners that land here
             // (measured: 1.25-1.6x faster at 128 segments, neutral at 32, slower at 4)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
