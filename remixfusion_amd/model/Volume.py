@@ -170,9 +170,20 @@ class moving_volume:
                                          int(old_dim[0]), int(old_dim[1]), int(old_dim[2]), farr(_F3, old_origin),
                                          self.voxel_size, self.index_decode, stream_ptr(self.device)), "rfx_tsdf_shift")
 
+    # A driver may run integrate / the volume moves on a stream of their own (MappingPipeline does, to overlap the mapper):
+    # it names that stream here, and the methods that READ the volume on the current stream wait for it first.
+    producer_stream = None
+
+    def _wait_for_producer(self):
+        if self.producer_stream is not None and self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self.producer_stream:
+                cur.wait_stream(self.producer_stream)
+
     def tri_interpolate(self, query_pc):
         """Trilinear tsdf/rgb at world points (reference :760-794, kernel :337-458).
         Returns (result [N,5], mask [N]) as numpy, like the reference."""
+        self._wait_for_producer()
         pts = self._dev(query_pc).reshape(-1, 3)
         out = torch.empty((pts.shape[0], 5), dtype=torch.float32, device=self.device)
         t, w, c = self._vols()
@@ -192,6 +203,7 @@ class moving_volume:
 
     def get_truncated_pc(self, pc_num=5000000, trunc_tsdf=0.5):
         """Near-surface voxels as a point cloud (reference :622-653, kernel :489-559)."""
+        self._wait_for_producer()
         pc = torch.zeros((pc_num, 7), dtype=torch.float32, device=self.device)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         d = self.vol_dim
@@ -206,6 +218,7 @@ class moving_volume:
 
     def get_volume_all(self):
         """D2H copy of the three volumes, flat, z fastest (reference :1265-1277)."""
+        self._wait_for_producer()
         n = self._n()
         self.tsdf_vol_cpu = self.tsdf_vol_gpu[:n].cpu().numpy()
         self.weight_vol_cpu = self.weight_vol_gpu[:n].cpu().numpy()

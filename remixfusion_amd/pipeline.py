@@ -64,6 +64,7 @@ class MappingPipeline:
                 config.get("pipeline", {}).get("mv_stream", True):
             self.mv_stream = torch.cuda.Stream(device=self.device)
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
+            self.mv.producer_stream = self.mv_stream     # readers on other streams (get_volume_all, ...) wait for it
         self._kf_inv = (-1, None)       # inverse pose of the newest keyframe, reused by the frames that follow it
         self.frames_done = 0
 

@@ -356,7 +356,7 @@ def test_pipeline_volume_stream_gives_the_same_volume():
         pipe.start(frames[0])
         for i in range(1, 31):
             pipe.step(i, frames[i])
-        torch.cuda.synchronize()
+        # no synchronize: get_volume_all itself waits for the stream that integrates (moving_volume.producer_stream)
         return [v.copy() for v in pipe.mv.get_volume_all()], np.array(pipe.mv.vol_bnds, copy=True)
 
     (t0, w0, c0), b0 = run(False)
