@@ -242,12 +242,14 @@ def main():
 
     barrier()
     timer.enabled = True
+    it0 = dict(direct.iterations) if direct is not None else None
     t0 = time.perf_counter()
     for i in range(1 + args.warmup, n_frames):
         pipe.step(i, frames[i])
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    iters = {k: direct.iterations[k] - it0[k] for k in it0} if direct is not None else {"map": 0, "pose": 0}
     if dist is not None:
         tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -305,9 +307,25 @@ def main():
     step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
     # device time per entry point over the timed region = avg x number of launches; the BA-iteration stages were only
     # visible (hence counted) in every `stagewise_every`-th iteration
+    # the BA-iteration stages were only visible in every `stagewise_every`-th iteration: their launch counts come from the
+    # number of map / pose iterations issued in the timed region
     per_frame = ("rfx_tsdf_integrate", "rfx_gbv_integrate", "rfx_render_rays")
-    mult = {k: (1 if (k in per_frame or direct is None) else direct.stagewise_every) for k in step_kernels}
-    dominant = max(step_kernels, key=lambda k: step_kernels[k][0] * mult[k] * step_kernels[k][1]) if step_kernels else None
+    map_only = ("rfx_field_backward_chain_weights", "rfx_field_backward_weights", "rfx_field_backward_scatter_merged", "rfx_tv_forward",
+                "rfx_tv_backward", "rfx_grid_encode_forward")
+    pose_only = ("rfx_field_backward_chain_inputs", "rfx_field_backward_scatter", "rfx_field_backward_dx")
+    if args.unused_gradients:                      # the pose phase then runs the map-gradient stages as well (on the full chain)
+        map_only, pose_only = ("rfx_field_backward_chain_weights",), pose_only + ("rfx_field_backward_chain",)
+    launches = {}
+    for k, (cnt, ms, _) in step_kernels.items():
+        if k in per_frame or direct is None:
+            launches[k] = cnt
+        elif k in map_only:
+            launches[k] = iters["map"]
+        elif k in pose_only:
+            launches[k] = iters["pose"]
+        else:
+            launches[k] = iters["map"] + iters["pose"]
+    dominant = max(step_kernels, key=lambda k: launches[k] * step_kernels[k][1]) if step_kernels else None
     roofline = None
     extra_rooflines = {}
 
@@ -437,6 +455,7 @@ def main():
                    "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},
         "render_rays_per_s": round(render, 1) if render else None,
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,
+        "iterations_timed": iters,
         "cpu_baseline": base,
     }
     print(json.dumps(out))

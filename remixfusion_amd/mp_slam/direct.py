@@ -135,6 +135,7 @@ class DirectIterations:
         # the TV value itself (SLAM.smoothness's return) only matters through its gradient: evaluated on request
         self.report_tv = bool(mapper.config["mapping"].get("report_tv", False))
         self._count = 0
+        self.iterations = {"map": 0, "pose": 0}          # issued so far (bench.py: launches per entry point)
 
     def _stagewise_now(self) -> bool:
         self._count += 1
@@ -343,6 +344,7 @@ class DirectIterations:
     def map_iteration(self, current_rays, poses_all):
         """one trip of the loop of Mapper.global_mapping (map parameters step; poses fixed)."""
         lc = self.map_gradients(current_rays, poses_all)
+        self.iterations["map"] += 1
         self.mp.map_optimizer.step()
         self._drop_grads()
         return lc
@@ -350,6 +352,7 @@ class DirectIterations:
     def pose_iteration(self, current_rays, idx):
         """one trip of the loop of Mapper.global_pose with opt_pose: poses = RBA(idx), pose-MLP step."""
         lc = self.pose_gradients(current_rays, idx, map_grads=self.unused_gradients)
+        self.iterations["pose"] += 1
         self.mp.rba_optimizer.step()
         self._drop_grads()
         return lc
