@@ -4,7 +4,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles/r1_bench_kernel_stats.csv")
 rows = list(csv.DictReader(open(src)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline (round 1)", "",
+out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline (round 1; the process also runs the warm-up pipeline, the 200 first-frame iterations and the closing full-frame renders)", "",
        "librfx kernels only (full table: r1_bench_kernel_stats.csv). Durations in microseconds.", "",
        f"All GPU kernel time in the run: {tot / 1e6:.1f} ms; librfx share: "
        f"{sum(float(r['TotalDurationNs']) for r in rows if 'rfx::' in r['Name']) / tot:.1%}.", "",
