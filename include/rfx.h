@@ -364,6 +364,11 @@ typedef struct rfx_rba_grads {          /* any pointer may be NULL (that gradien
 size_t rfx_rba_acts_floats(int64_t K);   /* size of `acts` (forward -> backward) */
 size_t rfx_rba_grads_floats(int64_t K);  /* size of the backward workspace */
 /* cam_ids dev [K] int64 (rows of init_r/init_t dev [num_cams,3]); poses16 dev [K,16] row-major c2w. */
+/* RBA.update_init_pose (model/rba.py:77-86): c2w16 dev [16] row-major pose of keyframe slot cam_id -> init_c2w16[cam_id],
+ * init_t[cam_id] (translation), init_r[cam_id] (rotation as angle-axis).  init_r / init_t dev [num_cams,3], init_c2w16 dev
+ * [num_cams,16]. */
+int rfx_rba_set_init_pose(const float* c2w16, int cam_id, int num_cams, float* init_r, float* init_t, float* init_c2w16,
+                          rfx_stream stream);
 int rfx_rba_forward(const rfx_rba_params* p, const float* init_r, const float* init_t, const int64_t* cam_ids, int64_t K,
                     int num_cams, float scale, float* poses16, float* acts, rfx_stream stream);
 /* dposes16 dev [K,16] = dL/dc2w; parameter gradients are overwritten (deterministic sums over K). */

@@ -61,6 +61,41 @@ __device__ void rodrigues_backward(const float aa[3], float eps, const float G[9
     for (int i = 0; i < 3; ++i) daa[i] = dw[i] * inv + dth * aa[i] / th;
 }
 
+// RBA.update_init_pose (reference model/rba.py:77-86): pose of a new keyframe -> init_c2w / init_t / init_r (rotation
+// as angle-axis, kornia's rotation_matrix_to_angle_axis map evaluated from the antisymmetric part, the diagonal form only
+// next to pi: the same expressions as remixfusion_amd/model/rba.py::rotation_matrix_to_angle_axis, which takes ~25 tiny
+// ATen launches per keyframe).  One thread.
+__global__ void rba_set_init_pose_kernel(const float* __restrict__ c2w, int cam, float* __restrict__ init_r,
+                                         float* __restrict__ init_t, float* __restrict__ init_c2w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float m[16];
+    for (int i = 0; i < 16; ++i) { m[i] = c2w[i]; init_c2w[(size_t)cam * 16 + i] = m[i]; }
+    init_t[cam * 3] = m[3]; init_t[cam * 3 + 1] = m[7]; init_t[cam * 3 + 2] = m[11];
+    const float v[3] = {0.5f * (m[9] - m[6]), 0.5f * (m[2] - m[8]), 0.5f * (m[4] - m[1])};
+    const float s = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float c = 0.5f * (m[0] + m[5] + m[10] - 1.0f);
+    const float theta = atan2f(s, c);
+    const bool small = s < 1e-4f;
+    const float scale = small ? 1.0f + theta * theta / 6.0f : theta / fmaxf(s, 1e-12f);
+    float aa[3] = {v[0] * scale, v[1] * scale, v[2] * scale};
+    if (small && c < 0.0f) {            // theta next to pi: |w_i| from R = 2 w w^T - I, signs from the row of the largest one
+        float ax[3] = {sqrtf(fmaxf((m[0] + 1.0f) * 0.5f, 0.0f)), sqrtf(fmaxf((m[5] + 1.0f) * 0.5f, 0.0f)),
+                       sqrtf(fmaxf((m[10] + 1.0f) * 0.5f, 0.0f))};
+        int k = 0;
+        if (ax[1] > ax[k]) k = 1;
+        if (ax[2] > ax[k]) k = 2;
+        float n2 = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            const float r = m[4 * k + i] + 1e-20f;
+            ax[i] *= r > 0.0f ? 1.0f : (r < 0.0f ? -1.0f : 0.0f);
+            n2 += ax[i] * ax[i];
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        for (int i = 0; i < 3; ++i) aa[i] = ax[i] * inv * theta;
+    }
+    init_r[cam * 3] = aa[0]; init_r[cam * 3 + 1] = aa[1]; init_r[cam * 3 + 2] = aa[2];
+}
+
 struct RbaW {
     const float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
 };
@@ -201,6 +236,14 @@ size_t rfx_rba_grads_floats(int64_t K) { return K > 0 ? (size_t)K * RBA_GRAD_LD 
 
 static bool rba_params_ok(const rfx_rba_params* p) {
     return p && p->w0 && p->b0 && p->w1 && p->b1 && p->w2 && p->b2 && p->w3 && p->b3 && p->hidden == RBA_H;
+}
+
+int rfx_rba_set_init_pose(const float* c2w16, int cam_id, int num_cams, float* init_r, float* init_t, float* init_c2w16,
+                          rfx_stream stream) {
+    if (!c2w16 || !init_r || !init_t || !init_c2w16 || cam_id < 0 || cam_id >= num_cams) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(rba_set_init_pose_kernel, dim3(1), dim3(64), 0, as_stream(stream), c2w16, cam_id, init_r, init_t, init_c2w16);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
 }
 
 int rfx_rba_forward(const rfx_rba_params* p, const float* init_r, const float* init_t, const int64_t* cam_ids, int64_t K,

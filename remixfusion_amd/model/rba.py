@@ -135,6 +135,11 @@ class RBA(nn.Module):
 
     def update_init_pose(self, cam_id, c2w):
         c2w = c2w.detach().to(self.init_c2w)
+        if c2w.is_cuda:              # one launch instead of ~25 tiny tensor ops per keyframe (the same expressions)
+            c2w = c2w.contiguous()
+            check(_lib.load().rfx_rba_set_init_pose(ptr(c2w), int(cam_id), int(self.num_cams), ptr(self.init_r), ptr(self.init_t),
+                                               ptr(self.init_c2w), stream_ptr(c2w.device)), "rfx_rba_set_init_pose")
+            return
         self.init_c2w[cam_id] = c2w
         self.init_r[cam_id] = rotation_matrix_to_angle_axis(c2w[:3, :3].reshape(1, 3, 3)).reshape(-1)
         self.init_t[cam_id] = c2w[:3, 3]

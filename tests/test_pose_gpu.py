@@ -41,6 +41,29 @@ def test_fused_rba_matches_torch_ops(scale):
     assert float(gr[2].abs().max()) > 0
 
 
+def test_set_init_pose_kernel_matches_the_tensor_formulation():
+    """RBA.update_init_pose on the device is one librfx launch; same init_c2w / init_t / init_r as the tensor-op
+    formulation (model/rba.py::rotation_matrix_to_angle_axis), incl. tiny rotations and rotations next to pi."""
+    from remixfusion_amd.model.rba import RBA, angle_axis_to_rotation_matrix, rotation_matrix_to_angle_axis
+    g = torch.Generator().manual_seed(4)
+    aa = torch.randn((12, 3), generator=g)
+    aa = aa / aa.norm(dim=-1, keepdim=True)
+    ang = torch.tensor([0.0, 1e-7, 1e-5, 3e-4, 0.1, 1.0, 2.0, 3.0, 3.14159, 3.1415926, 3.141, 2.5])
+    R = angle_axis_to_rotation_matrix(aa * ang[:, None])
+    rba = RBA(12, device="cuda")
+    for i in range(12):
+        c2w = torch.eye(4)
+        c2w[:3, :3] = R[i]
+        c2w[:3, 3] = torch.tensor([0.1 * i, -0.2, 0.3])
+        rba.update_init_pose(i, c2w.cuda())
+        ref = rotation_matrix_to_angle_axis(R[i:i + 1]).reshape(-1)
+        got = rba.init_r[i].cpu()
+        # the angle-axis of a rotation next to pi is defined up to the sign of the axis: compare the rotations
+        Rg = angle_axis_to_rotation_matrix(got[None])[0]
+        assert float((Rg - R[i]).abs().max()) < 2e-3 if ang[i] > 3.14 else float((got - ref).abs().max()) < 1e-5, (i, got, ref)
+        assert torch.equal(rba.init_c2w[i].cpu(), c2w) and torch.equal(rba.init_t[i].cpu(), c2w[:3, 3])
+
+
 def test_fused_rba_in_the_pose_loop():
     """a few Adam steps on a pose-only objective move the poses the same way through both paths."""
     import copy
