@@ -364,6 +364,10 @@ typedef struct rfx_rba_grads {          /* any pointer may be NULL (that gradien
 size_t rfx_rba_acts_floats(int64_t K);   /* size of `acts` (forward -> backward) */
 size_t rfx_rba_grads_floats(int64_t K);  /* size of the backward workspace */
 /* cam_ids dev [K] int64 (rows of init_r/init_t dev [num_cams,3]); poses16 dev [K,16] row-major c2w. */
+/* Per-frame pose bookkeeping of the tracker side (model/ROtracker.py:911-945, mp_slam/tracker.py): est_c2w16 <- c2w16 and,
+ * when rel_c2w16 is given (non-keyframes), rel_c2w16 <- c2w16 @ inverse(kf_c2w16), the pose relative to the newest
+ * keyframe.  All dev [16], row-major. */
+int rfx_frame_pose(const float* c2w16, const float* kf_c2w16, float* est_c2w16, float* rel_c2w16, rfx_stream stream);
 /* RBA.update_init_pose (model/rba.py:77-86): c2w16 dev [16] row-major pose of keyframe slot cam_id -> init_c2w16[cam_id],
  * init_t[cam_id] (translation), init_r[cam_id] (rotation as angle-axis).  init_r / init_t dev [num_cams,3], init_c2w16 dev
  * [num_cams,16]. */

@@ -130,6 +130,7 @@ PROTOTYPES = {
     "rfx_ba_forward_backward": (_i, [C.POINTER(BaDesc), _P, C.c_size_t, _P]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),
     "rfx_rba_grads_floats": (C.c_size_t, [_l]),
+    "rfx_frame_pose": (_i, [_P, _P, _P, _P, _P]),
     "rfx_rba_set_init_pose": (_i, [_P, _i, _i, _P, _P, _P, _P]),
     "rfx_rba_forward": (_i, [C.POINTER(RbaParams), _P, _P, _P, _l, _i, _f, _P, _P, _P]),
     "rfx_rba_backward": (_i, [C.POINTER(RbaParams), _P, _l, _P, _f, C.POINTER(RbaGrads), _P, _P]),

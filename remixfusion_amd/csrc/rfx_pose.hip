@@ -96,6 +96,42 @@ __global__ void rba_set_init_pose_kernel(const float* __restrict__ c2w, int cam,
     init_r[cam * 3] = aa[0]; init_r[cam * 3 + 1] = aa[1]; init_r[cam * 3 + 2] = aa[2];
 }
 
+// Per-frame pose bookkeeping of the tracker side (reference model/ROtracker.py:911-945 / mp_slam/tracker.py): store the frame's
+// pose, and for a non-keyframe its pose relative to the newest keyframe, delta = c2w @ inverse(kf_c2w) (general 4x4 inverse by
+// cofactors, like torch's .inverse()).  Thread = output element.
+__global__ void frame_pose_kernel(const float* __restrict__ c2w, const float* __restrict__ kf, float* __restrict__ est_out,
+                                  float* __restrict__ rel_out) {
+    __shared__ float inv[16];
+    const int t = threadIdx.x;
+    if (t < 16) est_out[t] = c2w[t];
+    if (!rel_out) return;
+    if (t < 16) {
+        // inv[r][c] = cofactor(c, r) / det
+        const int r = t >> 2, c = t & 3;
+        float mnr[9];
+        int q = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i == c) continue;
+            for (int j = 0; j < 4; ++j) {
+                if (j == r) continue;
+                mnr[q++] = kf[i * 4 + j];
+            }
+        }
+        const float cof = mnr[0] * (mnr[4] * mnr[8] - mnr[5] * mnr[7]) - mnr[1] * (mnr[3] * mnr[8] - mnr[5] * mnr[6]) +
+                          mnr[2] * (mnr[3] * mnr[7] - mnr[4] * mnr[6]);
+        inv[t] = ((r + c) & 1) ? -cof : cof;
+    }
+    __syncthreads();
+    if (t < 16) {
+        // det from the first row of kf and the first column of the adjugate
+        const float det = kf[0] * inv[0] + kf[1] * inv[4] + kf[2] * inv[8] + kf[3] * inv[12];
+        const int r = t >> 2, c = t & 3;
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a += c2w[r * 4 + k] * (inv[k * 4 + c] / det);
+        rel_out[t] = a;
+    }
+}
+
 struct RbaW {
     const float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;
 };
@@ -236,6 +272,13 @@ size_t rfx_rba_grads_floats(int64_t K) { return K > 0 ? (size_t)K * RBA_GRAD_LD 
 
 static bool rba_params_ok(const rfx_rba_params* p) {
     return p && p->w0 && p->b0 && p->w1 && p->b1 && p->w2 && p->b2 && p->w3 && p->b3 && p->hidden == RBA_H;
+}
+
+int rfx_frame_pose(const float* c2w16, const float* kf_c2w16, float* est_c2w16, float* rel_c2w16, rfx_stream stream) {
+    if (!c2w16 || !est_c2w16 || (rel_c2w16 && !kf_c2w16)) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(frame_pose_kernel, dim3(1), dim3(64), 0, as_stream(stream), c2w16, kf_c2w16, est_c2w16, rel_c2w16);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
 }
 
 int rfx_rba_set_init_pose(const float* c2w16, int cam_id, int num_cams, float* init_r, float* init_t, float* init_c2w16,

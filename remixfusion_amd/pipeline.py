@@ -11,6 +11,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from .datasets import get_dataset
 from .model.scene_rep import JointEncoding
 from .model.traj import Trajectory
@@ -65,7 +66,6 @@ class MappingPipeline:
             self.mv_stream = torch.cuda.Stream(device=self.device)
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
             self.mv.producer_stream = self.mv_stream     # readers on other streams (get_volume_all, ...) wait for it
-        self._kf_inv = (-1, None)       # inverse pose of the newest keyframe, reused by the frames that follow it
         self.frames_done = 0
 
     # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
@@ -113,15 +113,20 @@ class MappingPipeline:
             c2w_dev = batch.get("c2w_dev")
             if c2w_dev is None:
                 c2w_dev = c2w.to(self.device)
-            self.slam.est_c2w_data[i] = c2w_dev
             ke = self.config["mapping"]["keyframe_every"]
-            if i % ke != 0:     # relative pose to the last keyframe, like the tracker stores it
+            est, rel = self.slam.est_c2w_data, self.slam.est_c2w_data_rel
+            if est.is_cuda and est.dtype == torch.float32 and est.is_contiguous() and rel.is_contiguous():
+                # one launch: est[i] <- c2w, and for a non-keyframe rel[i] <- c2w @ inverse(est[newest keyframe]), the pose
+                # relative to the last keyframe, like the tracker stores it
+                c2w_dev = c2w_dev.to(torch.float32).contiguous()
                 k = (i // ke) * ke
-                if self._kf_inv[0] != k:
-                    # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop.  The newest keyframe's
-                    # pose only changes in a mapper step that refines the current frame (mapping.optim_cur), see step()
-                    self._kf_inv = (k, torch.linalg.inv_ex(self.slam.est_c2w_data[k]).inverse)
-                self.slam.est_c2w_data_rel[i] = c2w_dev @ self._kf_inv[1]
+                _lib.check(_lib.load().rfx_frame_pose(_lib.ptr(c2w_dev), _lib.ptr(est[k]) if i % ke else None, _lib.ptr(est[i]),
+                                                      _lib.ptr(rel[i]) if i % ke else None, _lib.stream_ptr(self.device)), "rfx_frame_pose")
+            else:
+                est[i] = c2w_dev
+                if i % ke != 0:
+                    # inv_ex: no host-side singularity check, i.e. no device sync in the frame loop
+                    rel[i] = c2w_dev @ torch.linalg.inv_ex(est[(i // ke) * ke]).inverse
             self.slam.tracking_idx[0] = i
 
     def _integrate(self, i, batch, rgb255, pose_np):
@@ -145,6 +150,4 @@ class MappingPipeline:
             # the reference's mapper wakes when tracking_idx > mapping_idx + map_every (mapper.py:879)
             if i > int(self.slam.mapping_idx[0]) + m["map_every"] and cur < len(self.dataset):
                 self.mapper.step(cur)
-                if m["optim_cur"]:
-                    self._kf_inv = (-1, None)
         self.frames_done += 1

@@ -41,6 +41,33 @@ def test_fused_rba_matches_torch_ops(scale):
     assert float(gr[2].abs().max()) > 0
 
 
+def test_frame_pose_kernel_matches_torch_inverse():
+    """rfx_frame_pose: est <- c2w, rel <- c2w @ inverse(kf) (the tracker-side bookkeeping of one frame)."""
+    from remixfusion_amd import _lib as L
+    from remixfusion_amd.model.rba import angle_axis_to_rotation_matrix
+    lib = L.load()
+    g = torch.Generator().manual_seed(2)
+    st = L.stream_ptr(torch.device("cuda"))
+    for trial in range(6):
+        def pose():
+            P = torch.eye(4)
+            P[:3, :3] = angle_axis_to_rotation_matrix(torch.randn((1, 3), generator=g) * 0.7)[0]
+            P[:3, 3] = torch.randn(3, generator=g) * 2.0
+            if trial == 5:
+                P[:3, :3] = P[:3, :3] * 1.01 + 0.001 * torch.randn((3, 3), generator=g)     # not exactly rigid
+            return P
+        c2w, kf = pose().cuda(), pose().cuda()
+        est, rel = torch.zeros((4, 4), device="cuda"), torch.zeros((4, 4), device="cuda")
+        assert lib.rfx_frame_pose(L.ptr(c2w), L.ptr(kf), L.ptr(est), L.ptr(rel), st) == 0
+        ref = (c2w.double() @ torch.linalg.inv(kf.double())).float()
+        assert torch.equal(est, c2w)
+        assert float((rel - ref).abs().max()) < 2e-5, trial
+        est2 = torch.zeros((4, 4), device="cuda")
+        assert lib.rfx_frame_pose(L.ptr(c2w), None, L.ptr(est2), None, st) == 0 and torch.equal(est2, c2w)
+    assert lib.rfx_frame_pose(None, None, L.ptr(est), None, st) == -1
+    assert lib.rfx_frame_pose(L.ptr(c2w), None, L.ptr(est), L.ptr(rel), st) == -1
+
+
 def test_set_init_pose_kernel_matches_the_tensor_formulation():
     """RBA.update_init_pose on the device is one librfx launch; same init_c2w / init_t / init_r as the tensor-op
     formulation (model/rba.py::rotation_matrix_to_angle_axis), incl. tiny rotations and rotations next to pi."""
