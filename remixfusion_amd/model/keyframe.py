@@ -76,7 +76,9 @@ class KeyFrameDatabase(object):
 
     def add_keyframe(self, batch, filter_depth=False):
         first = bool(batch["frame_id"] == 0)
-        rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+        rays = batch.get("_rays7")                      # built once per mapper step (Mapper.step)
+        if rays is None:
+            rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         rays = rays.reshape(1, -1, rays.shape[-1]).to(self.device)
         rays = self.sample_single_keyframe_rays(rays, "filter_depth" if filter_depth else "random", first=first)
         fid = batch["frame_id"]

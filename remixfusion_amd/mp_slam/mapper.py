@@ -199,14 +199,22 @@ class Mapper:
         n_cur = max(m["sample"] // len(self.keyframe.frame_ids), m["min_pixels_cur"])
         return _RayBatchFn.apply(poses_all, self.keyframe, current_rays, m["sample"], n_cur, m["keyframe_every"])
 
+    def _current_rays(self, batch):
+        """[H*W, 7] rays of the frame (camera direction | rgb | depth); step() builds them once for both phases and the
+        keyframe store (batch["_rays7"])."""
+        r = batch.get("_rays7")
+        if r is None:
+            r = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+            r = r.reshape(-1, r.shape[-1]).to(self.device)
+        return r
+
     def global_mapping(self, batch, cur_frame_id):
         """map update over all keyframes + the current frame (reference :366-423)."""
         m = self.config["mapping"]
         poses = self.est_c2w_data[0:cur_frame_id + 1:m["keyframe_every"]].clone()
         self.map_optimizer.zero_grad()
         self.rba_optimizer.zero_grad()
-        current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
-        current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
+        current_rays = self._current_rays(batch)
         with torch.no_grad():
             last_kf_id = torch.full((1, 1), cur_frame_id // m["keyframe_every"], dtype=torch.int64, device=self.device)
             poses_all = poses
@@ -234,8 +242,7 @@ class Mapper:
         frame_ids_all = list(range(0, cur_frame_id + 1, m["keyframe_every"]))
         self.map_optimizer.zero_grad()
         self.rba_optimizer.zero_grad()
-        current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
-        current_rays = current_rays.reshape(-1, current_rays.shape[-1]).to(self.device)
+        current_rays = self._current_rays(batch)
         all_index = torch.arange(0, poses.shape[0] + 1, device=self.device).unsqueeze(-1)
         direct = self._direct_iterations() if m["opt_pose"] else None
         if direct is not None:
@@ -310,6 +317,7 @@ class Mapper:
         if int(self.mapping_idx[0]) % ke == 0:
             self.model.rba.update_init_pose(int(current_map_id // ke), self.est_c2w_data[current_map_id])
             self.integrate_kf(batch, self.est_c2w_data[current_map_id])
+        batch["_rays7"] = self._current_rays(batch)
         self.global_mapping(batch, current_map_id)
         self.global_pose(batch, current_map_id)
         self.mapping_idx[0] = current_map_id
