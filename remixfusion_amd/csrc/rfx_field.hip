@@ -305,8 +305,21 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
     float2* __restrict__ planes = reinterpret_cast<float2*>(scratch);
     float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
     if (live) {
-        const float2* __restrict__ row = reinterpret_cast<const float2*>(src.dfeat + p * (int64_t)src.ld);
-        for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
+        const float* __restrict__ rowf = src.dfeat + p * (int64_t)src.ld;
+        if (n_levels == RFX_MAX_LEVELS && (src.ld & 3) == 0 && (((uintptr_t)src.dfeat) & 15) == 0) {
+            // the whole 128-byte row in eight 16-byte loads issued together, then the sixteen plane stores
+            float4 r4[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r4[q] = reinterpret_cast<const float4*>(rowf)[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
+                planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
+            }
+        } else {
+            const float2* __restrict__ row = reinterpret_cast<const float2*>(rowf);
+            for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
+        }
         xs[s] = src.x01[p * 3]; xs[slots + s] = src.x01[p * 3 + 1]; xs[2 * slots + s] = src.x01[p * 3 + 2];
     } else {
         for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
