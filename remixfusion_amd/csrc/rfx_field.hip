@@ -885,7 +885,10 @@ __global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __
     for (int d = 0; d < 3; ++d) {
         float g[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) g[k] = row[32 + 16 * d + k];
+        for (int q = 0; q < 4; ++q) {           // rows are 384-byte aligned: 16-byte loads
+            const float4 v = reinterpret_cast<const float4*>(row + 32 + 16 * d)[q];
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
         dx[d] = oneblob_dim_dx<16>(x[d], g);
     }
     const float4 dr = reinterpret_cast<const float4*>(draw4)[p];
@@ -893,7 +896,8 @@ __global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __
     const float4 ex = lookup4(f.gbv, f.gbv_level, x);
     float t = ex.x * f.c_trunc;
     t = t / f.trunc;
-    const float d_cin = row[80];
+    const float4 tailv = reinterpret_cast<const float4*>(row + 80)[0];      // d_cin, d_ex_rgb
+    const float d_cin = tailv.x;
     float d_t;
     if (f.clamp_mode) {
         const bool in_hi = (t >= -f.clamp_hi) && (t <= f.clamp_hi);
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __
         const bool in_one = (t >= -1.0f) && (t <= 1.0f);
         d_t = in_one ? (dr.w + d_cin) : 0.f;
     }
-    const float gex[4] = {d_t * f.c_trunc / f.trunc, row[81] + dr.x, row[82] + dr.y, row[83] + dr.z};
+    const float gex[4] = {d_t * f.c_trunc / f.trunc, tailv.y + dr.x, tailv.z + dr.y, tailv.w + dr.z};
     lookup_dx<4>(f.gbv, f.gbv_level, x, gex, dx);
     dx01[p * 3] += dx[0]; dx01[p * 3 + 1] += dx[1]; dx01[p * 3 + 2] += dx[2];
 }
