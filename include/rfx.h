@@ -144,7 +144,9 @@ typedef struct rfx_field_desc {
     float         trunc;
     float         clamp_hi;             /* mapping.clamp when clamp mode is on, else 1       */
     int32_t       clamp_mode;           /* JointEncoding.clamp (scene_rep.py:332-337)        */
-    int32_t       pos_fp16;             /* 1 = round OneBlob outputs to fp16 (tcnn default)  */
+    int32_t       pos_fp16;             /* 0 = fp32 OneBlob (the reference: model/encodings.py:73
+                                           passes dtype=torch.float); 1 = opt-in: outputs rounded
+                                           to fp16 and fed to the fp16 matrix pipe              */
     const float*  staged;               /* optional dev [rfx_field_staged_floats()]: w1..w4 in
                                            MFMA operand order, written by rfx_field_stage_weights
                                            for the CURRENT weights; NULL = every block re-derives

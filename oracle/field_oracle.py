@@ -36,8 +36,11 @@ Conventions restated from tiny-cuda-nn:
   * output [B, L*F] level-major ; all integer arithmetic wraps at 32 bits.
   * OneBlob: out[d*n+k] = L(k+1) - L(k), L(k) = cdf(k/n-x)+cdf(k/n-x-1)+cdf(k/n-x+1),
     L(n) := L(0)+1, cdf(t) = clamp(15/16*u*(1-2/3u^2+1/5u^4)+1/2, 0, 1), u = t*n.
-    The reference constructs OneBlob without ``dtype`` (model/encodings.py:67-74), so
-    tinycudann emits fp16; ``pos_fp16=True`` rounds the 48 outputs to fp16 and back.
+    The reference constructs OneBlob with ``dtype=torch.float`` (model/encodings.py:67-74, the
+    ``dtype`` argument is on line 73), i.e. tinycudann Precision.Fp32: the 48 outputs are fp32 and
+    ``pos_fp16=False`` is the reference behaviour.  ``pos_fp16=True`` (rounding the outputs to fp16
+    and back) models tinycudann's *default* half-precision output and is kept only as the oracle of
+    the product's explicit opt-in fast path.
 """
 from __future__ import annotations
 
@@ -160,7 +163,7 @@ def _quartic_cdf(t: torch.Tensor, n: int) -> torch.Tensor:
     return torch.clamp((15.0 / 16.0) * u * (1.0 - (2.0 / 3.0) * u2 + (1.0 / 5.0) * u4) + 0.5, 0.0, 1.0)
 
 
-def oneblob_encode(x: torch.Tensor, n_bins: int = 16, pos_fp16: bool = True) -> torch.Tensor:
+def oneblob_encode(x: torch.Tensor, n_bins: int = 16, pos_fp16: bool = False) -> torch.Tensor:
     """x [B,3] -> [B, 3*n_bins], dim-major."""
     B, D = x.shape
     k = torch.arange(n_bins + 1, dtype=torch.float32) / float(n_bins)       # boundaries 0..1
@@ -169,7 +172,7 @@ def oneblob_encode(x: torch.Tensor, n_bins: int = 16, pos_fp16: bool = True) -> 
     right = torch.cat([Lk[:, :, 1:], Lk[:, :, :1] + 1.0], dim=-1)
     out = (right - Lk).reshape(B, D * n_bins)
     if pos_fp16:
-        # straight-through rounding to half precision (tinycudann default output precision)
+        # straight-through rounding to half precision (NOT the reference: opt-in fast path only)
         out = out + (out.detach().to(torch.float16).to(torch.float32) - out.detach())
     return out
 
@@ -200,7 +203,7 @@ class FieldParams:
     trunc: float
     map_clamp: float = 1.0
     n_bins: int = 16
-    pos_fp16: bool = True
+    pos_fp16: bool = False        # reference: fp32 OneBlob (model/encodings.py:73)
 
 
 def query_color_sdf(fp: FieldParams, x01: torch.Tensor, clamp: bool = False) -> torch.Tensor:

@@ -21,7 +21,7 @@ HEADERS = ["rfx_common.h", "rfx_field_device.h", "rfx_field_mlp.h", os.path.join
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function", "-DHASH_GROUP=4", "-DFWD_WAVES=2", "-DRENDER_WAVES=3", "-DBWD_WAVES=2",
+    "-Wall", "-Wno-unused-function", "-DHASH_GROUP=4", "-DFWD_WAVES=2", "-DRENDER_WAVES=2", "-DBWD_WAVES=2",
 ]
 
 
@@ -40,8 +40,17 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra: List[str] | None = None) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra: List[str] | None = None, out: str | None = None) -> str:
+    """``extra``/``out``: A/B builds (tools/build_variant.py) -- later -D flags override the defaults above; such a
+    library is selected at run time with RFX_LIB_PATH (see _lib.py)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if out is not None:
+        cmd = [_hipcc()] + FLAGS + (extra or []) + ["-o", out] + srcs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("hipcc failed building " + out)
+        return out
     if not force and not _stale():
         return LIB
     cmd = [_hipcc()] + FLAGS + (extra or []) + ["-o", LIB + ".tmp"] + srcs

@@ -21,7 +21,9 @@ namespace rfx {
 #define BWD_WAVES 2
 #endif
 constexpr int N_EMB = 32, N_POS = 48, N_IN1 = 81, N_H = 32, N_OUT2 = 16, N_IN3 = 66, N_OUT4 = 3;
-constexpr int S1 = 41, S2 = 16, S3 = 34, S4 = 16;
+constexpr int NPOS_SLOTS = 27;      // pos region of a layer: 48 columns x 36 floats (sparse fp32 image); the fp16 form uses 24
+constexpr int POS_STRIDE = 36;      // floats per column of the sparse image (32 + 4 pad: conflict-free ds_read_b128)
+constexpr int S1 = 16 + NPOS_SLOTS + 1, S2 = 16, S3 = NPOS_SLOTS + 10, S4 = 16;
 constexpr int OFF1 = 0, OFF2 = OFF1 + S1, OFF3 = OFF2 + S2, OFF4 = OFF3 + S3, FWD_SLOTS = OFF4 + S4;   // 107
 constexpr int OFFB4 = FWD_SLOTS, OFFB3 = OFFB4 + 2, OFFB2 = OFFB3 + 48, OFFB1 = OFFB2 + 9, ALL_SLOTS = OFFB1 + 48;  // 214
 
@@ -69,25 +71,49 @@ __device__ inline float packed_pos_weight(const float* __restrict__ w, int ld, i
     return __uint_as_float(pack_half2(w16_part(row[0], part), w16_part(row[1], part)));
 }
 
+// ---- OneBlob x weights as a sparse fp32 dot product (pos_fp16 = 0: the reference's precision) -----------
+// The reference builds OneBlob with dtype=torch.float (model/encodings.py:73): 48 fp32 inputs.  With 16 bins the
+// kernel is one bin wide, so at most THREE bins per coordinate are non-zero: W[:, pos cols] . pos is a 9-term dot
+// product per hidden unit, 288 fp32 FMAs per point and layer on the VALU, instead of 24 k-steps x 2 tiles of
+// v_mfma_f32_32x32x2_f32 (3 072 matrix-pipe cycles per wave and layer) that multiply 39 zeros per point.
+// The result initialises the layer's accumulator tiles; the remaining inputs follow on the matrix pipe.
+// LDS image of one layer's pos columns (NPOS_SLOTS slots = 1 728 floats): column col occupies POS_STRIDE = 36 floats,
+//   float 36 col + a (a < 32) = W[row(a)][col], row(a) = krow(a, 0) for a < 16, krow(a - 16, 1) for a >= 16
+//   (so acc[0..15] / acc[16..31] become the two D-layout tiles with one v_permlane32_swap per register).
+// A lane reads its column with eight ds_read_b128 at immediate offsets from ONE address register.  36 col mod 64
+// takes sixteen different multiples of 4 over the sixteen columns of a coordinate, so the sixteen 4-bank windows
+// of lanes that pick different columns never overlap: conflict-free (same column = same address = broadcast).
+__device__ inline float sparse_pos_weight(const float* __restrict__ w, int ld, int col0, int i) {
+    const int col = i / POS_STRIDE, a = i % POS_STRIDE;
+    if (col >= N_POS || a >= 32) return 0.f;
+    const int m = a < 16 ? krow(a, 0) : krow(a - 16, 1);
+    return w[m * ld + col0 + col];
+}
+
 // value of staged slot `slot`, lane `l` (see header comment of each layer below)
 __device__ inline float staged_weight(const FieldK& f, int slot, int l) {
     const int lo = l & 31, h = l >> 5;
-    if (f.pos_fp16) {
-        if (slot >= OFF1 + 16 && slot < OFF1 + 40) return packed_pos_weight(f.w1, N_IN1, N_EMB, (slot - (OFF1 + 16)) * 64 + l);
-        if (slot >= OFF3 && slot < OFF3 + 24) return packed_pos_weight(f.w3, N_IN3, 0, (slot - OFF3) * 64 + l);
+    if (slot >= OFF1 + 16 && slot < OFF1 + 16 + NPOS_SLOTS) {
+        const int i = (slot - (OFF1 + 16)) * 64 + l;
+        return f.pos_fp16 ? (i < 24 * 64 ? packed_pos_weight(f.w1, N_IN1, N_EMB, i) : 0.f) : sparse_pos_weight(f.w1, N_IN1, N_EMB, i);
     }
-    if (slot < OFF2) {                       // L1: A[hid][k=2s+h] = W1[hid][k]
-        const int k = 2 * (slot - OFF1) + h;
-        return k < N_IN1 ? f.w1[lo * N_IN1 + k] : 0.f;
+    if (slot >= OFF3 && slot < OFF3 + NPOS_SLOTS) {
+        const int i = (slot - OFF3) * 64 + l;
+        return f.pos_fp16 ? (i < 24 * 64 ? packed_pos_weight(f.w3, N_IN3, 0, i) : 0.f) : sparse_pos_weight(f.w3, N_IN3, 0, i);
+    }
+    if (slot < OFF2) {                       // L1: A[hid][k=2s+h] = W1[hid][k]: 16 hash-level slots, [pos region], (cin, 0)
+        const int s = slot - OFF1;
+        const int k = s < 16 ? 2 * s + h : (h == 0 ? N_EMB + N_POS : -1);
+        return k >= 0 ? f.w1[lo * N_IN1 + k] : 0.f;
     } else if (slot < OFF3) {                // L2: k-slot r = previous accumulator register r
         const int k = krow(slot - OFF2, h);
         return lo < N_OUT2 ? f.w2[lo * N_H + k] : 0.f;
     } else if (slot < OFF4) {                // L3: [pos pairs | h2 regs 0..7 (out o -> geo o-1) | ex_r,ex_g | ex_b,0]
         const int s = slot - OFF3;
         int k;
-        if (s < 24) k = 2 * s + h;
-        else if (s < 32) { const int o = krow(s - 24, h); k = o >= 1 ? N_POS + o - 1 : -1; }
-        else if (s == 32) k = 63 + h;
+        if (s < NPOS_SLOTS) k = -1;            // pos region: handled above
+        else if (s < NPOS_SLOTS + 8) { const int o = krow(s - NPOS_SLOTS, h); k = o >= 1 ? N_POS + o - 1 : -1; }
+        else if (s == NPOS_SLOTS + 8) k = 63 + h;
         else k = h == 0 ? 65 : -1;
         return k >= 0 ? f.w3[lo * N_IN3 + k] : 0.f;
     } else if (slot < OFFB4) {               // L4 runs on the VALU (3 of 32 rows would be used on the MFMA):
@@ -127,7 +153,6 @@ __device__ inline void stage_weights(const FieldK& f, float* wl, int n_slots) {
 
 // ---------------------------------------------------------------- per-point encodings (own-point layout)
 struct Enc {
-    float pos[N_POS];
     unsigned pos16[N_POS / 2];   // POS16 path: fp16 pairs; after mlp_forward_123: tile-operand form
     float ex[4];      // GBV (tsdf in c_trunc units, r, g, b)
     float tres;       // tsdf rescaled/clamped: the residual added to the sdf output
@@ -147,7 +172,7 @@ __device__ __forceinline__ void encode_point(const FieldK& f, const float x[3], 
         e.cin = t;
     }
     e.tres = t;
-    // e.pos is filled by mlp_forward_123 after the hash levels (keeps the gather phase lean)
+    // OneBlob is evaluated inside mlp_forward_123
 }
 
 // ---------------------------------------------------------------- MLP forward on the matrix cores
@@ -157,7 +182,9 @@ struct Mlp {
 
 // Hash-grid levels are looked up and fed to the matrix cores level by level (level l = k-step l),
 // so the 32 features are never all live.  STAGE: also write them to x1row (backward staging).
-// consumes e.cin / e.ex; computes OneBlob itself (POS16: packed fp16 fragments in e.pos16, else fp32 e.pos in
+// consumes e.cin / e.ex; computes OneBlob itself (POS16: packed fp16 fragments in e.pos16, else the nine non-zero fp32 bins,
+// multiplied on the VALU: sparse_pos_tiles)
+// (historic note, dense fp32 form: e.pos in
 // tile-operand form).  STAGE also writes pos (own-point fp32) to x1row[32..79].
 // OneBlob (16 bins) of one coordinate as 16 fp16 values in 8 dwords (half k in dword k/2): the values of
 // oneblob_dim<16>(x, fp16 = true) (to within 2^-24 absolute: a boundary a hair outside the kernel can round one
@@ -226,6 +253,88 @@ __device__ __forceinline__ void scale16(f32x16& t, float s) {
     for (int r = 0; r < 16; ++r) t[r] *= s;
 }
 
+// OneBlob of one coordinate in sparse fp32 form.  tinycudann's formula (oracle/field_oracle.py::oneblob_encode):
+//   out[k] = L(k+1) - L(k),  L(k) = cdf(k/16 - x) + cdf(k/16 - x - 1) + cdf(k/16 - x + 1),  L(16) := L(0) + 1,
+// evaluated per boundary by oneblob_L16 (valid for every x).  The three kernel copies share frac(x), so the only
+// boundaries that are not saturated are those next to kb = floor(16 frac(x)): bins c0 = kb-1, c1 = kb, c2 = kb+1
+// (mod 16) carry the values, evaluated literally (wrap rule included).  The bins sum to L(16) - L(0) = 1 by
+// construction and are all >= 0, so whatever the three do not hold sits in bin 15 through the wrap rule: for x inside
+// about (-0.94, 1.94) that remainder is rounding noise (|.| < 1e-6, dropped below 4e-6 so that a point's result never
+// depends on its wave neighbours), for points far outside the bound it is the whole unit mass (tinycudann's e_15).
+// It is carried as a fourth (column, value) pair per coordinate that a wave multiplies only if some lane needs it.
+struct PosBins {
+    float v[9];        // [3 d + j]: values of the three bins around x[d]
+    int c[9];          // their columns 16 d + bin
+    float rest[3];     // value of column 16 d + 15 not covered by v (0 in range)
+};
+__device__ __forceinline__ void oneblob_dim_sparse(float x, int d, PosBins& pb) {
+    const float y = x - floorf(x);
+    int kb = (int)floorf(y * 16.0f);
+    kb = min(max(kb, 0), 15);
+    const int c0 = (kb + 15) & 15, c1 = kb, c2 = (kb + 1) & 15, c3 = (kb + 2) & 15;
+    const float L0 = oneblob_L16(c0, x), L1 = oneblob_L16(c1, x), L2 = oneblob_L16(c2, x), L3 = oneblob_L16(c3, x);
+    const float v0 = ((c1 == 0) ? L1 + 1.0f : L1) - L0;      // out[c0] = L(c0 + 1) - L(c0), L(16) = L(0) + 1
+    const float v1 = ((c2 == 0) ? L2 + 1.0f : L2) - L1;
+    const float v2 = ((c3 == 0) ? L3 + 1.0f : L3) - L2;
+    pb.v[3 * d + 0] = v0; pb.v[3 * d + 1] = v1; pb.v[3 * d + 2] = v2;
+    pb.c[3 * d + 0] = 16 * d + c0; pb.c[3 * d + 1] = 16 * d + c1; pb.c[3 * d + 2] = 16 * d + c2;
+    const float rest = 1.0f - ((v0 + v1) + v2);
+    const bool has15 = c0 == 15 || c1 == 15 || c2 == 15;
+    pb.rest[d] = (!has15 && fabsf(rest) > 4e-6f) ? rest : 0.0f;
+}
+
+// the dense 16 bins of coordinate d (backward staging, standalone encoder): zeros except the pairs of pb
+__device__ __forceinline__ void oneblob_dense_from_sparse(const PosBins& pb, int d, float full[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int col = 16 * d + k;
+        float v = col == pb.c[3 * d] ? pb.v[3 * d] : (col == pb.c[3 * d + 1] ? pb.v[3 * d + 1]
+                 : (col == pb.c[3 * d + 2] ? pb.v[3 * d + 2] : 0.f));
+        if (k == 15) v += pb.rest[d];
+        full[k] = v;
+    }
+}
+
+// acc[a] += v * W[row(a)][col] for the 32 accumulator positions; wp = the layer's sparse image
+__device__ __forceinline__ void sparse_col_fma(const float* __restrict__ wp, int col, float v, float acc[32]) {
+    const float* __restrict__ base = wp + col * POS_STRIDE;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(base + 4 * q);
+        acc[4 * q] = fmaf(v, w.x, acc[4 * q]); acc[4 * q + 1] = fmaf(v, w.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(v, w.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v, w.w, acc[4 * q + 3]);
+    }
+}
+
+// (t0, t1) += W[:, pos cols] . OneBlob(x) as D-layout tiles.  `extra` (wave-uniform): some lane has a non-zero
+// pb.rest (a point far outside the scene bound): three more columns, wave-uniform addresses (LDS broadcast).
+__device__ __forceinline__ void sparse_pos_tiles(const float* __restrict__ wp, const PosBins& pb, bool extra,
+                                                 f32x16& t0, f32x16& t1) {
+    float acc[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) acc[a] = 0.f;
+    // one column (8 x ds_read_b128 + 32 FMAs) at a time: left alone, the scheduler hoists all 72 reads of the nine
+    // columns to the top (288 live registers, spills)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        sparse_col_fma(wp, pb.c[j], pb.v[j], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (extra) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sparse_col_fma(wp, 16 * d + 15, pb.rest[d], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = acc[r], b = acc[16 + r];
+        swap32(a, b);           // a: [own half-0 rows | lower partner's half-1 rows] = tile 0;  b = tile 1
+        t0[r] += a; t1[r] += b;
+    }
+}
+
 template <bool STAGE, bool POS16>
 __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
                                                 int lane, Enc& e, Mlp& m, float* x1row = nullptr,
@@ -274,26 +383,28 @@ RFX_UNROLL(HASH_GROUP)
         m.h1[0] = mfma32(w, a, m.h1[0]);
         m.h1[1] = mfma32(w, b, m.h1[1]);
     }
+    PosBins pb;
+    bool extra = false;
     if (!POS16) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) oneblob_dim<16>(x[d], false, e.pos + 16 * d);
-        if (STAGE && valid) {
+        for (int d = 0; d < 3; ++d) oneblob_dim_sparse(x[d], d, pb);
+        extra = __any(pb.rest[0] != 0.0f || pb.rest[1] != 0.0f || pb.rest[2] != 0.0f) != 0;
+        if (STAGE && valid) {       // dense fp32 row for the weight-gradient kernel
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
-                *reinterpret_cast<float4*>(x1row + N_EMB + 4 * i) = make_float4(e.pos[4 * i], e.pos[4 * i + 1], e.pos[4 * i + 2], e.pos[4 * i + 3]);
-        }
+            for (int d = 0; d < 3; ++d) {
+                float full[16];
+                oneblob_dense_from_sparse(pb, d, full);
 #pragma unroll
-        for (int s = 0; s < 24; ++s) {
-            swap32(e.pos[2 * s], e.pos[2 * s + 1]);
-            const float w = wl[(OFF1 + 16 + s) * 64 + lane];
-            m.h1[0] = mfma32(w, e.pos[2 * s], m.h1[0]);
-            m.h1[1] = mfma32(w, e.pos[2 * s + 1], m.h1[1]);
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) = make_float4(full[4 * i], full[4 * i + 1], full[4 * i + 2], full[4 * i + 3]);
+            }
         }
+        sparse_pos_tiles(wl + (OFF1 + 16) * 64, pb, extra, m.h1[0], m.h1[1]);
     }
     {
         float a = e.cin, b = 0.f;
         swap32(a, b);
-        const float w = wl[(OFF1 + 40) * 64 + lane];
+        const float w = wl[(OFF1 + 16 + NPOS_SLOTS) * 64 + lane];
         m.h1[0] = mfma32(w, a, m.h1[0]);
         m.h1[1] = mfma32(w, b, m.h1[1]);
     }
@@ -314,28 +425,23 @@ RFX_UNROLL(HASH_GROUP)
         scale16(m.h3[0], 1.0f / POS_LO_SCALE); scale16(m.h3[1], 1.0f / POS_LO_SCALE);
         pos_mfma16(wl, OFF3, 1, lane, e.pos16, m.h3[0], m.h3[1]);
     } else {
-#pragma unroll
-        for (int s = 0; s < 24; ++s) {
-            const float w = wl[(OFF3 + s) * 64 + lane];
-            m.h3[0] = mfma32(w, e.pos[2 * s], m.h3[0]);
-            m.h3[1] = mfma32(w, e.pos[2 * s + 1], m.h3[1]);
-        }
+        sparse_pos_tiles(wl + OFF3 * 64, pb, extra, m.h3[0], m.h3[1]);
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const float w = wl[(OFF3 + 24 + r) * 64 + lane];
+        const float w = wl[(OFF3 + NPOS_SLOTS + r) * 64 + lane];
         m.h3[0] = mfma32(w, m.h2[0][r], m.h3[0]);
         m.h3[1] = mfma32(w, m.h2[1][r], m.h3[1]);
     }
     {
         float a = e.ex[1], b = e.ex[2];
         swap32(a, b);
-        float w = wl[(OFF3 + 32) * 64 + lane];
+        float w = wl[(OFF3 + NPOS_SLOTS + 8) * 64 + lane];
         m.h3[0] = mfma32(w, a, m.h3[0]);
         m.h3[1] = mfma32(w, b, m.h3[1]);
         a = e.ex[3]; b = 0.f;
         swap32(a, b);
-        w = wl[(OFF3 + 33) * 64 + lane];
+        w = wl[(OFF3 + NPOS_SLOTS + 9) * 64 + lane];
         m.h3[0] = mfma32(w, a, m.h3[0]);
         m.h3[1] = mfma32(w, b, m.h3[1]);
     }

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, RENDER_WAVES) void render_rays_kernel(FieldK f
             mlp_forward_4(wl, lane, e, m, raw);
             rv[c] = make_float4(raw[0], raw[1], raw[2], raw[3]);
             sdf[c] = raw[3];
+            __builtin_amdgcn_sched_barrier(0);       // S > 64: do not interleave the two chunks (register pressure)
         }
         __builtin_amdgcn_wave_barrier();
         const RayW rw = ray_weights(sdf, z, valid, S, lane, f.trunc, sc);

@@ -115,10 +115,12 @@ class DenseGrid(GridEncoding):
 
 class OneBlob(nn.Module):
     """tcnn OneBlob (n_bins=16).  No parameters; ``params`` is an empty tensor like tcnn's.
-    The reference builds it without ``dtype`` so tinycudann emits fp16; ``fp16=True`` reproduces
-    that rounding (values are returned as fp32)."""
+    The reference builds it with ``dtype=torch.float`` (model/encodings.py:65-76, line 73), so the
+    48 outputs are fp32 and that is the default here.  ``fp16=True`` is an explicit opt-in that
+    rounds the outputs to half precision (tinycudann's own default output type, NOT what the
+    reference selects) and lets the fused kernels run these columns on the fp16 matrix pipe."""
 
-    def __init__(self, n_bins=16, fp16=True):
+    def __init__(self, n_bins=16, fp16=False):
         super().__init__()
         if n_bins != 16:
             raise NotImplementedError("librfx implements n_bins=16 (every reference config)")

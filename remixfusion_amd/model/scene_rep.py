@@ -285,7 +285,7 @@ class JointEncoding(nn.Module):
         d.tsdf_scale = d.c_trunc / d.trunc
         d.clamp_mode = 1 if clamp else 0
         d.clamp_hi = float(self.config["mapping"]["clamp"]) if clamp else 1.0
-        d.pos_fp16 = 1 if getattr(self.embedpos_fn, "fp16", True) else 0
+        d.pos_fp16 = 1 if getattr(self.embedpos_fn, "fp16", False) else 0
         d.staged = self._staged_weights(d, (w1, w2, w3, w4))
         return d
 

@@ -154,7 +154,7 @@ def make_mapping():
         gbv = torch.rand(R ** 3 * 4, generator=g)
         gbv[0::4] = gbv[0::4] * 2.4 - 1.2
         m.embed_res_fn = _Enc(lambda x: FO.grid_encode(x, table, meta))
-        m.embedpos_fn = _Enc(lambda x: FO.oneblob_encode(x, 16, True))
+        m.embedpos_fn = _Enc(lambda x: FO.oneblob_encode(x, 16, False))   # reference: fp32 (model/encodings.py:73)
         m.GBV = _Enc(lambda x: FO.grid_encode(x, gbv, FO.dense_meta(R, 4)))
         torch.manual_seed(5)
         m.decoder_res = ColorSDFNet(cfg, input_ch=32, input_ch_pos=48)

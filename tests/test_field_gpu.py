@@ -48,7 +48,7 @@ def _oracle_params(cfg, m):
                           gbv=m.GBV.params.detach().cpu().clone(), gbw=m.GBW.params.detach().cpu().clone(),
                           gbv_res=cfg["globalV"]["base_resolution"], W1=w1, W2=w2, W3=w3, W4=w4,
                           c_trunc=cfg["training"]["c_trunc"], trunc=cfg["training"]["trunc"],
-                          map_clamp=cfg["mapping"]["clamp"], n_bins=16, pos_fp16=True)
+                          map_clamp=cfg["mapping"]["clamp"], n_bins=16, pos_fp16=False)     # reference: fp32 OneBlob
 
 
 def _points(n, seed=0, lo=-0.15, hi=1.15):
@@ -120,14 +120,16 @@ def test_oneblob_forward():
     assert int((fast != 0).sum(1).max()) <= 12
 
 
-@pytest.mark.parametrize("clamp,pos_fp16", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("clamp,pos_fp16", [(False, False), (True, False), (True, True)])
 def test_field_forward_matches_oracle(clamp, pos_fp16):
-    """pos_fp16=True (tinycudann default): OneBlob on the fp16 matrix pipe with hi/lo-split weights;
-    False: all-fp32 path."""
+    """pos_fp16=False: the default and the reference's precision (fp32 OneBlob, model/encodings.py:73; every operand of
+    the MLP in fp32).  pos_fp16=True: the explicit opt-in (OneBlob rounded to fp16, on the fp16 matrix pipe with
+    hi/lo-split weights), compared with an oracle that applies the same rounding."""
     cfg, m = _model()
     cfg["mapping"]["clamp"] = 1.5
     fp = _oracle_params(cfg, m)
     fp.map_clamp = 1.5
+    assert m.embedpos_fn.fp16 is False and fp.pos_fp16 is False and m._field_desc(False).pos_fp16 == 0     # the defaults
     fp.pos_fp16 = pos_fp16
     m.embedpos_fn.fp16 = pos_fp16
     for n in (1, 63, 64, 65, 1000, 4133):
@@ -136,6 +138,18 @@ def test_field_forward_matches_oracle(clamp, pos_fp16):
         got = m.query_color_sdf(x.cuda())
         ref = FO.query_color_sdf(fp, x, clamp)
         _close(got, ref, 1e-4, 2e-5, f"raw4 n={n} clamp={clamp}")
+
+
+def test_field_forward_points_far_outside_the_bound():
+    """OneBlob's sparse fp32 form (three bins per coordinate) holds for x in [-0.5, 1.5); a wave that contains a point
+    beyond that takes the dense evaluation.  Mixed and all-far batches, vs the fp32 oracle."""
+    cfg, m = _model()
+    fp = _oracle_params(cfg, m)
+    for lo, hi, seed in ((-1.3, 2.3, 21), (1.55, 2.4, 22), (-0.49, 1.49, 23)):
+        x = _points(777, seed=seed, lo=lo, hi=hi)[7:]
+        x[5] = torch.tensor([1.5, -0.5, 0.3])
+        x[6] = torch.tensor([1.4999999, -0.50000006, 2.0])
+        _close(m.query_color_sdf(x.cuda()), FO.query_color_sdf(fp, x, False), 1e-4, 2e-5, f"raw4 far points [{lo},{hi}]")
 
 
 def test_point_queries_match_oracle():
