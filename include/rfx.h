@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 1
+#define RFX_ABI_VERSION 2
 
 typedef void* rfx_stream;
 
@@ -52,14 +52,29 @@ int rfx_last_hip_error(void);
  *   color_packed/depth: dev [H*W]; old_bnd[6] = x0,x1,y0,y1,z0,z1 (host, used iff reintegrate).
  *   index_decode: 0 = reproduce the reference's fp32 index decode (incl. its rounding
  *   artefacts next to slab boundaries when dx*dy*dz > 2^24), 1 = exact integer decode.
- *   workspace: dev, >= rfx_tsdf_integrate_workspace_bytes(H, W). */
-size_t rfx_tsdf_integrate_workspace_bytes(int H, int W);
+ *   workspace: dev, 8-byte aligned, >= rfx_tsdf_integrate_workspace_bytes(dx, dy, dz, H, W): the packed
+ *   {depth, 1/lambda} image, its coarse max-depth tiles and the queue of 64-voxel chunks the frustum touches
+ *   (8 B per chunk of the volume: 51 MB at 800x800x600).  ABI 2: the query takes the volume dimensions. */
+size_t rfx_tsdf_integrate_workspace_bytes(int dx, int dy, int dz, int H, int W);
 int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
                        const float origin[3], float voxel, const float K[9], const float c2w[16],
                        const float* color_packed, const float* depth, int H, int W,
                        float trunc, float obs_weight, int weight_clamp, int reintegrate,
                        const float old_bnd[6], int index_decode,
                        void* workspace, size_t workspace_bytes, rfx_stream stream);
+
+/* V1 on one x-slab of the volume (multi-GPU: the volume is cut into contiguous x-slabs, x being the slowest axis of
+ * the reference layout model/Volume.py:224-226, one slab per GPU, every GPU integrating the same frame).  dx, dy, dz,
+ * origin describe the WHOLE volume; tsdf/weight/color hold only the planes [x0, x1) ((x1-x0)*dy*dz voxels each).  Every
+ * voxel is evaluated with its global index and coordinates, so the slabs put together are bit-identical to
+ * rfx_tsdf_integrate on the whole volume.  workspace >= rfx_tsdf_integrate_workspace_bytes(x1 - x0, dy, dz, H, W).
+ * The reference has no counterpart (single GPU); semantics are those of V1. */
+int rfx_tsdf_integrate_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
+                            const float origin[3], float voxel, const float K[9], const float c2w[16],
+                            const float* color_packed, const float* depth, int H, int W,
+                            float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                            const float old_bnd[6], int index_decode,
+                            void* workspace, size_t workspace_bytes, rfx_stream stream);
 
 /* host-side colour packing of model/Volume.py:725-728 moved to the device:
  * rgb255 dev [n,3] (0..255 valued floats) -> packed dev [n] = floor(B*65536+G*256+R). */

@@ -78,9 +78,11 @@ _i, _f, _l, _sz = C.c_int, C.c_float, C.c_int64, C.c_size_t
 PROTOTYPES = {
     "rfx_abi_version": (_i, []),
     "rfx_last_hip_error": (_i, []),
-    "rfx_tsdf_integrate_workspace_bytes": (_sz, [_i, _i]),
+    "rfx_tsdf_integrate_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "rfx_tsdf_integrate": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
                                 _i, _P, _sz, _P]),
+    "rfx_tsdf_integrate_slab": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
+                                     _i, _P, _sz, _P]),
     "rfx_pack_color": (_i, [_P, _P, _l, _P]),
     "rfx_tsdf_fill": (_i, [_P, _P, _P, _l, _P]),
     "rfx_tsdf_copy": (_i, [_P, _P, _P, _P, _P, _P, _l, _P]),
@@ -156,7 +158,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 1:
+    if lib.rfx_abi_version() != 2:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

@@ -24,15 +24,27 @@
 #define MV_TY 4
 #endif
 #ifndef MV_U
-#define MV_U 4
+#define MV_U 2          // chunks in flight per wave (queue form: 2 -> 8 waves per SIMD; measured 72 us per call vs 81 at 4)
 #endif
 #ifndef MV_TD
 #define MV_TD 32      // pixels per side of a coarse max-depth tile
 #endif
+#ifndef MV_ROWS_THREADS
+#define MV_ROWS_THREADS 1024     // mv_rows_kernel block: one queue atomic per block
+#endif
+#define MV_HDR 4       // workspace header words before the coarse tiles: [0] queue count, [1] risky-queue count
 
 namespace rfx {
 
 thread_local int g_last_hip_error = 0;
+
+#ifdef MV_STATS      // dev builds only (tools/v1_probe.py): work counters of the V1 kernel
+__device__ unsigned long long g_mv_stats[8];   // 0 waves, 1 waves with work, 2 chunk items, 3 lanes in z-range, 4 lanes projected
+                                               // in-image, 5 lanes updated, 6 colour-band lanes, 7 risky-row chunk items
+#define MV_STAT(i, v) do { unsigned long long _v = (v); if (_v) atomicAdd(&g_mv_stats[i], _v); } while (0)
+#else
+#define MV_STAT(i, v) do { } while (0)
+#endif
 
 struct MvParams {
     float K[9];
@@ -51,6 +63,7 @@ struct MvParams {
     // up to three disjoint windows of (x,y) tiles: [0] the frustum footprint (host AABB), [1],[2] the
     // first / last tile rows in y, which hold the literally-decoded boundary rows and are always walked
     int   win_x0[3], win_y0[3], win_wx[3], win_wy[3];
+    int   alias_margin;   // voxels within this index distance of an x-slab boundary may decode to another cell (decode_split)
 };
 
 // ---------------------------------------------------------------------------- prepass
@@ -59,7 +72,9 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
                                                          unsigned* __restrict__ dmax_bits, int H, int W,
                                                          float fx, float fy, float cx, float cy, int colmajor) {
     // one block per MV_TD x MV_TD pixel tile: packs {depth, 1/lambda} and stores the tile's max depth
-    // in dmax_bits[1 + tile] (plain store, no atomics).  dmax_bits[0] is unused.
+    // in dmax_bits[MV_HDR + tile] (plain store, no atomics).  dmax_bits[0], [1] are the work-queue counters of the
+    // queue-form integrate (mv_rows_kernel appends, mv_chunks_kernel reads): reset here.
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dmax_bits[0] = 0u; dmax_bits[1] = 0u; }
     const int tw = (W + MV_TD - 1) / MV_TD;
     const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
     float m = 0.0f;
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0)
-        dmax_bits[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+        dmax_bits[MV_HDR + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
 }
 
 // ---------------------------------------------------------------------------- per-voxel math
@@ -136,6 +151,7 @@ __device__ __forceinline__ void integrate_lanes(const MvParams& P, Lanes<U>& L,
         int py = f2i_rn(madd(P.K[4], (L.cy[u] / czs), P.K[5]));
         ok = ok && px >= 0 && px < P.W && py >= 0 && py < P.H;
         L.ok[u] = ok;
+        MV_STAT(4, __popcll(__ballot(ok)) * ((threadIdx.x & 63) == 0));
         L.pix[u] = ok ? py * P.W + px : 0;
         L.dix[u] = ok ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0;
     }
@@ -160,6 +176,8 @@ __device__ __forceinline__ void integrate_lanes(const MvParams& P, Lanes<U>& L,
         bool upd = L.ok[u] && (d > 0.0f) && (sdf[u] >= -P.trunc);
         L.ok[u] = upd;
         band[u] = upd && (sdf[u] <= P.trunc);
+        MV_STAT(5, __popcll(__ballot(upd)) * ((threadIdx.x & 63) == 0));
+        MV_STAT(6, __popcll(__ballot(band[u])) * ((threadIdx.x & 63) == 0));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
         if (need) {
             const int ntx = bu1 - bu0 + 1, nt = ntx * (bv1 - bv0 + 1);
             for (int t = sub; t < nt; t += HELPERS)
-                part = fmaxf(part, __uint_as_float(dmax_bits[1 + (bv0 + t / ntx) * tw + bu0 + t % ntx]));
+                part = fmaxf(part, __uint_as_float(dmax_bits[MV_HDR + (bv0 + t / ntx) * tw + bu0 + t % ntx]));
         }
 #pragma unroll
         for (int o = 1; o < HELPERS; o <<= 1) part = fmaxf(part, __shfl_xor(part, o));
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
     }
     const int excl = incl - nchunk;
     const int total = __shfl(incl, 63);
+    if (lane == 0) { MV_STAT(0, 1); MV_STAT(1, total > 0 ? 1 : 0); MV_STAT(2, total); }
     for (int base = 0; base < total; base += U) {
         Lanes<U> L;
 #pragma unroll
@@ -364,6 +383,7 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
             L.cz[u] = madd(P.c2w[10], tz, rc.az);
             L.ok[u] = ok;
             L.idx[u] = ((int64_t)rx * P.dy + ry) * P.dz + z;
+            MV_STAT(3, __popcll(__ballot(ok)) * (lane == 0));
         }
         integrate_lanes<U>(P, L, dimg, cpk, tsdf, weight, color);
     }
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
         const int rx = x0 + r / TY, ry = y0 + r % TY;
         const int64_t row_base = ((int64_t)rx * P.dy + ry) * P.dz;
         for (int zb = 0; zb < P.dz; zb += 64) {
+            if (lane == 0) MV_STAT(7, 1);
             Lanes<1> L;
             const int z = zb + lane;
             bool ok = z < P.dz;
@@ -393,6 +414,362 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
             integrate_lanes<1>(P, L, dimg, cpk, tsdf, weight, color);
         }
     }
+}
+
+
+// ============================================================================ V1, queue form
+// Two launches behind the prepass instead of one wave per tile of rows:
+//   mv_rows_kernel   : one THREAD per (x,y) row of the frustum's footprint window.  Frustum clip -> z interval, far
+//                      clip from the coarse max-depth tiles (held in LDS), then the row's 64-voxel chunks (aligned to
+//                      256 B of the volume arrays) are appended to a work queue: one wave-aggregated atomic per wave.
+//   mv_chunks_kernel : a fixed grid of waves pulls U chunks at a time off the queue, lanes along z.  Every wave does the
+//                      same amount of work whatever the view (no wave is stuck with a deep tile while others idle), and
+//                      the volume reads are issued BEFORE the projection: the HBM round trip of tsdf/weight overlaps the
+//                      projection arithmetic and the L2 gather of {depth, 1/lambda}, instead of following them.
+// The per-voxel expression tree is integrate_lanes' (bit-identical results); the cull only removes voxels that provably
+// fail the reference's tests.
+// Queue item (uint2): x = rx | ry << 15 | risky << 30;  y = chunk | lo << 16 | hi << 22: lanes [lo, hi) of the chunk
+// lie inside the row's z interval.  Rows next to an x-slab boundary ("risky": the reference's fp32 index decode may
+// alias there, see decode_split) decode literally; their voxels within alias_margin indices of the boundary are
+// always walked, the others decode to their own cell and follow the row's interval like everyone else.
+constexpr int MV_ROWS_LDS_TILES = 4096;         // coarse tiles kept in LDS by mv_rows_kernel (16 KB); more -> global reads
+constexpr int MV_Q_MAX_DIM = 32767;
+
+__device__ __forceinline__ bool alias_zone(const MvParams& P, int ry, int z) {
+    const int64_t off = (int64_t)ry * P.dz + z;                      // index distance from the slab's first voxel
+    return off < P.alias_margin || (int64_t)P.dy * P.dz - off <= P.alias_margin;
+}
+
+__global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, const unsigned* __restrict__ dmax_bits,
+                                                       unsigned* __restrict__ q_counts, uint2* __restrict__ queue,
+                                                       unsigned q_cap, uint2* __restrict__ queue_risky, unsigned q_cap_risky,
+                                                       int blocks_main) {
+    __shared__ float tmax_lds[MV_ROWS_LDS_TILES];
+    const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
+    const int n_tiles = tw * th;
+    const bool in_lds = n_tiles <= MV_ROWS_LDS_TILES;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) tmax_lds[i] = __uint_as_float(dmax_bits[MV_HDR + i]);
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    // a block works on ONE window: [0, blocks_main) the frustum footprint, the rest the risky boundary rows (windows 1, 2
+    // back to back); so `risky` is block-uniform and each block appends to one queue with one atomic
+    const bool risky = (int)blockIdx.x >= blocks_main;
+    int wi = 0, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (risky) {
+        t -= blocks_main * (int)blockDim.x;
+        wi = 1;
+        if (t >= P.win_wx[1] * P.win_wy[1]) { t -= P.win_wx[1] * P.win_wy[1]; wi = 2; }
+    }
+    int z0 = 0, z1 = 0, rx = 0, ry = 0;
+    bool row = false;
+    if (t < P.win_wx[wi] * P.win_wy[wi]) {
+        rx = P.win_x0[wi] + t / P.win_wy[wi];
+        ry = P.win_y0[wi] + t % P.win_wy[wi];
+        row = rx < P.dx && ry < P.dy;
+    }
+    if (row) {
+        const float wx = P.origin[0] + (float)rx * P.voxel - P.c2w[3];
+        const float wy = P.origin[1] + (float)ry * P.voxel - P.c2w[7];
+        const float wz = P.origin[2] - P.c2w[11];
+        const float Ax = P.c2w[0] * wx + P.c2w[4] * wy + P.c2w[8] * wz;
+        const float Ay = P.c2w[1] * wx + P.c2w[5] * wy + P.c2w[9] * wz;
+        const float Az = P.c2w[2] * wx + P.c2w[6] * wy + P.c2w[10] * wz;
+        const float Bx = P.c2w[8] * P.voxel, By = P.c2w[9] * P.voxel, Bz = P.c2w[10] * P.voxel;
+        const float fx = P.K[0], fy = P.K[4], cx = P.K[2], cy = P.K[5];
+        const float m = 0.05f;   // pixel margin
+        const float mag = fabsf(Ax) + fabsf(Ay) + fabsf(Az) + (float)P.dz * (fabsf(Bx) + fabsf(By) + fabsf(Bz));
+        const float eps = 1e-4f * fmaxf(fx, fy) * mag + 1e-4f;      // for the image-plane clips (pixel units x metres)
+        const float eps_z = 1e-5f * mag + 1e-5f;                    // for the depth clips (metres)
+        float lo = 0.0f, hi = (float)(P.dz - 1);
+        bool empty = false;
+        auto clip = [&](float a, float b, float e) {   // keep z with a + b z >= -e
+            a += e;
+            const float q = -a * __builtin_amdgcn_rcpf(b);   // ~1 ulp: absorbed by e and the +-1 voxel margin
+            if (b > 0.0f)      lo = fmaxf(lo, q);
+            else if (b < 0.0f) hi = fminf(hi, q);
+            else if (a < 0.0f) empty = true;
+        };
+        clip(Az, Bz, eps_z);                                                          // cam_z > 0
+        clip(fx * Ax + (cx + 0.5f + m) * Az, fx * Bx + (cx + 0.5f + m) * Bz, eps);    // px >= 0
+        clip(((float)P.W - 0.5f + m - cx) * Az - fx * Ax, ((float)P.W - 0.5f + m - cx) * Bz - fx * Bx, eps);   // px < W
+        clip(fy * Ay + (cy + 0.5f + m) * Az, fy * By + (cy + 0.5f + m) * Bz, eps);    // py >= 0
+        clip(((float)P.H - 0.5f + m - cy) * Az - fy * Ay, ((float)P.H - 0.5f + m - cy) * Bz - fy * By, eps);   // py < H
+        if (!empty && lo <= hi) {
+            // The row is a straight line in the image: its pixels lie in the bounding box of the two end points.  No
+            // voxel of the row can update if it is deeper than the deepest pixel of the coarse tiles that box touches
+            // (+ trunc).
+            const float za = fmaxf(Az + lo * Bz, 1e-6f), zb = fmaxf(Az + hi * Bz, 1e-6f);
+            const float ra = __builtin_amdgcn_rcpf(za), rb = __builtin_amdgcn_rcpf(zb);
+            const float u0 = fx * (Ax + lo * Bx) * ra + cx, v0 = fy * (Ay + lo * By) * ra + cy;
+            const float u1 = fx * (Ax + hi * Bx) * rb + cx, v1 = fy * (Ay + hi * By) * rb + cy;
+            const int tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)), tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
+            const int tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)), tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
+            float tm = 0.0f;
+            for (int tv = tv0; tv <= tv1; ++tv)
+                for (int tu = tu0; tu <= tu1; ++tu)
+                    tm = fmaxf(tm, in_lds ? tmax_lds[tv * tw + tu] : __uint_as_float(dmax_bits[MV_HDR + tv * tw + tu]));
+            if (tm > 0.0f) {
+                // cam_z <= (deepest pixel + trunc) / (1 - ratio_eps), on the far side
+                clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz, eps_z);
+                if (!empty && lo <= hi) {
+                    z0 = max(0, (int)floorf(lo) - 1);
+                    z1 = min(P.dz, (int)ceilf(hi) + 2);
+                    if (z1 < z0) z1 = z0;
+                }
+            }
+        }
+    }
+    // ---- chunks of this row: [c0, c1) from the interval; a risky row also walks the chunks its alias zones touch
+    const int nch_row = (P.dz + 63) >> 6;
+    const int c0 = z0 >> 6, c1 = z1 > z0 ? (z1 + 63) >> 6 : c0;
+    auto alias_chunk = [&](int c) {      // alias zones are a prefix and a suffix of the slab in index order: test the chunk's ends
+        return alias_zone(P, ry, c << 6) || alias_zone(P, ry, min(P.dz, (c << 6) + 64) - 1);
+    };
+    int n_items = row ? c1 - c0 : 0;
+    if (row && risky) {
+        n_items = 0;
+        for (int c = 0; c < nch_row; ++c) n_items += ((c >= c0 && c < c1) || alias_chunk(c)) ? 1 : 0;
+    }
+    // ---- append: wave prefix sums, then ONE returning atomic per block (a single counter word retires ~90 such atomics
+    //      per microsecond; one per wave, ~900 a frame, would cost as much as the rest of this kernel)
+    int incl = n_items;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (lane == 0) { MV_STAT(0, 1); MV_STAT(1, total > 0 ? 1 : 0); }
+    __shared__ int wave_total[16];
+    __shared__ unsigned block_base;
+    const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    if (lane == 63) wave_total[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < nwv; ++w) { const int tt = wave_total[w]; wave_total[w] = sum; sum += tt; }
+        block_base = sum ? atomicAdd(q_counts + (risky ? 1 : 0), (unsigned)sum) : 0u;
+    }
+    __syncthreads();
+    if (n_items == 0) return;
+    unsigned pos = block_base + (unsigned)wave_total[wv] + (unsigned)(incl - n_items);
+    const unsigned head = (unsigned)rx | ((unsigned)ry << 15);
+    uint2* __restrict__ q = risky ? queue_risky : queue;
+    const unsigned cap = risky ? q_cap_risky : q_cap;
+    for (int c = risky ? 0 : c0; c < (risky ? nch_row : c1); ++c) {
+        const bool in_iv = c >= c0 && c < c1;
+        if (!in_iv && !(risky && alias_chunk(c))) continue;
+        const int lo_l = in_iv ? max(z0 - (c << 6), 0) : 0, hi_l = in_iv ? min(z1 - (c << 6), 64) : 0;
+        if (pos < cap) q[pos] = make_uint2(head, (unsigned)c | ((unsigned)lo_l << 16) | ((unsigned)hi_l << 22));
+        ++pos;
+    }
+}
+
+// Correctly rounded fp32 quotients a0/b and a1/b from ONE reciprocal: the instruction sequence hipcc emits for an
+// IEEE division (v_rcp_f32, one Newton step on the reciprocal, two residual corrections of the quotient) without its
+// range scaling (v_div_scale / v_div_fixup), which is the identity for the operands used here (|a| < 1e3, 1e-6 < b < 1e3,
+// no denormal intermediate): bit-identical to a0 / b and a1 / b, 13 instructions instead of 22.
+__device__ __forceinline__ void div2_shared(float a0, float a1, float b, float& q0, float& q1) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r, 1.0f);
+    r = fmaf(e, r, r);
+    float x = a0 * r, t = fmaf(-b, x, a0);
+    x = fmaf(t, r, x); t = fmaf(-b, x, a0);
+    q0 = fmaf(t, r, x);
+    x = a1 * r; t = fmaf(-b, x, a1);
+    x = fmaf(t, r, x); t = fmaf(-b, x, a1);
+    q1 = fmaf(t, r, x);
+}
+
+// The voxel update proper (integrate_lanes' expression tree, Volume.py:285-334) for ONE voxel whose depth sample is known.
+__device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, float cxv, float cyv, float czv, float d, float rl,
+                                             int pix, float cur, float w_old, const float* __restrict__ cpk,
+                                             float* __restrict__ tsdf, float* __restrict__ weight, float* __restrict__ color) {
+    const float norm = sqrtf(madd(czv, czv, madd(cxv, cxv, cyv * cyv)));
+    const float sdf = -madd(rl, norm, -d);
+    const bool upd = (d > 0.0f) && (sdf >= -P.trunc);
+    if (!upd) return;
+    const bool band = sdf <= P.trunc;
+    float oc = 0.f, ncl = 0.f;
+    if (band) { oc = color[idx]; ncl = cpk[pix]; }
+    const float dist = fminf(1.0f, sdf / P.trunc);
+    const float w_new = w_old + P.obs_weight;
+    float new_t = madd(cur, w_old, P.obs_weight * dist) / w_new;
+    float new_w = w_new;
+    if (P.weight_clamp == 1) {
+        new_w = fminf(w_new, 128.0f);
+        if (new_w > 40.0f) new_w = 40.0f;
+    }
+    float new_c = 0.0f;
+    if (band) {
+        const float nc = ncl;
+        float nb = floorf(nc / 65536.0f);
+        float ng = floorf((nc - nb * 65536.0f) / 256.0f);
+        float nr = nc - nb * 65536.0f - ng * 256.0f;
+        const float ob = floorf(oc / 65536.0f);
+        const float og = floorf((oc - ob * 65536.0f) / 256.0f);
+        const float orr = oc - ob * 65536.0f - og * 256.0f;
+        nb = fminf(roundf(madd(ob, w_old, P.obs_weight * nb) / w_new), 255.0f);
+        ng = fminf(roundf(madd(og, w_old, P.obs_weight * ng) / w_new), 255.0f);
+        nr = fminf(roundf(madd(orr, w_old, P.obs_weight * nr) / w_new), 255.0f);
+        new_c = nb * 65536.0f + ng * 256.0f + nr;
+    }
+    const bool reset = (P.obs_weight == -1.0f) && (w_old <= 1.0f) && (P.reintegrate == 1);
+    if (reset) { new_t = 1.0f; new_w = 0.0f; new_c = 0.0f; }
+    tsdf[idx] = new_t;
+    weight[idx] = new_w;
+    if (band || reset) color[idx] = new_c;
+}
+
+// Work split inside a wave.  ~85 % of the voxels a frame updates lie in FREE SPACE in front of the surface
+// (sdf > trunc): for them dist = min(1, sdf / trunc) = 1 whatever the exact sdf, and a voxel that has only ever seen
+// free space holds tsdf = 1, so its running average (1 * w_old + obs_weight * 1) / (w_old + obs_weight) is 1 again:
+// numerator and denominator are the SAME fp32 number.  Such a voxel needs no division, no correctly rounded square
+// root and no tsdf store -- only its weight moves, and not even that once it sits at the clamp.  A lane is classified
+// with a 1-ulp square root and a margin far above that error:
+//     sdf~ >  trunc + margin  and tsdf == 1  ->  free: weight update only
+//     sdf~ < -trunc - margin  or no depth    ->  untouched (the reference returns)
+//     anything else                          ->  "near": the reference's full expression tree
+// The near lanes of the U chunks a wave has in flight (a dozen per chunk: the truncation band along the row) are
+// compacted through LDS and then evaluated TOGETHER by update_voxel, so the expensive path runs on full waves, once
+// per trip, instead of once per chunk at a fifth of its lanes.  Fast path only for obs_weight > 0 without
+// re-integration (every mapping frame); otherwise every lane takes the full path.
+constexpr int MV_NEAR_FIELDS = 9;
+
+template <int U, bool RISKY, bool REINT>
+__global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsigned* __restrict__ q_count,
+                                                        const uint2* __restrict__ queue, unsigned q_cap,
+                                                        const float2* __restrict__ dimg, const float* __restrict__ cpk,
+                                                        float* __restrict__ tsdf, float* __restrict__ weight,
+                                                        float* __restrict__ color) {
+    __shared__ float nbuf[4][MV_NEAR_FIELDS][128];             // per wave: pending near lanes (< 64 kept + <= 64 new), field-major
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float (*nb)[128] = nbuf[wv];
+    int n_near = 0;        // wave-uniform fill of nb
+    // the reference's full update on the top min(64, n_near) pending records (one per lane)
+    auto drain = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS stores have landed
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        const int take = min(64, n_near), base = n_near - take;
+        if (lane < take) {
+            const int s = base + lane;
+            update_voxel(P, (int64_t)__float_as_int(nb[0][s]), nb[1][s], nb[2][s], nb[3][s], nb[4][s], nb[5][s],
+                         __float_as_int(nb[6][s]), nb[7][s], nb[8][s], cpk, tsdf, weight, color);
+        }
+        MV_STAT(6, (unsigned long long)take * (lane == 0));
+        n_near = base;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();             // reads done before the buffer is written again
+        asm volatile("" ::: "memory");
+    };
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
+    const unsigned n = min(*q_count, q_cap);
+    const bool fast = !REINT && P.obs_weight > 0.0f;
+    for (unsigned it = wave * U; it < n; it += n_waves * U) {
+        int64_t idx[U];
+        bool ok[U];
+        float cxv[U], cyv[U], czv[U], cur[U], wold[U];
+        // ---- stage 0: the trip's U items in one scalar load (the queue is padded by U entries; an item past the end
+        //      is replaced by the trip's first).  Every load below is UNCONDITIONAL with an in-bounds address: a load under
+        //      a lane mask sits in its own basic block with its own s_waitcnt, which strings the U round trips together.
+        unsigned ixs[U], iys[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint2 item = queue[it + u];
+            ixs[u] = __builtin_amdgcn_readfirstlane(item.x); iys[u] = __builtin_amdgcn_readfirstlane(item.y);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = it + u < n;
+            const unsigned ix = live ? ixs[u] : ixs[0], iy = live ? iys[u] : iys[0];
+            const int rx = ix & 0x7fff, ry = (ix >> 15) & 0x7fff;
+            const int c = iy & 0xffff, lo_l = (iy >> 16) & 63, hi_l = (iy >> 22) & 127;
+            const int z = (c << 6) + lane;
+            bool v = live && lane >= lo_l && lane < hi_l;
+            if (RISKY) v = live && z < P.dz && (v || alias_zone(P, ry, z));
+            // the row's first voxel as a scalar base: per-lane addresses are base + 32-bit offsets
+            const int64_t row0 = ((int64_t)rx * P.dy + ry) * P.dz;
+            idx[u] = row0 + z;
+            const int zc = min(z, P.dz - 1);
+            cur[u] = (tsdf + row0)[zc]; wold[u] = (weight + row0)[zc];
+            float fvx = (float)rx, fvy = (float)ry, fvz = (float)z;
+            if (RISKY) decode_literal(v ? (int)idx[u] : 0, P.dy, P.dz, fvx, fvy, fvz);
+            const RowConst rc = make_row(P, fvx, fvy);
+            const float pz = madd(fvz, P.voxel, P.origin[2]);
+            if (REINT) v = v && !outside_old(P, rc.px, rc.py, pz);
+            const float tz = pz - P.c2w[11];
+            cxv[u] = madd(P.c2w[8], tz, rc.ax);
+            cyv[u] = madd(P.c2w[9], tz, rc.ay);
+            czv[u] = madd(P.c2w[10], tz, rc.az);
+            ok[u] = v;
+            MV_STAT(2, live && lane == 0 ? 1 : 0);
+            MV_STAT(7, live && RISKY && lane == 0 ? 1 : 0);
+            MV_STAT(3, __popcll(__ballot(v)) * (lane == 0));
+        }
+        // ---- stage 1: projection (correctly rounded quotients, see div2_shared), {depth, 1/lambda} gather
+        int pix[U];
+        float2 dl[U];
+        bool generic = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            generic = generic || (ok[u] && czv[u] > 0.0f && !(czv[u] > 1e-6f && czv[u] < 1e3f && fabsf(cxv[u]) < 1e3f && fabsf(cyv[u]) < 1e3f));
+        const bool any_generic = __any(generic) != 0;       // operands outside div2_shared's range: the compiler's division
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool v = ok[u] && (czv[u] > 0.0f);
+            const float czs = v ? czv[u] : 1.0f;
+            float qx, qy;
+            if (!any_generic) div2_shared(v ? cxv[u] : 0.0f, v ? cyv[u] : 0.0f, czs, qx, qy);
+            else { qx = cxv[u] / czs; qy = cyv[u] / czs; }
+            const int px = f2i_rn(madd(P.K[0], qx, P.K[2]));
+            const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
+            v = v && px >= 0 && px < P.W && py >= 0 && py < P.H;
+            ok[u] = v;
+            MV_STAT(4, __popcll(__ballot(v)) * (lane == 0));
+            pix[u] = v ? py * P.W + px : 0;
+            const int dix = v ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0;
+            dl[u] = dimg[dix];
+        }
+        // ---- stage 2: classify; free-space lanes finish here, near lanes are appended to the wave's LDS list, which is
+        //      evaluated 64 records at a time (full waves of the expensive path, about once per sixteen chunks)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float d = dl[u].x;
+            const float norm_a = __builtin_amdgcn_sqrtf(madd(czv[u], czv[u], madd(cxv[u], cxv[u], cyv[u] * cyv[u])));
+            const float sdf_a = d - dl[u].y * norm_a;
+            // |sdf~ - sdf| <= ~2.5 ulp of max(norm, d) (1-ulp square root, two more roundings): margin = 5 ulp + 1e-7
+            const float margin = fmaf(6e-7f, norm_a + fabsf(d), 1e-7f);
+            const bool cand = ok[u] && (d > 0.0f) && (sdf_a >= -P.trunc - margin);          // else: provably untouched
+            const bool free_l = fast && cand && (sdf_a > P.trunc + margin) && (cur[u] == 1.0f);
+            const bool near_l = cand && !free_l;
+            if (free_l) {
+                float new_w = wold[u] + P.obs_weight;
+                if (P.weight_clamp == 1) {
+                    new_w = fminf(new_w, 128.0f);
+                    if (new_w > 40.0f) new_w = 40.0f;
+                }
+                if (new_w != wold[u]) weight[idx[u]] = new_w;       // tsdf stays 1 (see above)
+            }
+            MV_STAT(5, __popcll(__ballot(free_l)) * (lane == 0));
+            const unsigned long long m = __ballot(near_l);
+            if (m) {
+                if (near_l) {
+                    const int s = n_near + __popcll(m & ((1ull << lane) - 1ull));
+                    nb[0][s] = __int_as_float((int)idx[u]);        // < 2^31 voxels (checked by the host)
+                    nb[1][s] = cxv[u]; nb[2][s] = cyv[u]; nb[3][s] = czv[u];
+                    nb[4][s] = d; nb[5][s] = dl[u].y; nb[6][s] = __int_as_float(pix[u]);
+                    nb[7][s] = cur[u]; nb[8][s] = wold[u];
+                }
+                n_near += __popcll(m);
+                if (n_near >= 64) drain();
+            }
+        }
+    }
+    while (n_near > 0) drain();
 }
 
 // ---------------------------------------------------------------------------- simple sweeps
@@ -641,12 +1018,14 @@ static inline int sweep_blocks(int64_t n_items) {
 }
 
 // rows whose fp32 index decode may differ from the exact one (see oracle/tsdf_oracle.c header).
-static void decode_split(int dx, int dy, int dz, int index_decode, int* risky_rows, int* literal_all) {
+static void decode_split(int dx, int dy, int dz, int index_decode, int* risky_rows, int* literal_all, int* alias_margin = nullptr) {
     *risky_rows = 0; *literal_all = 0;
+    if (alias_margin) *alias_margin = 0;
     if (index_decode == 1) return;                   // exact everywhere
     const int64_t M = (int64_t)dy * dz, N = M * dx;
     if (M >= (1 << 24)) { *literal_all = 1; return; }
     const int64_t margin = (N >> 22) + 64;           // >= 2x the worst fp32 rounding of idx/(dy*dz)
+    if (alias_margin) *alias_margin = (int)margin;
     int64_t rr = (margin + dz - 1) / dz;
     if (2 * rr >= dy) { *literal_all = 1; return; }
     *risky_rows = (int)rr;
@@ -656,31 +1035,63 @@ static void decode_split(int dx, int dy, int dz, int index_decode, int* risky_ro
 
 using namespace rfx;
 
-static inline size_t mv_header_bytes(size_t tiles) { return ((1 + tiles) * sizeof(unsigned) + 255) / 256 * 256; }
+static inline size_t mv_header_bytes(size_t tiles) { return ((MV_HDR + tiles) * sizeof(unsigned) + 255) / 256 * 256; }
 
 extern "C" {
+
+#ifdef MV_STATS
+int rfx_debug_mv_stats(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rfx::g_mv_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rfx::g_mv_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 int rfx_last_hip_error(void) { return g_last_hip_error; }
 
-size_t rfx_tsdf_integrate_workspace_bytes(int H, int W) {
-    if (H <= 0 || W <= 0) return 0;
+// workspace = [queue counter + coarse max-depth tiles | {depth, 1/lambda} image | work queue].  The queue is sized for the
+// worst case (every 64-voxel chunk of the volume), so an append can never overflow: 8 B per chunk, 51 MB at 800x800x600.
+static inline size_t mv_queue_capacity(int dx, int dy, int dz) { return (size_t)dx * dy * (size_t)((dz + 63) / 64); }
+constexpr size_t MV_QUEUE_PAD = 16;      // entries past the capacity that mv_chunks_kernel may read (never uses)
+// queue of the rows next to x-slab boundaries (they decode the voxel index literally): 2 * risky_rows rows per x
+// (risky_rows <= ceil(576 / dz) for any volume below 2^31 voxels: decode_split's margin is at most (2^31 >> 22) + 64;
+//  the bound does not depend on the slab a call works on)
+static inline size_t mv_risky_capacity(int dx, int dz) {
+    const size_t rr_max = (size_t)((576 + dz - 1) / dz);
+    return 2 * rr_max * (size_t)dx * (size_t)((dz + 63) / 64);
+}
+static inline size_t mv_image_bytes(int H, int W) { return ((size_t)H * W * sizeof(float2) + 255) / 256 * 256; }
+
+size_t rfx_tsdf_integrate_workspace_bytes(int dx, int dy, int dz, int H, int W) {
+    if (H <= 0 || W <= 0 || dx <= 0 || dy <= 0 || dz <= 0) return 0;
     const size_t tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
-    return mv_header_bytes(tiles) + (size_t)H * W * sizeof(float2);
+    return mv_header_bytes(tiles) + mv_image_bytes(H, W) +
+           (mv_queue_capacity(dx, dy, dz) + mv_risky_capacity(dx, dz) + 2 * MV_QUEUE_PAD) * sizeof(uint2);
 }
 
-int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
-                       const float origin[3], float voxel, const float K[9], const float c2w[16],
-                       const float* color_packed, const float* depth, int H, int W,
-                       float trunc, float obs_weight, int weight_clamp, int reintegrate,
-                       const float old_bnd[6], int index_decode,
-                       void* workspace, size_t workspace_bytes, rfx_stream stream) {
+// V1 on the x-planes [x0, x1) of a dx*dy*dz volume; tsdf/weight/color hold ONLY those planes (slab-local arrays).  Every
+// voxel is computed with its GLOBAL index and coordinates -- including the reference's fp32 index decode, which depends on
+// the global linear index -- so the slabs of a volume, integrated separately (one per GPU), are bit-identical to the whole.
+// The kernels index `base + global_idx` with base = slab pointer - x0*dy*dz: only rows inside the slab are ever touched.
+static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
+                          const float origin[3], float voxel, const float K[9], const float c2w[16],
+                          const float* color_packed, const float* depth, int H, int W,
+                          float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                          const float old_bnd[6], int index_decode,
+                          void* workspace, size_t workspace_bytes, rfx_stream stream) {
     if (!tsdf || !weight || !color || !origin || !K || !c2w || !color_packed || !depth) return RFX_ERR_ARG;
     if (dx <= 0 || dy <= 0 || dz <= 0 || H <= 0 || W <= 0 || !(voxel > 0.0f)) return RFX_ERR_ARG;
+    if (x0 < 0 || x1 > dx || x1 <= x0) return RFX_ERR_ARG;
     if (reintegrate && !old_bnd) return RFX_ERR_ARG;
     if ((int64_t)dx * dy * dz >= (1LL << 31)) return RFX_ERR_UNSUPPORTED;   // the reference indexes with int32
-    if (!workspace || workspace_bytes < rfx_tsdf_integrate_workspace_bytes(H, W)) return RFX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < rfx_tsdf_integrate_workspace_bytes(x1 - x0, dy, dz, H, W) || ((uintptr_t)workspace & 7)) return RFX_ERR_WORKSPACE;
     if (K[0] == 0.0f || K[4] == 0.0f) return RFX_ERR_ARG;
+    const bool whole = x0 == 0 && x1 == dx;
+    {
+        const int64_t skip = (int64_t)x0 * dy * dz;
+        tsdf -= skip; weight -= skip; color -= skip;
+    }
 
     MvParams P;
     for (int i = 0; i < 9; ++i) P.K[i] = K[i];
@@ -690,7 +1101,7 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
     P.trunc = trunc; P.obs_weight = obs_weight; P.weight_clamp = weight_clamp ? 1 : 0;
     P.reintegrate = reintegrate ? 1 : 0;
     for (int i = 0; i < 6; ++i) P.old_bnd[i] = old_bnd ? old_bnd[i] : 0.0f;
-    decode_split(dx, dy, dz, index_decode, &P.risky_rows, &P.literal_all);
+    decode_split(dx, dy, dz, index_decode, &P.risky_rows, &P.literal_all, &P.alias_margin);
     {   // |cam_norm/(lambda*cam_z) - 1| <= e: pixel rounding moves the ray by <= half a pixel
         const float mvx = fmaxf(fabsf(K[2]), fabsf((float)(W - 1) - K[2])) / fabsf(K[0]);
         const float mvy = fmaxf(fabsf(K[5]), fabsf((float)(H - 1) - K[5])) / fabsf(K[4]);
@@ -733,6 +1144,64 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
     }
     const int all_tx = (dx + TX - 1) / TX, all_ty = (dy + TY - 1) / TY;
     for (int i = 0; i < 3; ++i) { P.win_x0[i] = P.win_y0[i] = P.win_wx[i] = P.win_wy[i] = 0; }
+#ifndef MV_NO_QUEUE
+    if (!P.literal_all && dx <= MV_Q_MAX_DIM && dy <= MV_Q_MAX_DIM && dz <= 64 * 65535) {
+        // queue form: windows in ROWS.  [0] = the frustum footprint without the risky boundary rows, [1],[2] = those rows
+        // (every x: their alias zones are walked whatever the view); they go to a queue of their own, whose kernel
+        // instance carries the literal index decode.
+        int rx0 = std::min(dx, tx0 * TX), rx1 = std::min(dx, tx1 * TX), ry0 = std::min(dy, ty0 * TY), ry1 = std::min(dy, ty1 * TY);
+        rx0 = std::max(rx0, x0); rx1 = std::min(rx1, x1);              // the slab
+        if (rx1 < rx0) rx1 = rx0;
+        if (P.risky_rows > 0) {
+            P.win_x0[1] = x0; P.win_y0[1] = 0; P.win_wx[1] = x1 - x0; P.win_wy[1] = P.risky_rows;
+            P.win_x0[2] = x0; P.win_y0[2] = dy - P.risky_rows; P.win_wx[2] = x1 - x0; P.win_wy[2] = P.risky_rows;
+            ry0 = std::max(ry0, P.risky_rows); ry1 = std::min(ry1, dy - P.risky_rows);
+            if (ry1 < ry0) ry1 = ry0;
+        }
+        P.win_x0[0] = rx0; P.win_y0[0] = ry0; P.win_wx[0] = rx1 - rx0; P.win_wy[0] = ry1 - ry0;
+        const int64_t rows_main = (int64_t)P.win_wx[0] * P.win_wy[0];
+        const int64_t rows_risky = (int64_t)P.win_wx[1] * P.win_wy[1] + (int64_t)P.win_wx[2] * P.win_wy[2];
+        if (rows_main + rows_risky == 0) return RFX_OK;
+        const int nch = (dz + 63) / 64;
+        const size_t cap = mv_queue_capacity(x1 - x0, dy, dz), cap_risky = mv_risky_capacity(x1 - x0, dz);
+        uint2* queue = reinterpret_cast<uint2*>(reinterpret_cast<char*>(dimg) + mv_image_bytes(H, W));
+        uint2* queue_risky = queue + cap + MV_QUEUE_PAD;
+        const unsigned q_cap = (unsigned)std::min<size_t>(cap, 0xffffffffu), q_cap_risky = (unsigned)std::min<size_t>(cap_risky, 0xffffffffu);
+        const int blocks_main = (int)((rows_main + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS), blocks_risky = (int)((rows_risky + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS);
+        hipLaunchKernelGGL(mv_rows_kernel, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
+                           q_cap, queue_risky, q_cap_risky, blocks_main);
+        RFX_LAUNCH_CHECK();
+        // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
+        // chip); small volumes need fewer
+        using Kern = void (*)(MvParams, const unsigned*, const uint2*, unsigned, const float2*, const float*, float*, float*, float*);
+        const Kern k_main = P.reintegrate ? (Kern)mv_chunks_kernel<U, false, true> : (Kern)mv_chunks_kernel<U, false, false>;
+        const Kern k_risky = P.reintegrate ? (Kern)mv_chunks_kernel<U, true, true> : (Kern)mv_chunks_kernel<U, true, false>;
+        static int resident[2] = {0, 0};       // blocks per CU x CUs, [reintegrate]; benign if raced (same value)
+        if (!resident[P.reintegrate]) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            RFX_HIP_TRY(hipGetDevice(&dev));
+            RFX_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            RFX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_main), 256, 0));
+            resident[P.reintegrate] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        }
+        if (rows_main > 0) {
+            const int64_t max_items = std::min<int64_t>((int64_t)cap, rows_main * nch);
+            const int blocks_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate], (max_items + 4 * U - 1) / (4 * U)));
+            hipLaunchKernelGGL(k_main, dim3(blocks_q), dim3(256), 0, st, P, dmax_bits, queue, q_cap, dimg, color_packed, tsdf, weight, color);
+            RFX_LAUNCH_CHECK();
+        }
+        if (rows_risky > 0) {
+            const int64_t max_items = std::min<int64_t>((int64_t)cap_risky, rows_risky * nch);
+            const int blocks_q = (int)std::max<int64_t>(1, std::min<int64_t>(256 * 2, (max_items + 4 * U - 1) / (4 * U)));
+            hipLaunchKernelGGL(k_risky, dim3(blocks_q), dim3(256), 0, st, P, dmax_bits + 1, queue_risky, q_cap_risky, dimg, color_packed, tsdf,
+                               weight, color);
+            RFX_LAUNCH_CHECK();
+        }
+        return RFX_OK;
+    }
+#endif
+    if (!whole) return RFX_ERR_UNSUPPORTED;      // the tile-form fallback (literal decode everywhere) is not slab-aware
     if (P.risky_rows > 0 && !P.literal_all) {
         // boundary strips (all x): tile rows [0, s) and [all_ty - s, all_ty); the main window is clipped to what is left
         const int s_rows = std::min((P.risky_rows + TY - 1) / TY, all_ty / 2);
@@ -750,6 +1219,26 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
                        color_packed, tsdf, weight, color);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
+                       const float origin[3], float voxel, const float K[9], const float c2w[16],
+                       const float* color_packed, const float* depth, int H, int W,
+                       float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                       const float old_bnd[6], int index_decode,
+                       void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return integrate_slab(tsdf, weight, color, dx, dy, dz, 0, dx, origin, voxel, K, c2w, color_packed, depth, H, W, trunc, obs_weight,
+                          weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
+}
+
+int rfx_tsdf_integrate_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
+                            const float origin[3], float voxel, const float K[9], const float c2w[16],
+                            const float* color_packed, const float* depth, int H, int W,
+                            float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                            const float old_bnd[6], int index_decode,
+                            void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return integrate_slab(tsdf, weight, color, dx, dy, dz, x0, x1, origin, voxel, K, c2w, color_packed, depth, H, W, trunc, obs_weight,
+                          weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
 }
 
 int rfx_pack_color(const float* rgb255, float* packed, int64_t n, rfx_stream stream) {

@@ -3,9 +3,10 @@ moving TSDF volume.  Host-side mirror of the reference ``model/ROtracker.py:33-9
 PyCUDA kernels replaced by librfx (``rfx_track_vertex / _normal / _evaluate``).
 
 Differences, on purpose:
-  * the pre-sampled particle templates ("PST", 60 float TIFFs under PFO/ in the reference, read with
-    cv2) are generated here from a seeded sampler with the same structure -- row 0 is the null
-    perturbation, the rest fill the 6-D unit ball, ordered by decreasing norm (``make_pst``);
+  * the pre-sampled particle templates ("PST", 60 float32 TIFFs under PFO/fps_uniform_sphere in the reference,
+    read there with cv2) are read from ``RO.PST_path`` by ``model/pst.py`` (own baseline-TIFF reader) into the
+    same ``ALL_PST[class][index]`` container; only when a configuration says ``RO.PST_fallback: "generated"`` and
+    the directory is absent are seeded templates of the same structure used instead, with a warning;
   * ``cal_transform``'s python loop over up to 10 240 candidates is vectorised with numpy (same
     selection: the first ``count_search`` candidates that beat candidate 0, same weights);
   * compute_vertex's cuRAND jitter is replaced by a counter-based hash (exactly zero anyway for
@@ -26,15 +27,7 @@ from .traj import Trajectory
 from .Volume import moving_volume
 
 
-def make_pst(n: int, seed: int) -> np.ndarray:
-    """[n,6] particle template: origin first, then points uniform in the 6-D unit ball, farthest first."""
-    rng = np.random.default_rng(seed)
-    g = rng.standard_normal((n - 1, 6))
-    g /= np.linalg.norm(g, axis=1, keepdims=True)
-    r = rng.uniform(0.0, 1.0, (n - 1, 1)) ** (1.0 / 6.0)
-    pts = g * r
-    pts = pts[np.argsort(-np.linalg.norm(pts, axis=1))]
-    return np.concatenate([np.zeros((1, 6)), pts], 0).astype(np.float32)
+from .pst import generated_pst, load_pst, make_pst, pst_slot  # noqa: E402,F401  (make_pst re-exported)
 
 
 class ROTracker(object):
@@ -77,31 +70,41 @@ class ROTracker(object):
         self.tiff_index = [0, 1 + 20, 2 + 40, 3, 4 + 20, 5 + 40, 6 + 0, 7 + 20, 8 + 40, 9 + 0, 10 + 20, 11 + 40, 12 + 0,
                            13 + 20, 14 + 40, 15 + 0, 16 + 20, 17 + 40, 18 + 0, 19 + 20]
         self.depth_level = [32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16]
-        self.readpst(ro.get("PST_seed", 20251205), self.PST_size)
+        self.PST_path = ro.get("PST_path", "PFO/fps_uniform_sphere")        # reference configs/*/*.yaml RO.PST_path
+        self.readpst(self.PST_path, self.PST_size)
         self.current_global_R = np.zeros((3, 3), dtype=np.float32)
         self.current_global_T = np.zeros((3), dtype=np.float32)
         rgb = torch.floor(init_batch["rgb"].squeeze() * 255.0)
         self.MV.integrate(rgb, init_batch["depth"].squeeze(), self.K, init_pose, self.MV.vol_bnds, obs_weight=1.)
 
     # ------------------------------------------------------------------ particle templates
-    def readpst(self, seed, PST_size):
-        """same container layout as the reference (:834-866): ALL_PST[class][index] -> [P,6]; device copies."""
-        n_idx = len(self.tiff_index)
-        shapes = {0: (n_idx // 3 + 1, PST_size[0]), 1: (n_idx // 3 + 1, PST_size[1]), 2: (n_idx // 3, PST_size[2])}
-        self.ALL_PST = {c: np.zeros((s[0], s[1], 6), np.float32) for c, s in shapes.items()}
-        for i in range(n_idx):
-            cls = self.tiff_index[i] // 20
-            num = self.tiff_index[i] - cls * 20
-            self.ALL_PST[cls][num // 3] = make_pst(PST_size[cls], seed + 97 * self.tiff_index[i])
+    def readpst(self, PST_path, PST_size):
+        """reference :834-866: ``ALL_PST[class][index]`` <- ``PST_path/pst_{size}_{num}.tiff`` ([P,6] float32), plus
+        device copies.  ``RFX_PST_PATH`` in the environment overrides the configured directory.  Generated templates are
+        used only if the directory is absent AND the configuration carries ``RO.PST_fallback: "generated"``."""
+        import os
+        import warnings
+        path = os.environ.get("RFX_PST_PATH") or PST_path
+        ro = self.cfg["RO"]
+        if path and os.path.isdir(path):
+            self.ALL_PST = load_pst(path, PST_size, self.tiff_index)
+            self.PST_source = path
+        elif ro.get("PST_fallback") == "generated":
+            warnings.warn(f"ROTracker: PST directory {path!r} not found; searching with GENERATED templates "
+                          "(RO.PST_fallback='generated'): poses will differ from the reference's", stacklevel=2)
+            self.ALL_PST = generated_pst(ro.get("PST_seed", 20251205), PST_size, self.tiff_index)
+            self.PST_source = "generated"
+        else:
+            self.ALL_PST = load_pst(path or "", PST_size, self.tiff_index)      # raises with the explanation
         self.ALL_PST_dev = {c: torch.from_numpy(a).to(self.device) for c, a in self.ALL_PST.items()}
 
     def get_PST(self, tiff_index):
-        cls = tiff_index // 20
-        return self.ALL_PST[cls][(tiff_index - cls * 20) // 3, ...]
+        cls, _, slot = pst_slot(tiff_index)
+        return self.ALL_PST[cls][slot, ...]
 
     def _get_PST_dev(self, tiff_index):
-        cls = tiff_index // 20
-        return self.ALL_PST_dev[cls][(tiff_index - cls * 20) // 3]
+        cls, _, slot = pst_slot(tiff_index)
+        return self.ALL_PST_dev[cls][slot]
 
     # ------------------------------------------------------------------ kernels
     def init_searchsize(self):

@@ -99,11 +99,12 @@ class moving_volume:
         return int(np.prod(self.vol_dim))
 
     def _workspace(self, H: int, W: int) -> torch.Tensor:
-        if self._ws_hw != (H, W):
-            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(H, W)
+        d = tuple(int(v) for v in self.vol_dim)
+        if self._ws_hw != (H, W) + d:
+            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(d[0], d[1], d[2], H, W)
             self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
             self._cpk = torch.empty(H * W, dtype=torch.float32, device=self.device)
-            self._ws_hw = (H, W)
+            self._ws_hw = (H, W) + d
         return self._ws
 
     def _dev(self, a, dtype=torch.float32) -> torch.Tensor:

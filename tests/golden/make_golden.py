@@ -299,7 +299,30 @@ def make_volume_bounds():
     save("volume_bounds.npz", **out)
 
 
+def make_pst_fixture():
+    """digest of the reference's 60 PST templates (PFO/fps_uniform_sphere, data files read by model/ROtracker.py:834-866
+    with cv2): per file its shape, the first 4 rows, float64 sum / sum of squares and the SHA-256 of the sample bytes
+    -- enough to tell whether a user's directory holds the same particles, without shipping the 6.9 MB of data.
+    Read here with Pillow (an independent reader: the product's own TIFF parser is checked against it)."""
+    import hashlib
+    from PIL import Image
+    d = os.path.join(REF, "PFO", "fps_uniform_sphere")
+    names, shapes, heads, sums, sqs, shas = [], [], [], [], [], []
+    for size in (10240, 3072, 1024):
+        for num in range(20):
+            a = np.ascontiguousarray(np.array(Image.open(os.path.join(d, f"pst_{size}_{num}.tiff")), dtype=np.float32))
+            names.append(f"pst_{size}_{num}.tiff"); shapes.append(a.shape); heads.append(a[:4].copy())
+            sums.append(float(a.astype(np.float64).sum())); sqs.append(float((a.astype(np.float64) ** 2).sum()))
+            shas.append(hashlib.sha256(a.tobytes()).hexdigest())
+    save("pst_fixture.npz", names=np.array(names), shapes=np.array(shapes), heads=np.stack(heads), sums=np.array(sums),
+         sqs=np.array(sqs), sha256=np.array(shas))
+
+
 if __name__ == "__main__":
+    if "--pst-only" in sys.argv:
+        make_pst_fixture()
+        sys.exit(0)
+    make_pst_fixture()
     make_decoder()
     make_render()
     make_losses()

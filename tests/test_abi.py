@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, fn), f"{fn} declared in include/rfx.h but not exported"
         assert fn in _lib.PROTOTYPES, f"{fn} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == declared
-    assert lib.rfx_abi_version() == 1
+    assert lib.rfx_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -41,8 +41,8 @@ def test_struct_layouts_match_header():
 def test_argument_validation_without_gpu():
     from remixfusion_amd import _lib
     lib = _lib.load()
-    assert lib.rfx_tsdf_integrate_workspace_bytes(480, 640) >= 256 + 480 * 640 * 8
-    assert lib.rfx_tsdf_integrate_workspace_bytes(0, 5) == 0
+    assert lib.rfx_tsdf_integrate_workspace_bytes(800, 800, 600, 480, 640) >= 256 + 480 * 640 * 8 + 800 * 800 * 10 * 8
+    assert lib.rfx_tsdf_integrate_workspace_bytes(8, 8, 8, 0, 5) == 0 and lib.rfx_tsdf_integrate_workspace_bytes(0, 8, 8, 4, 5) == 0
     assert lib.rfx_field_backward_workspace_bytes(0) == 0 and lib.rfx_field_backward_workspace_bytes(1000) > 1000 * 368 * 4
     z3, z6, z9, z16 = _lib.farr(_lib._F3, [0] * 3), _lib.farr(_lib._F6, [0] * 6), _lib.farr(_lib._F9, [0] * 9), _lib.farr(_lib._F16, [0] * 16)
     assert lib.rfx_tsdf_fill(None, None, None, 10, None) == -1                      # RFX_ERR_ARG

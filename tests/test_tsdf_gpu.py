@@ -39,7 +39,7 @@ class Vol:
         torch, L = self.torch, self.L
         H, W = depth.shape
         if self.ws is None:
-            nb = self.lib.rfx_tsdf_integrate_workspace_bytes(H, W)
+            nb = self.lib.rfx_tsdf_integrate_workspace_bytes(*self.dims, H, W)
             self.ws = torch.empty((nb + 3) // 4, device="cuda:0")
             self.cpk = torch.empty(H * W, device="cuda:0")
         d_rgb = torch.from_numpy(np.ascontiguousarray(rgb255, np.float32)).cuda().reshape(-1, 3)
@@ -129,6 +129,52 @@ def test_integrate_reintegrate_and_deintegrate():
     _assert_bit_equal(gw, ow, "weight")
     _assert_bit_equal(gt, ot, "tsdf")
     _assert_bit_equal(gc, oc, "colour")
+
+
+@pytest.mark.parametrize("dims,cuts,decode", [((200, 200, 150), (0, 37, 100, 101, 200), "reference"), ((300, 300, 250), (0, 150, 300), "reference"),
+                                              ((300, 300, 250), (0, 75, 150, 225, 300), "exact"), ((64, 48, 40), (0, 1, 63, 64), "reference")])
+def test_integrate_slabs_equal_the_whole_volume(dims, cuts, decode):
+    """multi-GPU form (rfx_tsdf_integrate_slab): the volume cut into x-slabs, each slab integrating the same frames into
+    its own arrays, is bit-identical to the whole volume -- including above 2^24 voxels, where the reference's fp32 index
+    decode aliases voxels next to the x-slab boundaries of the GLOBAL index (300x300x250: 22.5e6 voxels)."""
+    import torch
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    frames = [small_frame(frame=f)[:4] for f in (0, 11)]
+    origin, voxel, trunc = (-3, -4, -2), 0.02 if dims[0] == 300 else 0.04, 0.06 if dims[0] == 300 else 0.15
+    dec = 0 if decode == "reference" else 1
+    whole = Vol(dims, origin, voxel, trunc, 1, dec)
+    for (K, c2w, rgb, depth) in frames:
+        whole.integrate(K, c2w, rgb, depth)
+    wt, ww, wc = whole.host()
+    H, W = frames[0][3].shape
+    plane = dims[1] * dims[2]
+    st = L.stream_ptr()
+    for x0, x1 in zip(cuts[:-1], cuts[1:]):
+        n = (x1 - x0) * plane
+        t, w, c = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        nb = lib.rfx_tsdf_integrate_workspace_bytes(x1 - x0, dims[1], dims[2], H, W)
+        ws, cpk = torch.empty((nb + 3) // 4, device="cuda"), torch.empty(H * W, device="cuda")
+        for (K, c2w, rgb, depth) in frames:
+            d_rgb = torch.from_numpy(np.ascontiguousarray(rgb, np.float32)).cuda().reshape(-1, 3)
+            d_dep = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).cuda().reshape(-1)
+            L.check(lib.rfx_pack_color(L.ptr(d_rgb), L.ptr(cpk), H * W, st), "pack")
+            L.check(lib.rfx_tsdf_integrate_slab(L.ptr(t), L.ptr(w), L.ptr(c), *dims, x0, x1, L.farr(L._F3, np.asarray(origin, np.float32)),
+                                                voxel, L.farr(L._F9, K.reshape(-1)), L.farr(L._F16, c2w.reshape(-1)), L.ptr(cpk), L.ptr(d_dep),
+                                                H, W, trunc, 1.0, 1, 0, L.farr(L._F6, np.zeros(6, np.float32)), dec, L.ptr(ws),
+                                                ws.numel() * 4, st), "slab")
+        torch.cuda.synchronize()
+        sl = slice(x0 * plane, x1 * plane)
+        _assert_bit_equal(w.cpu().numpy(), ww[sl], f"weight slab [{x0},{x1})")
+        _assert_bit_equal(t.cpu().numpy(), wt[sl], f"tsdf slab [{x0},{x1})")
+        _assert_bit_equal(c.cpu().numpy(), wc[sl], f"colour slab [{x0},{x1})")
+    assert float((ww > 0).sum()) > 1000
+    # argument checks
+    t = torch.ones(plane, device="cuda")
+    rc = lib.rfx_tsdf_integrate_slab(L.ptr(t), L.ptr(t), L.ptr(t), *dims, 5, 5, L.farr(L._F3, np.asarray(origin, np.float32)), voxel,
+                                     L.farr(L._F9, K.reshape(-1)), L.farr(L._F16, c2w.reshape(-1)), L.ptr(cpk), L.ptr(d_dep), H, W, trunc, 1.0,
+                                     1, 0, L.farr(L._F6, np.zeros(6, np.float32)), dec, L.ptr(ws), ws.numel() * 4, st)
+    assert rc != 0
 
 
 def test_integrate_no_valid_depth_is_noop_and_camera_outside():
