@@ -94,6 +94,18 @@ int rfx_tsdf_shift(float* tsdf, float* weight, float* color, int dx, int dy, int
                    int odx, int ody, int odz, const float old_origin[3], float voxel,
                    int index_decode, rfx_stream stream);
 
+/* V2 on one x-slab (multi-GPU): the planes [x0, x1) of the new volume are gathered from the planes [ox_a, ox_b) of the
+ * old one; tsdf/weight/color hold only [x0, x1), old_* only [ox_a, ox_b) (the caller fetched them from the ranks that
+ * own them: rfx_tsdf_shift_source_planes says which are read).  dims/origins describe the WHOLE volumes; results are
+ * bit-identical to rfx_tsdf_shift on the whole volume.  old_* may be NULL when ox_a == ox_b (slab outside the old box). */
+int rfx_tsdf_shift_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1, const float origin[3],
+                        const float* old_tsdf, const float* old_weight, const float* old_color,
+                        int odx, int ody, int odz, int ox_a, int ox_b, const float old_origin[3], float voxel,
+                        int index_decode, rfx_stream stream);
+/* host: the old x-planes [*a, *b) that new planes [x0, x1) read in rfx_tsdf_shift_slab (one plane of slack either side). */
+int rfx_tsdf_shift_source_planes(int x0, int x1, const float origin[3], int odx, const float old_origin[3], float voxel,
+                                 int* a, int* b);
+
 /* V3: replaces `tri_intepolate` model/Volume.py:337-458 (host :760-794).
  * pts dev [n,3] world coords; out5 dev [n,5] = (tsdf, r, g, b, tsdf at low corner). */
 int rfx_tsdf_trilerp(const float* tsdf, const float* weight, const float* color, int dx, int dy, int dz,
@@ -279,6 +291,16 @@ int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float
                              const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
                              float depth_trunc, int rgb_missing_on, double* sums8, float* losses4, float* coef4,
                              rfx_stream stream);
+/* The same forward in two halves, for a ray batch spread over several GPUs (multi-GPU mapping: every rank renders a
+ * share of the batch).  rfx_mapping_loss_sums reduces THIS rank's rays to total8 dev double[8] (scratch: dev
+ * double[RFX_LOSS_WS_DOUBLES]); the caller adds total8 over the ranks (all-reduce of 64 bytes); rfx_mapping_loss_finalize
+ * forms the four losses and the backward's coefficients of the WHOLE batch (n_rays_total rays) from the summed total8.
+ * The loss weights fs_w / sdf_w depend on sample counts of the whole batch (model/utils.py:170-198), so the loss is not a
+ * sum of per-rank losses: this split keeps it identical to the single-GPU value. */
+int rfx_mapping_loss_sums(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                          const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
+                          float depth_trunc, int rgb_missing_on, double* scratch, double* total8, rfx_stream stream);
+int rfx_mapping_loss_finalize(const double* total8, int64_t n_rays_total, int S, float* losses4, float* coef4, rfx_stream stream);
 /* d_raw4 = d(sum_i gout4[i] * loss_i)/d raw4 including the path through the compositing (R1
  * backward); g_rgb_map / g_depth_map: optional extra grads on the rendered maps (may be NULL). */
 int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "rfx_tsdf_fill": (_i, [_P, _P, _P, _l, _P]),
     "rfx_tsdf_copy": (_i, [_P, _P, _P, _P, _P, _P, _l, _P]),
     "rfx_tsdf_shift": (_i, [_P, _P, _P, _i, _i, _i, _F3, _P, _P, _P, _i, _i, _i, _F3, _f, _i, _P]),
+    "rfx_tsdf_shift_slab": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _F3, _P, _P, _P, _i, _i, _i, _i, _i, _F3, _f, _i, _P]),
+    "rfx_tsdf_shift_source_planes": (_i, [_i, _i, _F3, _i, _F3, _f, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rfx_tsdf_trilerp": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _P, _l, _P, _P]),
     "rfx_tsdf_filter": (_i, [_P, _P, _P, _l, _f, _P]),
     "rfx_tsdf_truncated_pc": (_i, [_P, _P, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _i, _P]),
@@ -112,6 +114,8 @@ PROTOTYPES = {
     "rfx_composite_forward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
     "rfx_composite_backward": (_i, [_P, _P, _l, _i, _f, _f, _P, _P, _P, _P]),
     "rfx_mapping_loss_forward": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _i, _P, _P, _P, _P]),
+    "rfx_mapping_loss_sums": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _i, _P, _P, _P]),
+    "rfx_mapping_loss_finalize": (_i, [_P, _l, _i, _P, _P, _P]),
     "rfx_mapping_loss_backward": (_i, [_P, _P, _P, _P, _P, _P, _l, _i, _f, _f, _f, _f, _i, _P, _P, _P, _P, _P, _P]),
     "rfx_tv_forward": (_i, [_P, _i, _i, _P, _P]),
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),

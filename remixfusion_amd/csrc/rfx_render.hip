@@ -902,6 +902,51 @@ int rfx_mapping_loss_forward(const float* raw4, const float* z_vals, const float
     return RFX_OK;
 }
 
+// ---- the forward in two halves, for a ray batch that is spread over several GPUs: each rank reduces its rays to the
+// eight sums, the sums are added across ranks (all-reduce of 64 bytes), and every rank forms losses and coefficients
+// of the WHOLE batch from them.
+__global__ __launch_bounds__(256) void mapping_loss_total_kernel(const double* __restrict__ partial, int n_partials,
+                                                                 double* __restrict__ total8) {
+    __shared__ double part[32][8];
+    const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
+    double a = 0.0;
+    for (int k = q; k < n_partials; k += 32) a += partial[k * 8 + v];
+    part[q][v] = a;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int qq = 0; qq < 32; ++qq) t += part[qq][threadIdx.x];
+        total8[threadIdx.x] = t;
+    }
+}
+
+int rfx_mapping_loss_sums(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
+                          const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc_loss,
+                          float depth_trunc, int rgb_missing_on, double* scratch, double* total8, rfx_stream stream) {
+    if (!scratch || !total8 || n_rays < 0 || S <= 0) return RFX_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    if (n_rays == 0) {
+        RFX_HIP_TRY(hipMemsetAsync(total8, 0, 8 * sizeof(double), st));
+        return RFX_OK;
+    }
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d) return RFX_ERR_ARG;
+    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
+    const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_BLOCKS);
+    hipLaunchKernelGGL(mapping_loss_forward_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, st, L,
+                       reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, scratch);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mapping_loss_total_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, total8);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_mapping_loss_finalize(const double* total8, int64_t n_rays_total, int S, float* losses4, float* coef4, rfx_stream stream) {
+    if (!total8 || !losses4 || !coef4 || n_rays_total <= 0 || S <= 0) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), total8, 1, n_rays_total, S, losses4, coef4);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
                               const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc,
                               float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, const float* coef4,

@@ -818,19 +818,22 @@ struct ShiftParams {
     int dx, dy, dz, odx, ody, odz;
     float origin[3], old_origin[3], voxel;
     int risky_rows, literal_all;
+    int x0;           // first x-plane of the destination slab (its arrays start there); 0 for a whole volume
+    int ox_a, ox_b;   // x-planes [ox_a, ox_b) of the OLD volume that the source arrays hold (0, odx for a whole volume)
 };
 
 // V2: one block per (x,y) row of the NEW volume, threads along z.
 __global__ __launch_bounds__(256) void mv_shift_kernel(ShiftParams P, float* __restrict__ t, float* __restrict__ w,
                                                        float* __restrict__ c, const float* __restrict__ ot,
                                                        const float* __restrict__ ow, const float* __restrict__ oc) {
-    const int row = blockIdx.x;
-    const int rx = row / P.dy, ry = row - rx * P.dy;
+    const int row_l = blockIdx.x;                    // row of the destination slab
+    const int rx = P.x0 + row_l / P.dy, ry = row_l % P.dy;
     const bool risky = P.literal_all || ry < P.risky_rows || ry >= P.dy - P.risky_rows;
-    const int64_t base = (int64_t)row * P.dz;
+    const int64_t base = (int64_t)row_l * P.dz;                       // slab-local
+    const int64_t gbase = ((int64_t)rx * P.dy + ry) * P.dz;          // global index: what the literal decode sees
     for (int z = threadIdx.x; z < P.dz; z += blockDim.x) {
         float vx = (float)rx, vy = (float)ry, vz = (float)z;
-        if (risky) decode_literal((int)(base + z), P.dy, P.dz, vx, vy, vz);
+        if (risky) decode_literal((int)(gbase + z), P.dy, P.dz, vx, vy, vz);
         const float wx = madd(vx, P.voxel, P.origin[0]);
         const float wy = madd(vy, P.voxel, P.origin[1]);
         const float wz = madd(vz, P.voxel, P.origin[2]);
@@ -838,8 +841,8 @@ __global__ __launch_bounds__(256) void mv_shift_kernel(ShiftParams P, float* __r
         const int oy = (int)roundf((wy - P.old_origin[1]) / P.voxel);
         const int oz = (int)roundf((wz - P.old_origin[2]) / P.voxel);
         float a = 1.0f, b = 0.0f, d = 0.0f;
-        if (0 <= ox && ox < P.odx && 0 <= oy && oy < P.ody && 0 <= oz && oz < P.odz) {
-            const int64_t o = (int64_t)oz + (int64_t)oy * P.odz + (int64_t)ox * P.ody * P.odz;
+        if (P.ox_a <= ox && ox < P.ox_b && 0 <= oy && oy < P.ody && 0 <= oz && oz < P.odz) {
+            const int64_t o = (int64_t)oz + (int64_t)oy * P.odz + (int64_t)(ox - P.ox_a) * P.ody * P.odz;
             a = ot[o]; b = ow[o]; d = oc[o];
         }
         t[base + z] = a; w[base + z] = b; c[base + z] = d;
@@ -1270,20 +1273,53 @@ int rfx_tsdf_copy(const float* tsdf, const float* weight, const float* color,
     return RFX_OK;
 }
 
+// V2 for the x-planes [x0, x1) of the new volume, reading x-planes [ox_a, ox_b) of the old one (both array sets hold
+// only those planes); everything else as rfx_tsdf_shift: global coordinates, global index decode.
+static int shift_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1, const float origin[3],
+                      const float* old_tsdf, const float* old_weight, const float* old_color,
+                      int odx, int ody, int odz, int ox_a, int ox_b, const float old_origin[3], float voxel,
+                      int index_decode, rfx_stream stream) {
+    if (!tsdf || !weight || !color || !origin || !old_origin) return RFX_ERR_ARG;
+    if (dx <= 0 || dy <= 0 || dz <= 0 || odx <= 0 || ody <= 0 || odz <= 0 || !(voxel > 0.0f)) return RFX_ERR_ARG;
+    if (x0 < 0 || x1 > dx || x1 <= x0 || ox_a < 0 || ox_b > odx || ox_b < ox_a) return RFX_ERR_ARG;
+    if (ox_b > ox_a && (!old_tsdf || !old_weight || !old_color)) return RFX_ERR_ARG;
+    if ((int64_t)dx * dy * dz >= (1LL << 31)) return RFX_ERR_UNSUPPORTED;
+    ShiftParams P;
+    P.dx = dx; P.dy = dy; P.dz = dz; P.odx = odx; P.ody = ody; P.odz = odz; P.voxel = voxel;
+    P.x0 = x0; P.ox_a = ox_a; P.ox_b = ox_b;
+    for (int i = 0; i < 3; ++i) { P.origin[i] = origin[i]; P.old_origin[i] = old_origin[i]; }
+    decode_split(dx, dy, dz, index_decode, &P.risky_rows, &P.literal_all);
+    hipLaunchKernelGGL(mv_shift_kernel, dim3((unsigned)((int64_t)(x1 - x0) * dy)), dim3(256), 0, as_stream(stream), P, tsdf,
+                       weight, color, old_tsdf, old_weight, old_color);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 int rfx_tsdf_shift(float* tsdf, float* weight, float* color, int dx, int dy, int dz, const float origin[3],
                    const float* old_tsdf, const float* old_weight, const float* old_color,
                    int odx, int ody, int odz, const float old_origin[3], float voxel,
                    int index_decode, rfx_stream stream) {
-    if (!tsdf || !weight || !color || !old_tsdf || !old_weight || !old_color || !origin || !old_origin) return RFX_ERR_ARG;
-    if (dx <= 0 || dy <= 0 || dz <= 0 || odx <= 0 || ody <= 0 || odz <= 0 || !(voxel > 0.0f)) return RFX_ERR_ARG;
-    if ((int64_t)dx * dy * dz >= (1LL << 31)) return RFX_ERR_UNSUPPORTED;
-    ShiftParams P;
-    P.dx = dx; P.dy = dy; P.dz = dz; P.odx = odx; P.ody = ody; P.odz = odz; P.voxel = voxel;
-    for (int i = 0; i < 3; ++i) { P.origin[i] = origin[i]; P.old_origin[i] = old_origin[i]; }
-    decode_split(dx, dy, dz, index_decode, &P.risky_rows, &P.literal_all);
-    hipLaunchKernelGGL(mv_shift_kernel, dim3((unsigned)((int64_t)dx * dy)), dim3(256), 0, as_stream(stream), P, tsdf,
-                       weight, color, old_tsdf, old_weight, old_color);
-    RFX_LAUNCH_CHECK();
+    if (!old_tsdf || !old_weight || !old_color) return RFX_ERR_ARG;
+    return shift_slab(tsdf, weight, color, dx, dy, dz, 0, dx, origin, old_tsdf, old_weight, old_color, odx, ody, odz, 0, odx, old_origin,
+                      voxel, index_decode, stream);
+}
+
+int rfx_tsdf_shift_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1, const float origin[3],
+                        const float* old_tsdf, const float* old_weight, const float* old_color,
+                        int odx, int ody, int odz, int ox_a, int ox_b, const float old_origin[3], float voxel,
+                        int index_decode, rfx_stream stream) {
+    return shift_slab(tsdf, weight, color, dx, dy, dz, x0, x1, origin, old_tsdf, old_weight, old_color, odx, ody, odz, ox_a, ox_b,
+                      old_origin, voxel, index_decode, stream);
+}
+
+// old x-planes a slab of the new volume reads (host; same arithmetic as mv_shift_kernel, one plane of slack either side,
+// clipped to the old volume): [*a, *b), empty when the slab lies outside the old volume
+int rfx_tsdf_shift_source_planes(int x0, int x1, const float origin[3], int odx, const float old_origin[3], float voxel, int* a, int* b) {
+    if (!origin || !old_origin || !a || !b || x1 <= x0 || !(voxel > 0.0f)) return RFX_ERR_ARG;
+    const float w0 = fmaf((float)x0, voxel, origin[0]), w1 = fmaf((float)(x1 - 1), voxel, origin[0]);
+    const long lo = lroundf((w0 - old_origin[0]) / voxel) - 1, hi = lroundf((w1 - old_origin[0]) / voxel) + 2;
+    *a = (int)std::max<long>(0, std::min<long>(odx, lo));
+    *b = (int)std::max<long>(*a, std::min<long>(odx, hi));
     return RFX_OK;
 }
 

@@ -24,6 +24,8 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from .model.Volume import moving_volume
+
 
 def partition_config(cfg: Dict, rank: int, world: int) -> Dict:
     """config of slab ``rank``: bound / room / marching-cubes bound shifted along x so that adjacent
@@ -108,3 +110,295 @@ def exchange_planes(dist, rank: int, left: Optional[int], right: Optional[int], 
 
 def make_shard(cfg: Dict, rank: int, world: int, dist=None) -> ScenePartition:
     return ScenePartition(cfg, rank, world, dist)
+
+
+# ============================================================================================================
+# ONE scene over N GPUs (BASELINE configs 4 / 5)
+# ============================================================================================================
+# One camera stream.  The moving TSDF volume is cut into contiguous x-slabs (x is the slowest axis of the reference
+# layout, model/Volume.py:224-226: idx = z + y*Dz + x*Dy*Dz, so a slab is one contiguous range of the three arrays);
+# every rank integrates the SAME frame into its slab (rfx_tsdf_integrate_slab: global indices and coordinates, hence
+# bit-identical to the unsharded volume) -- V1 needs no voxel exchange.  When the volume follows the camera (V2,
+# model/Volume.py:796-855) a shift along x crosses slab boundaries: each rank fetches the old x-planes its new slab
+# reads from the ranks that own them (point-to-point, contiguous plane ranges) and gathers locally
+# (rfx_tsdf_shift_slab).  The residual field and the global explicit volume are small (6.6 MB .. 166 MB, 160 MB) and
+# replicated: each rank renders a strided share of an iteration's ray batch, the loss sums are all-reduced before the
+# loss weights are formed (so the loss is that of the whole batch), and the gradients (hash table, decoder, poses) are
+# all-reduced before the identical Adam step on every rank.  Collectives: broadcast (frame, 8*H*W B), send/recv
+# (volume move), all-reduce (56 B of loss sums; gradients).  torch.distributed: backend "nccl" = RCCL over xGMI on the
+# GPUs, "gloo" for the CPU / single-GPU rehearsal (device tensors are staged through the host there).
+
+def slab_bounds(dx: int, world: int) -> List[int]:
+    """x-plane cuts [c_0 = 0, ..., c_world = dx]: slab r is [c_r, c_{r+1}); sizes differ by at most one plane."""
+    return [(dx * r) // world for r in range(world + 1)]
+
+
+def _host_staged(dist, t: torch.Tensor) -> bool:
+    return dist is not None and t.is_cuda and dist.get_backend() == "gloo"
+
+
+def broadcast_(dist, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """in-place broadcast of a device tensor (gloo: via the host)."""
+    if dist is None or dist.get_world_size() == 1:
+        return t
+    if _host_staged(dist, t):
+        h = t.cpu()
+        dist.broadcast(h, src)
+        if dist.get_rank() != src:
+            t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+    return t
+
+
+def all_reduce_sum_(dist, tensors) -> None:
+    """in-place sum over ranks of a list of tensors (one flattened bucket per dtype: the hash gradient dominates)."""
+    if dist is None or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in tensors if t is not None]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for ts in by_dtype.values():
+        if len(ts) == 1 and ts[0].is_contiguous():
+            flat = ts[0].view(-1)
+        else:
+            flat = torch.cat([t.reshape(-1) for t in ts])
+        if _host_staged(dist, flat):
+            h = flat.cpu()
+            dist.all_reduce(h)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat)
+        if not (len(ts) == 1 and ts[0].is_contiguous()):
+            o = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view_as(t))
+                o += n
+
+
+def shift_plan(cuts: List[int], need: List) -> List:
+    """who sends which old x-planes to whom when the volume moves: need[r] = (a_r, b_r) are the old planes rank r's new
+    slab reads; cuts are the (unchanged) slab boundaries of the old volume.  Returns [(src, dst, p0, p1)] with src != dst,
+    in a canonical order every rank derives identically."""
+    plan = []
+    world = len(cuts) - 1
+    for dst in range(world):
+        a, b = need[dst]
+        for src in range(world):
+            p0, p1 = max(a, cuts[src]), min(b, cuts[src + 1])
+            if p1 > p0 and src != dst:
+                plan.append((src, dst, p0, p1))
+    return plan
+
+
+class sharded_volume(moving_volume):
+    """x-slab ``rank`` of ``world`` of a moving TSDF volume: the reference's ``moving_volume`` interface
+    (model/Volume.py:19-1408) over one slab.  Host bound logic is inherited unchanged (every rank follows the same camera,
+    so all ranks take the same decisions); device state is the slab only."""
+
+    def __init__(self, cfg, traj, init_pose, rank: int, world: int, dist=None, device=None, start=0):
+        self.rank, self.world, self.dist = int(rank), int(world), dist
+        super().__init__(cfg, traj, init_pose, start=start, device=device)
+
+    # -- geometry of the slab
+    def _cuts(self):
+        return slab_bounds(int(self.vol_dim[0]), self.world)
+
+    def _slab(self):
+        c = self._cuts()
+        return c[self.rank], c[self.rank + 1]
+
+    def _n(self) -> int:
+        x0, x1 = self._slab()
+        return (x1 - x0) * int(self.vol_dim[1]) * int(self.vol_dim[2])
+
+    def _alloc_voxels(self) -> int:
+        """voxels to allocate: the widest slab this rank can get (slab widths differ by at most one plane)"""
+        d = self.vol_dim
+        return (int(d[0]) // self.world + 1) * int(d[1]) * int(d[2])
+
+    def _workspace(self, H: int, W: int):
+        from . import _lib
+        d = tuple(int(v) for v in self.vol_dim)
+        x0, x1 = self._slab()
+        key = (H, W, x1 - x0) + d[1:]
+        if self._ws_hw != key:
+            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(x1 - x0, d[1], d[2], H, W)
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self._cpk = torch.empty(H * W, dtype=torch.float32, device=self.device)
+            self._ws_hw = key
+        return self._ws
+
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, old_bnd, obs_weight=1., reintegrate_flag=0.0, color_packed=None):
+        """V1 on this rank's slab (every rank is handed the same frame)."""
+        from . import _lib
+        from ._lib import _F3, _F6, _F9, _F16, check, farr, ptr, stream_ptr
+        lib = _lib.load()
+        H, W = depth_im.shape[-2:]
+        ws = self._workspace(H, W)
+        st = stream_ptr(self.device)
+        depth = self._dev(depth_im).reshape(-1)
+        if color_packed is None:
+            rgb = self._dev(color_im).reshape(-1, 3)
+            check(lib.rfx_pack_color(ptr(rgb), ptr(self._cpk), H * W, st), "rfx_pack_color")
+            color_packed = self._cpk
+        K = np.asarray(cam_intr.detach().cpu() if isinstance(cam_intr, torch.Tensor) else cam_intr, np.float32).reshape(-1)
+        c2w = np.asarray(cam_pose.detach().cpu() if isinstance(cam_pose, torch.Tensor) else cam_pose, np.float32).reshape(-1)
+        ob = np.zeros(6, np.float32) if old_bnd is None else np.asarray(old_bnd, np.float32).reshape(-1)
+        d = self.vol_dim
+        x0, x1 = self._slab()
+        check(lib.rfx_tsdf_integrate_slab(ptr(self.tsdf_vol_gpu), ptr(self.weight_vol_gpu), ptr(self.color_vol_gpu),
+                                          int(d[0]), int(d[1]), int(d[2]), x0, x1, farr(_F3, self.vol_origin), self.voxel_size,
+                                          farr(_F9, K), farr(_F16, c2w), ptr(color_packed), ptr(depth), H, W,
+                                          float(self.trunc_margin), float(obs_weight), int(self.weight_clamp == 1.0),
+                                          int(reintegrate_flag == 1.0), farr(_F6, ob), self.index_decode,
+                                          ptr(ws), ws.numel() * 4, st), "rfx_tsdf_integrate_slab")
+
+    def update_tsdf_swap_rot_trans(self, vol_bnds, old_bnds):
+        """V2 across slabs: fetch the old planes this slab reads from their owners, then gather locally."""
+        import ctypes as C
+        from . import _lib
+        from ._lib import _F3, check, farr, ptr, stream_ptr
+        lib = _lib.load()
+        old_cuts = self._cuts()
+        old_dim = np.ceil((old_bnds[:, 1] - old_bnds[:, 0]) / self.voxel_size).copy(order="C").astype(int)
+        old_origin = old_bnds[:, 0].copy(order="C").astype(np.float32)
+        self._set_geometry(vol_bnds)
+        d = [int(v) for v in self.vol_dim]
+        cuts = self._cuts()
+        plane = int(old_dim[1]) * int(old_dim[2])
+        need = []
+        for r in range(self.world):
+            a, b = C.c_int(0), C.c_int(0)
+            check(lib.rfx_tsdf_shift_source_planes(cuts[r], cuts[r + 1], farr(_F3, self.vol_origin), int(old_dim[0]),
+                                                   farr(_F3, old_origin), self.voxel_size, C.byref(a), C.byref(b)), "source_planes")
+            need.append((a.value, b.value))
+        a, b = need[self.rank]
+        backs = self._backs()                      # copy_volume() put the old slab there (old planes [oc0, oc1))
+        oc0, oc1 = old_cuts[self.rank], old_cuts[self.rank + 1]
+        stage = [torch.empty(max(b - a, 0) * plane, dtype=torch.float32, device=self.device) for _ in range(3)]
+        # own planes: device copy
+        p0, p1 = max(a, oc0), min(b, oc1)
+        if p1 > p0:
+            for s_, bk in zip(stage, backs):
+                s_[(p0 - a) * plane:(p1 - a) * plane].copy_(bk[(p0 - oc0) * plane:(p1 - oc0) * plane])
+        # remote planes: point-to-point, canonical order
+        plan = shift_plan(old_cuts, need)
+        if plan and self.dist is not None:
+            host = _host_staged(self.dist, stage[0])
+            ops, recvs = [], []
+            for (src, dst, q0, q1) in plan:
+                for k in range(3):
+                    if src == self.rank:
+                        buf = backs[k][(q0 - oc0) * plane:(q1 - oc0) * plane]
+                        ops.append(self.dist.P2POp(self.dist.isend, buf.cpu() if host else buf.contiguous(), dst))
+                    elif dst == self.rank:
+                        view = stage[k][(q0 - a) * plane:(q1 - a) * plane]
+                        buf = torch.empty(view.shape, dtype=torch.float32) if host else view
+                        ops.append(self.dist.P2POp(self.dist.irecv, buf, src))
+                        if host:
+                            recvs.append((view, buf))
+            if ops:
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()     # the back copy is complete before it is sent
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()
+                for view, buf in recvs:
+                    view.copy_(buf)
+        t, w, c = self._vols()
+        x0, x1 = cuts[self.rank], cuts[self.rank + 1]
+        check(lib.rfx_tsdf_shift_slab(ptr(t), ptr(w), ptr(c), d[0], d[1], d[2], x0, x1, farr(_F3, self.vol_origin),
+                                      ptr(stage[0]) if b > a else None, ptr(stage[1]) if b > a else None, ptr(stage[2]) if b > a else None,
+                                      int(old_dim[0]), int(old_dim[1]), int(old_dim[2]), a, b, farr(_F3, old_origin),
+                                      self.voxel_size, self.index_decode, stream_ptr(self.device)), "rfx_tsdf_shift_slab")
+
+    def get_volume_all(self):
+        """this rank's slab (three flat arrays, z fastest); ``gather_whole`` assembles the volume on every rank"""
+        self._wait_for_producer()
+        n = self._n()
+        return self.tsdf_vol_gpu[:n].cpu().numpy(), self.weight_vol_gpu[:n].cpu().numpy(), self.color_vol_gpu[:n].cpu().numpy()
+
+    def gather_whole(self):
+        """the whole volume as three host arrays on every rank (tests / meshing): all_gather of the slabs"""
+        parts = self.get_volume_all()
+        if self.dist is None or self.world == 1:
+            return parts
+        out = []
+        cuts = self._cuts()
+        plane = int(self.vol_dim[1]) * int(self.vol_dim[2])
+        width = max(cuts[r + 1] - cuts[r] for r in range(self.world)) * plane
+        for p in parts:
+            mine = torch.zeros(width, dtype=torch.float32)
+            mine[:p.size] = torch.from_numpy(p)
+            bufs = [torch.empty(width, dtype=torch.float32) for _ in range(self.world)]
+            self.dist.all_gather(bufs, mine)
+            out.append(np.concatenate([bufs[r][:(cuts[r + 1] - cuts[r]) * plane].numpy() for r in range(self.world)]))
+        return tuple(out)
+
+
+class SceneShard:
+    """what Mapper / ShardedIterations need to know about the process group"""
+
+    def __init__(self, dist, rank: int, world: int):
+        self.dist, self.rank, self.world = dist, int(rank), int(world)
+
+
+def ShardedPipeline(config: Dict, dist, rank: int, world: int, device: str = "cuda:0", n_frames: Optional[int] = None, seed: int = 0):
+    """MappingPipeline over ONE scene on ``world`` GPUs: rank 0 is the camera (it renders / reads the frame and broadcasts
+    depth + colour), every rank integrates the frame into its x-slab of the moving volume, integrates keyframes into its
+    replica of the global volume, and takes a strided share of each iteration's ray batch (mp_slam/sharded.py)."""
+    from .pipeline import MappingPipeline
+
+    class _Sharded(MappingPipeline):
+        def __init__(self):
+            self._shard = SceneShard(dist, rank, world)
+            super().__init__(config, device=device, n_frames=n_frames, seed=seed)
+            self.mapper.scene_shard = self._shard
+            self.mapper._direct = None
+
+        def _make_volume(self, config, traj, pose0):
+            return sharded_volume(config, traj, pose0, rank, world, dist, device=self.device)
+
+        def prefetch(self, ids):
+            """frames resident in HBM on every rank: rank 0 produces them, the others receive depth and colour"""
+            frames = super().prefetch(ids) if rank == 0 else None
+            if rank != 0:
+                H, W = self.dataset.H, self.dataset.W
+                frames = {}
+                for i in ids:
+                    frames[i] = {"frame_id": i, "c2w": self.dataset.poses[i], "direction": self.dataset.rays_d,
+                                 "rgb": torch.empty((H, W, 3), dtype=torch.float32, device=self.device),
+                                 "depth": torch.empty((H, W), dtype=torch.float32, device=self.device)}
+            for i in ids:
+                broadcast_(dist, frames[i]["rgb"], 0)
+                broadcast_(dist, frames[i]["depth"], 0)
+                if rank != 0:
+                    b = frames[i]
+                    b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
+                    b["c2w_dev"] = b["c2w"].to(self.device)
+                    self.dataset._cache[i] = {k: b[k] for k in ("frame_id", "c2w", "rgb", "depth", "direction")}
+            if self.mv_stream is not None:
+                self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))
+            return frames
+
+        def start(self, batch0, first_iters=None):
+            """frame 0 on every rank (replicated: 200-1000 small iterations), then the replicas are made identical once:
+            rank 0's parameters and Adam state (float atomics make the ranks' first-frame results differ in the last bits);
+            from here on all-reduced gradients keep them identical"""
+            super().start(batch0, first_iters)
+            self.sync_replicas()
+
+        def sync_replicas(self):
+            with torch.no_grad():
+                for prm in self.model.parameters():
+                    if prm.numel():
+                        broadcast_(dist, prm.data, 0)
+                for opt in (self.slam.map_optimizer, self.slam.rba_optimizer):
+                    for st in opt.state.values():
+                        for k in ("exp_avg", "exp_avg_sq"):
+                            if k in st:
+                                broadcast_(dist, st[k], 0)
+
+    return _Sharded()

@@ -65,7 +65,7 @@ class moving_volume:
             raise _lib.RfxError("moving_volume needs a HIP device")
         self.gpu_mode = True
         self.device = torch.device(device if device is not None else "cuda:0")
-        n = int(np.prod(self.vol_dim))
+        n = self._alloc_voxels()
         self._capacity = n
         dev = self.device
         # tsdf=1, weight=0, colour=0 (reference :85-107); sized for 288 GB HBM: front + back resident
@@ -86,7 +86,7 @@ class moving_volume:
         self.vol_dim = np.ceil((bnds[:, 1] - bnds[:, 0]) / self.voxel_size).copy(order="C").astype(int)
         self.vol_bnds[:, 1] = self.vol_bnds[:, 0] + self.vol_dim * self.voxel_size
         self.vol_origin = self.vol_bnds[:, 0].copy(order="C").astype(np.float32)
-        if hasattr(self, "_capacity") and int(np.prod(self.vol_dim)) > self._capacity:
+        if hasattr(self, "_capacity") and self._n() > self._capacity:
             raise _lib.RfxError("volume grew past its allocation (reference would overflow here)")
 
     def _vols(self):
@@ -96,6 +96,10 @@ class moving_volume:
         return self.tsdf_vol_gpu_back, self.weight_vol_gpu_back, self.color_vol_gpu_back
 
     def _n(self) -> int:
+        return int(np.prod(self.vol_dim))
+
+    def _alloc_voxels(self) -> int:
+        """voxels per array to allocate (dist.sharded_volume: one x-slab)"""
         return int(np.prod(self.vol_dim))
 
     def _workspace(self, H: int, W: int) -> torch.Tensor:

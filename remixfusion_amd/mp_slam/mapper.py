@@ -283,7 +283,15 @@ class Mapper:
         """graph-free issue of the BA iterations (mp_slam/direct.py) when the configuration allows it."""
         if getattr(self, "_direct", None) is None:
             from .direct import DirectIterations
-            self._direct = DirectIterations(self) if DirectIterations.supported(self) else False
+            sh = getattr(self, "scene_shard", None)        # dist.ShardedPipeline: ONE scene over several GPUs
+            if sh is not None:
+                from .sharded import ShardedIterations
+                if not DirectIterations.supported(self):
+                    raise _lib.RfxError("the sharded scene needs the configuration DirectIterations supports "
+                                        "(device ray sampling, accumulation steps of 1, TV term on)")
+                self._direct = ShardedIterations(self, sh.dist, sh.rank, sh.world)
+            else:
+                self._direct = DirectIterations(self) if DirectIterations.supported(self) else False
         return self._direct or None
 
     def convert_relative_pose(self, idx=None):

@@ -29,11 +29,12 @@ class MappingPipeline:
         self.traj = Trajectory()
         self.K = self.dataset.K()
         pose0 = self.dataset.poses[0].numpy().astype(np.float64)
-        self.mv = moving_volume(config, self.traj, pose0, device=self.device) if shard is None \
+        self.mv = self._make_volume(config, self.traj, pose0) if shard is None \
             else shard.make_volume(config, self.traj, pose0, self.device)
         self.shard = shard
         self.slam = self.mapper = self.model = None
         if not self.tsdf_only:
+            SLAM.seed_everything(None, seed)       # before the decoder / pose-MLP initialisers draw: a run is a function of `seed`
             bb = torch.from_numpy(np.array(config["mapping"]["bound"])).to(self.device)
             num_kf = int(self.dataset.num_frames // config["mapping"]["keyframe_every"] + 1)
             self.model = JointEncoding(config, bb, num_kf).to(self.device)
@@ -67,6 +68,9 @@ class MappingPipeline:
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
             self.mv.producer_stream = self.mv_stream     # readers on other streams (get_volume_all, ...) wait for it
         self.frames_done = 0
+
+    def _make_volume(self, config, traj, pose0):
+        return moving_volume(config, traj, pose0, device=self.device)
 
     # frames are rendered once and kept resident in HBM (bench: inputs resident before the timed region)
     def prefetch(self, ids: List[int]) -> Dict[int, Dict]:
@@ -107,6 +111,12 @@ class MappingPipeline:
         else:
             if rgb255 is None:                          # not prefetched: the frame was just produced on the current stream
                 self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))
+                # ... and was allocated there: tell the caching allocator that the volume's stream reads these blocks, or it
+                # may hand them to new current-stream work while the queued integrate is still reading them
+                for k in ("rgb", "depth"):
+                    v = batch.get(k)
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(self.mv_stream)
             with torch.cuda.stream(self.mv_stream):
                 self._integrate(i, batch, rgb255, pose_np)
         if self.slam is not None:

@@ -68,3 +68,51 @@ def test_ghost_plane_exchange_world2(tmp_path):
     assert torch.equal(v0[:, :, :R - 1], b0[:, :, :R - 1]) and torch.equal(v1[:, :, 1:], b1[:, :, 1:])
     # after the exchange both ranks agree on the two overlap planes
     assert torch.equal(v0[:, :, R - 2], v1[:, :, 0]) and torch.equal(v0[:, :, R - 1], v1[:, :, 1])
+
+
+# ---- ONE scene over N ranks: host logic (slab cuts, move plan) and the collective helpers on gloo
+def test_slab_bounds_and_shift_plan():
+    from remixfusion_amd.dist import shift_plan, slab_bounds
+    assert slab_bounds(800, 8) == [0, 100, 200, 300, 400, 500, 600, 700, 800]
+    c = slab_bounds(7, 3)
+    assert c[0] == 0 and c[-1] == 7 and all(b > a for a, b in zip(c[:-1], c[1:]))
+    cuts = slab_bounds(800, 4)
+    # the volume moves +1 m at 1 cm: new plane x reads old plane x + 100; one plane of slack either side
+    need = [(max(0, cuts[r] + 100 - 1), min(800, cuts[r + 1] + 100 + 1)) for r in range(4)]
+    plan = shift_plan(cuts, need)
+    assert all(s != d for s, d, _, _ in plan)
+    for r in range(4):                                   # every needed remote plane is sent exactly once
+        got = sorted((p0, p1) for s, d, p0, p1 in plan if d == r)
+        a, b = need[r]
+        remote = [(max(a, cuts[s]), min(b, cuts[s + 1])) for s in range(4) if s != r and min(b, cuts[s + 1]) > max(a, cuts[s])]
+        assert got == sorted(remote)
+    assert (1, 0, 200, 301) in plan and (0, 1, 299, 200) not in plan
+    assert shift_plan(cuts, [(c0, c1) for c0, c1 in zip(cuts[:-1], cuts[1:])]) == []      # no move: nothing to send
+
+
+def _worker_collectives(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from remixfusion_amd.dist import all_reduce_sum_, broadcast_
+    a = torch.full((5,), float(rank + 1))
+    b = torch.arange(6, dtype=torch.float32).view(2, 3).t()          # non-contiguous view
+    b = b * (rank + 1)
+    d = torch.full((8,), 0.5 * (rank + 1), dtype=torch.float64)
+    all_reduce_sum_(dist, [a, None, b, d])
+    f = torch.full((4,), float(rank * 10 + 3))
+    broadcast_(dist, f, 0)
+    torch.save({"a": a, "b": b, "d": d, "f": f}, os.path.join(out_dir, f"c{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_helpers_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker_collectives, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        c = torch.load(os.path.join(tmp_path, f"c{r}.pt"))
+        assert torch.equal(c["a"], torch.full((5,), 3.0))
+        assert torch.equal(c["b"], torch.arange(6, dtype=torch.float32).view(2, 3).t() * 3)
+        assert torch.equal(c["d"], torch.full((8,), 1.5, dtype=torch.float64))
+        assert torch.equal(c["f"], torch.full((4,), 3.0))
