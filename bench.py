@@ -10,8 +10,11 @@ map_every = 5 frames) -- keyframe integration into the global volume plus iters 
 BA_iters (5) pose optimisation steps of the residual field (forward, backward, Adam), exactly
 the reference schedule.  All frames are rendered and resident in HBM before the timed region.
 Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @ 1 cm, ground-truth-initialised poses).
-At N>1 every rank maps its own spatial partition of an N-times larger scene (weak scaling) and
-exchanges the boundary planes of the global volume with its neighbours over RCCL.
+At N>1 two things are measured, back to back.  `value` (weak scaling): every rank maps its own spatial partition of an
+N-times larger scene and exchanges the boundary planes of the global volume with its neighbours over RCCL.
+`one_scene` (strong scaling): the SAME single scene over the N GPUs -- the moving volume cut into x-slabs that all
+integrate the broadcast frame, the field replicated, each rank rendering a share of every ray batch, loss sums and
+gradients all-reduced (remixfusion_amd/dist.py, mp_slam/sharded.py); frames/s of that one camera stream.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream) and `cpu_baseline` (the C / torch CPU oracle timed on this host's cores).
@@ -51,6 +54,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-frames", type=int, default=3)
     ap.add_argument("--no-process-warmup", action="store_true", help="skip the throwaway pipeline that loads kernels / primes the allocator")
+    ap.add_argument("--pos-fp16", action="store_true",
+                    help="opt in to OneBlob outputs rounded to fp16 on the fp16 matrix pipe (NOT the reference's precision, which "
+                         "is fp32: model/encodings.py:73); reported in dtype/config")
+    ap.add_argument("--no-one-scene", action="store_true", help="N>1: skip the strong-scaling run of ONE sharded scene")
     ap.add_argument("--unused-gradients", action="store_true",
                     help="pose iterations also compute the map gradients the reference's backward produces and then zeroes "
                          "(mapping.unused_gradients); results are the same, only slower")
@@ -97,9 +104,9 @@ class KernelTimer:
 
 
 def cpu_baseline(cfg, frame, model_points: int):
-    """Oracle timed on the host: TSDF integrate of one full frame into the full-size volume (C,
-    1 thread) + one optimisation iteration of the field on a point sample (torch CPU, all cores),
-    scaled to the per-frame schedule.  A reported baseline, not a target."""
+    """Oracle timed on the host: TSDF integrate of one full frame into the full-size volume (C, the voxel range cut over
+    `cores` threads) + one optimisation iteration of the field on a point sample (torch CPU, `cores` threads), scaled to
+    the per-frame schedule.  A reported baseline, not a target."""
     from oracle import field_oracle as FO
     from oracle import tsdf as OT
     cores = min(os.cpu_count() or 1, 16)     # torch-CPU ops of this size stop scaling (and thrash) beyond ~16 threads
@@ -117,7 +124,8 @@ def cpu_baseline(cfg, frame, model_points: int):
     cpk = OT.pack_color(frame["rgb255"].cpu().numpy())
     depth = frame["depth"].cpu().numpy()
     t0 = time.time()
-    upd, col = OT.load().mv_integrate(t, w, c, dims, origin.astype(np.float32), vol["voxel_size"], K, c2w, cpk, depth, vol["trunc"])
+    upd, col = OT.load().mv_integrate_threads(t, w, c, dims, origin.astype(np.float32), vol["voxel_size"], K, c2w, cpk, depth, vol["trunc"],
+                                              threads=cores)
     t_v1 = time.time() - t0
     del t, w, c
     # --- one field iteration (forward + backward) on a sample of the points, torch CPU
@@ -147,10 +155,55 @@ def cpu_baseline(cfg, frame, model_points: int):
     iters_per_frame = (m["iters"] + m["BA_iters"]) / m["map_every"]
     t_frame = t_v1 + iters_per_frame * t_iter
     return {"value": round(1.0 / t_frame, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"C oracle mv_integrate of 1 frame into {dims[0]}x{dims[1]}x{dims[2]} voxels on 1 core ({t_v1:.2f} s, "
+            "sample": f"C oracle mv_integrate of 1 frame into {dims[0]}x{dims[1]}x{dims[2]} voxels on {cores} threads ({t_v1:.2f} s, "
                       f"{upd} voxels updated) + torch-CPU oracle field fwd+bwd on {sample} of {n_pts_iter} points/iter "
                       f"on {cores} cores ({t_iter_sample:.2f} s, scaled), {iters_per_frame:g} iters/frame",
             "v1_seconds": round(t_v1, 3), "field_iter_seconds_scaled": round(t_iter, 2)}
+
+
+def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
+    """frames/s of ONE camera stream mapped by `world` GPUs together (remixfusion_amd/dist.py): the moving volume in
+    x-slabs, every rank integrating the frame rank 0 broadcast; keyframes integrated into every replica of the global
+    volume; each BA iteration's ray batch shared out, loss sums and gradients all-reduced.  Same barrier / max-over-ranks
+    timing as the main line."""
+    from remixfusion_amd.dist import ShardedPipeline, broadcast_
+    if args.first_iters is not None:
+        cfg["mapping"]["first_iters"] = args.first_iters
+    cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
+    if args.pos_fp16:
+        cfg["pos"]["fp16_opt_in"] = True
+    pipe = ShardedPipeline(cfg, dist, rank, world, device=device, n_frames=n_frames + 8, seed=0)
+    frames = pipe.prefetch(list(range(n_frames)))            # rank 0 renders, the others receive (resident before timing)
+    pipe.start(frames[0])
+    for i in range(1, 1 + args.warmup):
+        pipe.step(i, frames[i])
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(1 + args.warmup, n_frames):
+        # the camera is rank 0: in the timed loop the frame's depth and colour travel to the other ranks (16 H W bytes)
+        for k in ("depth", "rgb255"):
+            broadcast_(dist, frames[i][k], 0)
+        pipe.step(i, frames[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    x0, x1 = pipe.mv._slab()
+    return {"value": round(args.steps / elapsed, 2), "unit": "frames/s", "scaling": "strong", "n_gpus": world,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "workload": "the N = 1 scene and camera stream, unchanged, on all GPUs together",
+            "partition": f"moving volume in {world} x-slabs of {x1 - x0} planes (every rank integrates the broadcast frame, no voxel "
+                         "exchange; P2P plane exchange when the volume moves); residual field + global volume replicated, ray "
+                         "batches shared out, all-reduce of 64 B of loss sums and of the gradients per iteration",
+            "collectives_per_frame": "broadcast 16*H*W B (depth + rgb); per BA iteration all-reduce 64 B + gradients "
+                                     f"({int(pipe.model.embed_res_fn.params.numel() * 4 / 1e6 * 10) / 10} MB hash table, 21 KB decoder)"}
 
 
 def main():
@@ -191,6 +244,8 @@ def main():
     if args.first_iters is not None:
         cfg["mapping"]["first_iters"] = args.first_iters
     cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
+    if args.pos_fp16:
+        cfg["pos"]["fp16_opt_in"] = True
     n_frames = 1 + args.warmup + args.steps
     shard = make_shard(cfg, rank, world, dist) if world > 1 else None
     if shard is not None:
@@ -292,6 +347,11 @@ def main():
         render = rays_d.shape[0] * args.render_frames / (time.perf_counter() - t1)
         timer.enabled = False
 
+    # ---- N > 1: ONE scene over the N GPUs (strong scaling): same stream, same schedule as the N = 1 workload
+    one_scene = None
+    if dist is not None and not args.no_one_scene:
+        one_scene = run_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -361,14 +421,17 @@ def main():
                                                      "note": "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
                                                              "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
                                                              "non-zero entry; bound by LDS atomics / index arithmetic, not HBM",
-                                                     # for orientation: ds_add_f32 retires 0.38 lanes/clock/CU on gfx950, 2.03e11 lane-adds/s
-                                                     # chip-wide (tools/micro/lds_atomic.hip, time-based), which is what bounds the float
-                                                     # variant; algorithmic adds = points x 16 levels x 8 corners x 2 features (the register
-                                                     # run accumulation merges some before they reach LDS; the double variant issues ~9x faster)
-                                                     "lds_atomic": {"algorithmic_lane_adds": int(pts * 256),
-                                                                    "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
-                                                                    "ds_add_f32_peak_per_s_measured": 2.03e11,
-                                                                    "frac": round(pts * 256 / (ms * 1e-3) / 2.03e11, 3)}}
+                                                     # algorithmic adds = points x 16 levels x 8 corners x 2 features, priced against the
+                                                     # LDS atomic of the accumulator type this table size uses (tools/micro/lds_atomic.hip:
+                                                     # a full-wave ds_add_f64 retires in 19 clocks per CU, ds_add_f32 in 169; x 256 CUs x 2.4 GHz).
+                                                     # The register run accumulation merges adds of consecutive points in one cell before
+                                                     # they reach LDS, so the issued count is lower than the algorithmic one.
+                                                     "lds_atomic": (lambda f64: {"accumulator": "f64" if f64 else "f32",
+                                                                                 "algorithmic_lane_adds": int(pts * 256),
+                                                                                 "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
+                                                                                 "peak_per_s_measured": 2.07e12 if f64 else 2.03e11,
+                                                                                 "frac": round(pts * 256 / (ms * 1e-3) / (2.07e12 if f64 else 2.03e11), 3)})(
+                                                         cfg["grid"]["hash_size"] <= 17)}
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]
         pts = float(evs[0][2][6]) * S
@@ -398,7 +461,7 @@ def main():
         if uc is not None:
             nbytes = 16 * uc[0] + 8 * uc[1] + 8 * cam["H"] * cam["W"]
             ach = nbytes / (ms * 1e-3) / 1e9
-            extra_rooflines["tsdf_integrate"] = {"kernel": "rfx_tsdf_integrate (prepass + integrate)", "bound": "hbm",
+            extra_rooflines["tsdf_integrate"] = {"kernel": "rfx_tsdf_integrate (mv_prepass + mv_rows + mv_chunks kernels)", "bound": "hbm",
                                                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                  "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
@@ -409,18 +472,22 @@ def main():
                             "mapper's kernels; *_alone: the same call on an otherwise idle GPU, after the timed region",
                     "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
                     "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-    # summarised by tools/summarize_pmc.py into profiles/r1_pmc_traffic.json); raw counter bytes.
+    # HBM traffic per launch: NOT measured by this run (PMC counters need rocprofv3 passes of their own).  The figure is
+    # taken from the committed summary of those passes, profiles/r2_pmc_traffic.json (tools/summarize_pmc.py), and tagged
+    # with the commit the passes ran at; it stays null when that file does not cover the kernel.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        pmc, tag = pmc_all.get("kernels", {}), pmc_all.get("measured_at_commit", "unknown")
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
-                        ("field_forward", ("rfx::field_forward_kernel",)), ("field_backward_chain", ("rfx::field_backward_kernel<true, true, false>", "rfx::field_backward_kernel<false, true, false>")),
+                        ("field_forward", ("rfx::field_forward_kernel<false>",)), ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false>",)),
                         ("field_backward_weights", ("rfx::field_dw_partial_kernel", "rfx::field_dw_reduce_kernel")),
-                        ("render_rays", ("rfx::render_rays_kernel",)), ("tsdf_integrate", ("rfx::mv_integrate_kernel", "rfx::mv_prepass_kernel"))):
+                        ("render_rays", ("rfx::render_rays_kernel<false>",)),
+                        ("tsdf_integrate", ("rfx::mv_chunks_kernel", "rfx::mv_rows_kernel", "rfx::mv_prepass_kernel"))):
             keys = [k for k in pmc if any(kn in k for kn in kns)]
             if rk in extra_rooflines and keys:
-                extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes_raw"] for k in keys))
-                extra_rooflines[rk]["traffic_source"] = "profiles/r1_pmc_traffic.json (FETCH_SIZE+WRITE_SIZE, raw; " + " + ".join(keys) + ")"
+                extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes"] for k in keys))
+                extra_rooflines[rk]["traffic_source"] = (f"profiles/r2_pmc_traffic.json, rocprofv3 --pmc passes at commit {tag} (not this run): "
+                                                         "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B) + WRITE_SIZE; " + " + ".join(keys))
     except Exception:
         pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
@@ -443,12 +510,13 @@ def main():
     out = {
         "metric": "RGB-D frames/sec mapping (640x480, 1cm TSDF)", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume "
                                f"{'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
                                f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
                                f"{cfg['mapping']['iters']} map + {cfg['mapping']['BA_iters']} pose iters every {cfg['mapping']['map_every']} frames, poses initialised from the ground-truth trajectory and refined by the RBA pose MLP",
-                   "unused_gradients": bool(args.unused_gradients),
+                   "unused_gradients": bool(args.unused_gradients), "pos_fp16_opt_in": bool(args.pos_fp16),
                    "streams": "V1 on its own HIP stream, concurrent with the mapper" if getattr(pipe, "mv_stream", None) is not None else "one stream",
                    "note": "pose iterations step only the pose MLP (reference mapper.py:494-499); the map gradients its backward also "
                            "produces and zeroes are computed only with --unused-gradients (same parameters and poses either way)",
@@ -458,6 +526,8 @@ def main():
         "iterations_timed": iters,
         "cpu_baseline": base,
     }
+    if one_scene is not None:
+        out["one_scene"] = one_scene
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -33,6 +33,9 @@ class TsdfOracle:
         L.orc_mv_integrate.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, C.c_float, _F, _F, _F, _F,
                                        C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _F,
                                        C.c_int, C.POINTER(Counts)]
+        L.orc_mv_integrate_range.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, C.c_float, _F, _F, _F, _F,
+                                             C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _F,
+                                             C.c_int, C.c_int64, C.c_int64, C.POINTER(Counts)]
         L.orc_mv_shift.argtypes = [_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _F,
                                    C.c_int, C.c_int, C.c_int, _F, C.c_float, C.c_int]
         L.orc_mv_trilerp.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, C.c_float, _F, C.c_int64, _F]
@@ -68,6 +71,29 @@ class TsdfOracle:
                                   float(trunc), float(obs_weight), float(weight_clamp), float(reintegrate),
                                   ob, 0 if decode == "reference" else 1, C.byref(cnt))
         return cnt.updated, cnt.colour
+
+    def mv_integrate_threads(self, tsdf, weight, color, dims, origin, voxel, K, c2w, color_packed, depth, trunc,
+                             threads: int, obs_weight=1.0, weight_clamp=1.0, decode="reference") -> Tuple[int, int]:
+        """the same sweep with the voxel index range cut into ``threads`` pieces run by that many host threads (the C call
+        releases the GIL; voxels are independent, so the result is the single-threaded one).  bench.py's cpu_baseline."""
+        from concurrent.futures import ThreadPoolExecutor
+        H, W = depth.shape
+        n = int(dims[0]) * int(dims[1]) * int(dims[2])
+        args = (np.ascontiguousarray(origin, np.float32), float(voxel), np.ascontiguousarray(K, np.float32).reshape(-1),
+                np.ascontiguousarray(c2w, np.float32).reshape(-1), np.ascontiguousarray(color_packed, np.float32).reshape(-1),
+                np.ascontiguousarray(depth, np.float32).reshape(-1), H, W, float(trunc), float(obs_weight), float(weight_clamp), 0.0,
+                np.zeros(6, np.float32), 0 if decode == "reference" else 1)
+        cuts = [n * k // threads for k in range(threads + 1)]
+
+        def piece(k):
+            cnt = Counts()
+            self.lib.orc_mv_integrate_range(tsdf, weight, color, int(dims[0]), int(dims[1]), int(dims[2]), *args, cuts[k], cuts[k + 1],
+                                            C.byref(cnt))
+            return cnt.updated, cnt.colour
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            res = list(ex.map(piece, range(threads)))
+        return sum(r[0] for r in res), sum(r[1] for r in res)
 
     def mv_shift(self, dst3, src3, dims, origin, odims, old_origin, voxel, decode="reference"):
         self.lib.orc_mv_shift(dst3[0], dst3[1], dst3[2], src3[0], src3[1], src3[2],

@@ -111,17 +111,21 @@ static inline int project_sdf(const float* K, float cx, float cy, float cz, int 
 typedef struct { int64_t updated; int64_t colour; } orc_counts;
 
 /* V1 -- model/Volume.py:196-336.  color_packed = floor(B*65536+G*256+R) (host :728). */
-void orc_mv_integrate(float* tsdf, float* weight, float* color,
-                      int dx, int dy, int dz, const float* origin, float voxel,
-                      const float* K, const float* c2w,
-                      const float* color_packed, const float* depth, int H, int W,
-                      float trunc, float obs_weight, float weight_clamp, float reintegrate,
-                      const float* old_bnd, int decode_mode, orc_counts* counts) {
+/* voxels idx0 <= idx < idx1 (one thread per voxel in the reference: any split of the index range gives the same
+ * volume, which is how bench.py's cpu_baseline spreads the sweep over the host's cores) */
+void orc_mv_integrate_range(float* tsdf, float* weight, float* color,
+                            int dx, int dy, int dz, const float* origin, float voxel,
+                            const float* K, const float* c2w,
+                            const float* color_packed, const float* depth, int H, int W,
+                            float trunc, float obs_weight, float weight_clamp, float reintegrate,
+                            const float* old_bnd, int decode_mode, int64_t idx0, int64_t idx1, orc_counts* counts) {
     int64_t n = (int64_t)dx * dy * dz;
+    if (idx0 < 0) idx0 = 0;
+    if (idx1 > n) idx1 = n;
     /* int origin_x = vol_origin[0];  -- C truncation toward zero (:230-232) */
     int ox = (int)origin[0], oy = (int)origin[1], oz = (int)origin[2];
     int64_t nu = 0, nc = 0;
-    for (int64_t idx = 0; idx < n; ++idx) {
+    for (int64_t idx = idx0; idx < idx1; ++idx) {
         float vx, vy, vz;
         mv_decode(idx, dx, dy, dz, decode_mode, &vx, &vy, &vz);
         float px = MADD(vx, voxel, (float)ox);
@@ -171,6 +175,16 @@ void orc_mv_integrate(float* tsdf, float* weight, float* color,
         }
     }
     if (counts) { counts->updated = nu; counts->colour = nc; }
+}
+
+void orc_mv_integrate(float* tsdf, float* weight, float* color,
+                      int dx, int dy, int dz, const float* origin, float voxel,
+                      const float* K, const float* c2w,
+                      const float* color_packed, const float* depth, int H, int W,
+                      float trunc, float obs_weight, float weight_clamp, float reintegrate,
+                      const float* old_bnd, int decode_mode, orc_counts* counts) {
+    orc_mv_integrate_range(tsdf, weight, color, dx, dy, dz, origin, voxel, K, c2w, color_packed, depth, H, W, trunc, obs_weight,
+                           weight_clamp, reintegrate, old_bnd, decode_mode, 0, (int64_t)dx * dy * dz, counts);
 }
 
 /* V2 -- model/Volume.py:128-194.  Full-precision fp32 origins (no int cast here). */

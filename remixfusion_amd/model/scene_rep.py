@@ -252,6 +252,8 @@ class JointEncoding(nn.Module):
     def get_encoding(self, config, GBV=True):
         """reference :41-93: OneBlob position encoding, hash-grid residual features, GBV / GBW."""
         self.embedpos_fn, self.input_ch_pos = get_encoder(config["pos"]["enc"], n_bins=config["pos"]["n_bins"])
+        if config["pos"].get("fp16_opt_in", False) and hasattr(self.embedpos_fn, "fp16"):
+            self.embedpos_fn.fp16 = True      # explicit opt-in (not the reference's precision): see encodings.OneBlob
         self.embed_res_fn, self.input_ch = get_encoder(config["grid"]["enc"], log2_hashmap_size=config["grid"]["hash_size"],
                                                        desired_resolution=self.resolution_sdf)
         if GBV:
