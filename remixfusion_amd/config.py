@@ -135,6 +135,12 @@ _OVERRIDES: Dict[str, Dict[str, Any]] = {
                   "volume": {"voxel_size": 0.01, "trunc": 0.06, "x_config": _axis(8), "y_config": _axis(8),
                              "z_config": _axis(3)},
                   "synthetic": {"room": [[-10, 10], [-5, 5], [0, 3]]}},
+    # north-star target workload (SURVEY 8d "stress"): a (10 m)^3 scene at 1 cm on one GPU -- 1000^3 voxels, 12 GB + back
+    # buffers; field and schedule as cfg 2
+    "stress10m": {"cam": _cam(480, 640, 0.1, 8.0, 100.0),
+                  "mapping": {"bound": [[-5, 5], [-5, 5], [-5, 5]], "marching_cubes_bound": [[-5, 5], [-5, 5], [-5, 5]]},
+                  "volume": {"x_config": _axis(5), "y_config": _axis(5), "z_config": _axis(5)},
+                  "synthetic": {"room": [[-4.7, 4.7], [-4.6, 4.6], [-4.5, 4.5]]}},
 }
 
 
