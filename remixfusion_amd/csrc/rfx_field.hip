@@ -453,57 +453,289 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     }
 }
 
+// ---------------------------------------------------------------- E1 backward, binned scatter (large tables)
+// A level cut into many LDS segments makes every segment's block scan every point for the few corners that land in it:
+// 32-256 scans of the point list per level at T = 2^19-2^21.  Such a level (>= SCATTER_BIN_MIN_SEGMENTS segments) is
+// instead sorted by segment first, one level at a time:
+//   bin_count   : per block of 1 024 points, an LDS histogram of the segments its 8 x points corners fall into
+//   bin_scan    : exclusive offsets per (segment, block): every block gets a range of its own inside every segment's bin
+//   bin_records : the same walk again; each corner becomes a 12-byte record (slot in segment, w*g0, w*g1) at the next
+//                 free place of its block's range (LDS cursors)
+//   bin_reduce  : the blocks of a segment add its bin's records into 128 KB of LDS (double accumulators) and add the
+//                 non-zero sums to the table with contiguous float atomics.
+// Records of one level take 96 B per point: they re-use the staging buffer the LDS sweep of the small levels is done with.
+#ifndef SCATTER_BIN_MIN_SEGMENTS
+#define SCATTER_BIN_MIN_SEGMENTS 16
+#endif
+#ifndef SCATTER_BIN_MAX_SEGMENTS
+#define SCATTER_BIN_MAX_SEGMENTS 1024
+#endif
+constexpr int BIN_THREADS = 1024;
+constexpr unsigned BIN_SEG_SHIFT = 13, BIN_SEG = 1u << BIN_SEG_SHIFT;        // 8 192 entries x 2 doubles = 128 KB
+constexpr int BIN_MAX_SEGS = 1024;
+
+struct BinRec { unsigned slot; float a, b; };
+
+__device__ __forceinline__ bool bin_load(const ScatterSrc& a, const ScatterSrc& b, int64_t j, int level, float x[3], float2& gv) {
+    const bool in_a = j < a.n;
+    const ScatterSrc& s = in_a ? a : b;
+    const int64_t p = in_a ? j : j - a.n;
+    if (p >= s.n) return false;
+    gv = reinterpret_cast<const float2*>(s.dfeat + p * (int64_t)s.ld)[level];
+    x[0] = s.x01[p * 3]; x[1] = s.x01[p * 3 + 1]; x[2] = s.x01[p * 3 + 2];
+    return gv.x != 0.f || gv.y != 0.f;
+}
+
+// LDS atomics to ONE address from all 64 lanes serialise (a dense level's neighbouring points fall into the same segment):
+// when the whole wave agrees on the segment, one lane adds for all and the lanes take consecutive ranks.
+__device__ __forceinline__ unsigned bin_take(unsigned* counters, unsigned seg, bool active) {
+    const unsigned long long m = __ballot(active);
+    if (m == 0ull) return 0u;
+    const int leader = __ffsll((long long)m) - 1;
+    const unsigned seg0 = __shfl(seg, leader);
+    const int lane = threadIdx.x & 63;
+    if (__ballot(active && seg != seg0) == 0ull) {          // wave-uniform segment
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&counters[seg0], (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&counters[seg], 1u) : 0u;
+}
+
+constexpr int BIN_PPT = 2;            // points per thread in the count / record kernels: 2 048 points per block
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(Level lv, int level, ScatterSrc a, ScatterSrc b, int n_seg, int n_blk,
+                                                                unsigned* __restrict__ counts) {
+    __shared__ unsigned h[BIN_MAX_SEGS];
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) h[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BIN_PPT; ++q) {
+        const int64_t j = ((int64_t)blockIdx.x * BIN_PPT + q) * BIN_THREADS + threadIdx.x;
+        float x[3] = {0.5f, 0.5f, 0.5f};
+        float2 gv;
+        const bool act = bin_load(a, b, j, level, x, gv);
+        const Cell c = locate(lv, x);
+        unsigned idx8[8];
+        corner_indices(lv, c, idx8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bin_take(h, idx8[k] >> BIN_SEG_SHIFT, act);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) counts[(size_t)i * n_blk + blockIdx.x] = h[i];      // [seg][blk]
+}
+
+// counts / offsets are [seg][blk].  offsets[seg][blk] = start of block blk's range in segment seg's bin; seg_start[seg] =
+// start of the bin (seg_start[n_seg] = total).  One block; a wave takes a segment at a time, lanes over the blocks.
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(const unsigned* __restrict__ counts, int n_blk, int n_seg,
+                                                               unsigned* __restrict__ offsets, unsigned* __restrict__ seg_start) {
+    __shared__ unsigned tot[BIN_MAX_SEGS + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_wv = BIN_THREADS / 64;
+    for (int s = wv; s < n_seg; s += n_wv) {
+        unsigned t = 0;
+        for (int b0 = 0; b0 < n_blk; b0 += 64) t += (b0 + lane < n_blk) ? counts[(size_t)s * n_blk + b0 + lane] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) tot[s] = t;
+    }
+    __syncthreads();
+    if (wv == 0) {                    // exclusive scan of the segment totals by one wave: a run of consecutive segments per lane
+        const int per = (n_seg + 63) / 64;
+        unsigned run = 0;
+        for (int i = 0; i < per; ++i) run += (lane * per + i < n_seg) ? tot[lane * per + i] : 0u;
+        unsigned incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        unsigned start = incl - run;
+        for (int i = 0; i < per; ++i) {
+            const int sidx = lane * per + i;
+            if (sidx < n_seg) { const unsigned v = tot[sidx]; tot[sidx] = start; start += v; }
+        }
+        if (lane == 63) tot[n_seg] = incl;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= n_seg; i += BIN_THREADS) seg_start[i] = tot[i];
+    for (int s = wv; s < n_seg; s += n_wv) {
+        unsigned run = tot[s];
+        for (int b0 = 0; b0 < n_blk; b0 += 64) {
+            const bool in = b0 + lane < n_blk;
+            const unsigned v = in ? counts[(size_t)s * n_blk + b0 + lane] : 0u;
+            unsigned incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned u = __shfl_up(incl, d);
+                if (lane >= d) incl += u;
+            }
+            if (in) offsets[(size_t)s * n_blk + b0 + lane] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(Level lv, int level, ScatterSrc a, ScatterSrc b, int n_seg, int n_blk,
+                                                                  const unsigned* __restrict__ offsets, BinRec* __restrict__ rec) {
+    __shared__ unsigned cur[BIN_MAX_SEGS];
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) cur[i] = offsets[(size_t)i * n_blk + blockIdx.x];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BIN_PPT; ++q) {
+        const int64_t j = ((int64_t)blockIdx.x * BIN_PPT + q) * BIN_THREADS + threadIdx.x;
+        float x[3] = {0.5f, 0.5f, 0.5f};
+        float2 gv = make_float2(0.f, 0.f);
+        const bool act = bin_load(a, b, j, level, x, gv);
+        const Cell c = locate(lv, x);
+        unsigned idx8[8];
+        corner_indices(lv, c, idx8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = corner_weight(c, k);
+            const unsigned pos = bin_take(cur, idx8[k] >> BIN_SEG_SHIFT, act);
+            if (act) {
+                BinRec r;
+                r.slot = idx8[k] & (BIN_SEG - 1u); r.a = w * gv.x; r.b = w * gv.y;
+                rec[pos] = r;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(Level lv, const unsigned* __restrict__ seg_start,
+                                                                 const BinRec* __restrict__ rec, float* __restrict__ dtable) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
+    double* acc = reinterpret_cast<double*>(acc_raw);
+    const unsigned seg = blockIdx.x, base = seg << BIN_SEG_SHIFT;
+    const unsigned cnt = min(BIN_SEG, lv.size - base);
+    // gridDim.y blocks share a segment's bin (a level has 64-256 segments: one block each would leave most CUs idle)
+    const unsigned s0 = seg_start[seg], s1 = seg_start[seg + 1];
+    const unsigned per = (s1 - s0 + gridDim.y - 1) / gridDim.y;
+    const unsigned r0 = min(s1, s0 + blockIdx.y * per), r1 = min(s1, r0 + per);
+    if (r0 == r1) return;                                   // block-uniform
+    for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) acc[i] = 0.0;
+    __syncthreads();
+    for (unsigned r = r0 + threadIdx.x; r < r1; r += BIN_THREADS) {
+        const BinRec q = rec[r];
+        atomicAdd(&acc[2 * q.slot], (double)q.a);
+        atomicAdd(&acc[2 * q.slot + 1], (double)q.b);
+    }
+    __syncthreads();
+    float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
+    for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) {
+        const float v = (float)acc[i];
+        if (v != 0.f) atomicAdd(out + i, v);                // contiguous float atomics: the memory side's fast path
+    }
+}
+
+static bool level_is_binned(const rfx_grid_desc& g, int l) {
+    const unsigned segs = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
+    return segs >= (unsigned)SCATTER_BIN_MIN_SEGMENTS && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
+}
+
+// one level through the four kernels above; scratch: >= n_all * 96 + (2 n_blk + 1) * (n_seg + 1) * 4 bytes
+static int launch_binned_level(const rfx_grid_desc& g, int l, const ScatterSrc& a, const ScatterSrc& b, float* dtable, float* scratch,
+                               size_t scratch_floats, hipStream_t st) {
+    const int64_t n_all = a.n + b.n;
+    const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
+    const int n_blk = (int)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
+    const size_t rec_floats = (size_t)n_all * 8 * 3, cnt_words = (size_t)n_blk * n_seg;
+    if (rec_floats + 2 * cnt_words + n_seg + 1 > scratch_floats) return RFX_ERR_WORKSPACE;
+    BinRec* rec = reinterpret_cast<BinRec*>(scratch);
+    unsigned* counts = reinterpret_cast<unsigned*>(scratch + rec_floats);
+    unsigned* offsets = counts + cnt_words;
+    unsigned* seg_start = offsets + cnt_words;
+    Level lv;
+    lv.scale = g.scale[l]; lv.res = g.res[l]; lv.size = g.size[l]; lv.offset = g.offset[l]; lv.hashed = g.hashed[l];
+    hipLaunchKernelGGL(bin_count_kernel, dim3(n_blk), dim3(BIN_THREADS), 0, st, lv, l, a, b, n_seg, n_blk, counts);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, st, counts, n_blk, n_seg, offsets, seg_start);
+    hipLaunchKernelGGL(bin_records_kernel, dim3(n_blk), dim3(BIN_THREADS), 0, st, lv, l, a, b, n_seg, n_blk, offsets, rec);
+    const size_t lds = (size_t)BIN_SEG * 2 * sizeof(double);
+    static bool attr_set[64] = {};            // per device (the attribute is per device; benign if raced)
+    int dev = 0;
+    RFX_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bin_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    const int split = std::max(1, std::min(8, 256 / std::max(1, n_seg)));
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3(n_seg, split), dim3(BIN_THREADS), lds, st, lv, seg_start, rec, dtable);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 // dtable += scatter of dfeat (row stride ld).  With a scratch buffer of scatter_scratch_floats() the
 // LDS path is taken when the table is small enough to sweep segment by segment; otherwise direct atomics.
 static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
                                const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0) {
     ScatterPlan plan;
+    const int64_t n_all = n + n_b;
+    const bool staged_ok = scratch && n_all >= SCATTER_MIN_POINTS;
+    // levels cut into many segments are binned (one at a time, below); the others share one LDS sweep
+    bool binned[RFX_MAX_LEVELS] = {};
+    int n_binned = 0;
     unsigned largest = 0;
-    for (int l = 0; l < g.n_levels; ++l) largest = std::max(largest, g.size[l]);
+    for (int l = 0; l < g.n_levels; ++l) {
+        binned[l] = staged_ok && level_is_binned(g, l);
+        n_binned += binned[l] ? 1 : 0;
+        if (!binned[l]) largest = std::max(largest, g.size[l]);
+    }
     const bool f64 = largest < 16u * SCATTER_SEG;           // see grid_scatter_lds_kernel
     const unsigned seg_entries = f64 ? SCATTER_SEG / 2 : SCATTER_SEG;
     int total = 0;
     for (int l = 0; l < g.n_levels; ++l) {
         plan.seg_start[l] = total;
-        total += (int)((g.size[l] + seg_entries - 1) / seg_entries);
+        if (!binned[l]) total += (int)((g.size[l] + seg_entries - 1) / seg_entries);
     }
     for (int l = g.n_levels; l <= RFX_MAX_LEVELS; ++l) plan.seg_start[l] = total;
-    const int64_t n_all = n + n_b;
-    if (!scratch || total > SCATTER_MAX_SEGMENTS || n_all < SCATTER_MIN_POINTS) {
+    if (!staged_ok || total > SCATTER_MAX_SEGMENTS) {
         if (n > 0)
             hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
                                dfeat, ld, dtable, (float*)nullptr, 0);
         if (n_b > 0)
             hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, g, table, x01_b,
                                n_b, dfeat_b, ld_b, dtable, (float*)nullptr, 0);
+        RFX_LAUNCH_CHECK();
         return RFX_OK;
     }
-    scatter_shape(n_all, total, &plan.chunks, &plan.K);
-    const int64_t per_a = (n + plan.chunks - 1) / plan.chunks, per_b = (n_b + plan.chunks - 1) / plan.chunks;
-    plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
-    plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
-    if ((size_t)plan.slots * (2 * g.n_levels + 3) > scatter_scratch_floats(n_all, g.n_levels)) return RFX_ERR_WORKSPACE;
     const ScatterSrc a{dfeat, ld, x01, n}, b{dfeat_b, ld_b, x01_b, n_b};
-    hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, per_a, per_b,
-                       g.n_levels, plan.K, plan.slots, scratch);
-    const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<float, SCATTER_SEG>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<double, SCATTER_SEG / 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const size_t scratch_floats = scatter_scratch_floats(n_all, g.n_levels);
+    if (total > 0) {
+        scatter_shape(n_all, total, &plan.chunks, &plan.K);
+        const int64_t per_a = (n + plan.chunks - 1) / plan.chunks, per_b = (n_b + plan.chunks - 1) / plan.chunks;
+        plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
+        plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
+        if ((size_t)plan.slots * (2 * g.n_levels + 3) > scratch_floats) return RFX_ERR_WORKSPACE;
+        hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, per_a, per_b,
+                           g.n_levels, plan.K, plan.slots, scratch);
+        RFX_LAUNCH_CHECK();
+        const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
+        static bool attr_set[64] = {};       // the attribute is per device
+        int dev = 0;
+        RFX_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<float, SCATTER_SEG>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<double, SCATTER_SEG / 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = true;
+        }
+        // (an XCD-aware block order -- all segments of one (level, chunk) on one XCD's L2 -- was measured: no gain at
+        // T = 2^16 / 2^19 and a loss at 2^21, the levels' costs differ too much to be dealt out per XCD)
+        if (f64)
+            hipLaunchKernelGGL((grid_scatter_lds_kernel<double, SCATTER_SEG / 2>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g,
+                               plan, g.n_levels, scratch, dtable);
+        else
+            hipLaunchKernelGGL((grid_scatter_lds_kernel<float, SCATTER_SEG>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan,
+                               g.n_levels, scratch, dtable);
+        RFX_LAUNCH_CHECK();
     }
-    // (an XCD-aware block order -- all segments of one (level, chunk) on one XCD's L2 -- was measured: no gain at
-    // T = 2^16 / 2^19 and a loss at 2^21, the levels' costs differ too much to be dealt out per XCD)
-    if (f64)
-        hipLaunchKernelGGL((grid_scatter_lds_kernel<double, SCATTER_SEG / 2>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g,
-                           plan, g.n_levels, scratch, dtable);
-    else
-        hipLaunchKernelGGL((grid_scatter_lds_kernel<float, SCATTER_SEG>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan,
-                           g.n_levels, scratch, dtable);
+    for (int l = 0; l < g.n_levels; ++l) {
+        if (!binned[l]) continue;
+        const int rc = launch_binned_level(g, l, a, b, dtable, scratch, scratch_floats, st);
+        if (rc) return rc;
+    }
     return RFX_OK;
 }
 

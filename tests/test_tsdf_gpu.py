@@ -142,6 +142,8 @@ def test_integrate_slabs_equal_the_whole_volume(dims, cuts, decode):
     lib = L.load()
     frames = [small_frame(frame=f)[:4] for f in (0, 11)]
     origin, voxel, trunc = (-3, -4, -2), 0.02 if dims[0] == 300 else 0.04, 0.06 if dims[0] == 300 else 0.15
+    if dims[0] == 64:
+        origin, voxel, trunc = (-2, -3, -2), 0.08, 0.24
     dec = 0 if decode == "reference" else 1
     whole = Vol(dims, origin, voxel, trunc, 1, dec)
     for (K, c2w, rgb, depth) in frames:
