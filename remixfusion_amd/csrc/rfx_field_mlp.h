@@ -367,21 +367,58 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         scale16(m.h1[0], 1.0f / POS_LO_SCALE); scale16(m.h1[1], 1.0f / POS_LO_SCALE);
         pos_mfma16(wl, OFF1 + 16, 1, lane, e.pos16, m.h1[0], m.h1[1]);
     }
-    // a real loop (2 levels per trip): level constants are fetched per trip instead of keeping all
-    // 16 x 5 of them live in SGPRs, and the code stays small enough for the instruction cache
-RFX_UNROLL(HASH_GROUP)
-    for (int s = 0; s < 16; ++s) {
+    // HASH_GROUP levels per trip, in three phases: (1) cells and corner indices of all the group's levels, (2) their
+    // 8 x HASH_GROUP gathers issued back to back, (3) interpolation and the matrix steps.  Written as one lookup2() per level
+    // the loop made one memory round trip per LEVEL (index arithmetic with its level-uniform branches, eight loads, wait
+    // for all eight, two MFMAs; sixteen dependent trips per batch): the compiler does not move loads across the branches
+    // of the next level's index arithmetic.  A real loop over the groups: level constants are fetched per trip instead of
+    // keeping all 16 x 5 of them live in SGPRs.
+    constexpr int HG = HASH_GROUP;
+    static_assert(16 % HG == 0, "HASH_GROUP must divide the 16 levels");
+#pragma unroll 1
+    for (int s0 = 0; s0 < 16; s0 += HG) {
+        float2 v[HG];
 #if defined(FIELD_DBG) && FIELD_DBG == 4
-        const float2 v = make_float2(x[0] * (float)s, x[1]);          // timing experiment: no hash lookups
+#pragma unroll
+        for (int g = 0; g < HG; ++g) v[g] = make_float2(x[0] * (float)(s0 + g), x[1]);      // timing experiment: no hash lookups
 #else
-        const float2 v = lookup2(f.table, get_level(f.hash, s), x);
+        Cell cell[HG];
+        unsigned idx[HG][8];
+        const float2* tl[HG];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            const Level L = get_level(f.hash, s0 + g);
+            cell[g] = locate(L, x);
+            corner_indices(L, cell[g], idx[g]);
+            tl[g] = reinterpret_cast<const float2*>(f.table) + L.offset;
+        }
+        float2 cv[HG][8];
+#pragma unroll
+        for (int g = 0; g < HG; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[g][k] = tl[g][idx[g][k]];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = corner_weight(cell[g], k);
+                acc.x = fmaf(w, cv[g][k].x, acc.x);
+                acc.y = fmaf(w, cv[g][k].y, acc.y);
+            }
+            v[g] = acc;
+        }
 #endif
-        if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v;
-        float a = v.x, b = v.y;
-        swap32(a, b);
-        const float w = wl[(OFF1 + s) * 64 + lane];
-        m.h1[0] = mfma32(w, a, m.h1[0]);
-        m.h1[1] = mfma32(w, b, m.h1[1]);
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            const int s = s0 + g;
+            if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v[g];
+            float a = v[g].x, b = v[g].y;
+            swap32(a, b);
+            const float w = wl[(OFF1 + s) * 64 + lane];
+            m.h1[0] = mfma32(w, a, m.h1[0]);
+            m.h1[1] = mfma32(w, b, m.h1[1]);
+        }
     }
     PosBins pb;
     bool extra = false;
