@@ -639,14 +639,14 @@ __device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, flo
 constexpr int MV_NEAR_FIELDS = 9;
 
 template <int U, bool RISKY, bool REINT>
-__global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsigned* __restrict__ q_count,
-                                                        const uint2* __restrict__ queue, unsigned q_cap,
-                                                        const float2* __restrict__ dimg, const float* __restrict__ cpk,
-                                                        float* __restrict__ tsdf, float* __restrict__ weight,
-                                                        float* __restrict__ color) {
-    __shared__ float nbuf[4][MV_NEAR_FIELDS][128];             // per wave: pending near lanes (< 64 kept + <= 64 new), field-major
+__device__ __forceinline__ void mv_chunks_body(const MvParams& P, const unsigned* __restrict__ q_count,
+                                               const uint2* __restrict__ queue, unsigned q_cap,
+                                               const float2* __restrict__ dimg, const float* __restrict__ cpk,
+                                               float* __restrict__ tsdf, float* __restrict__ weight,
+                                               float* __restrict__ color, unsigned block, unsigned n_blocks,
+                                               float (*nbuf)[MV_NEAR_FIELDS][128]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float (*nb)[128] = nbuf[wv];
+    float (*nb)[128] = nbuf[wv];                               // per wave: pending near lanes (< 64 kept + <= 64 new), field-major
     int n_near = 0;        // wave-uniform fill of nb
     // the reference's full update on the top min(64, n_near) pending records (one per lane)
     auto drain = [&]() {
@@ -665,8 +665,8 @@ __global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsign
         __builtin_amdgcn_wave_barrier();             // reads done before the buffer is written again
         asm volatile("" ::: "memory");
     };
-    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
+    const unsigned n_waves = n_blocks * (blockDim.x >> 6);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(block * (blockDim.x >> 6) + wv);
     const unsigned n = min(*q_count, q_cap);
     const bool fast = !REINT && P.obs_weight > 0.0f;
     for (unsigned it = wave * U; it < n; it += n_waves * U) {
@@ -770,6 +770,24 @@ __global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsign
         }
     }
     while (n_near > 0) drain();
+}
+
+// one launch for both queues: blocks [0, blocks_main) pull the frustum rows' chunks, the rest the chunks of the rows next to
+// x-slab boundaries (literal index decode; a few thousand items -- a launch of their own cost 5 us behind the main one)
+template <int U, bool REINT>
+__global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsigned* __restrict__ q_counts,
+                                                        const uint2* __restrict__ queue, unsigned q_cap,
+                                                        const uint2* __restrict__ queue_risky, unsigned q_cap_risky,
+                                                        unsigned blocks_main,
+                                                        const float2* __restrict__ dimg, const float* __restrict__ cpk,
+                                                        float* __restrict__ tsdf, float* __restrict__ weight,
+                                                        float* __restrict__ color) {
+    __shared__ float nbuf[4][MV_NEAR_FIELDS][128];
+    if (blockIdx.x < blocks_main)
+        mv_chunks_body<U, false, REINT>(P, q_counts, queue, q_cap, dimg, cpk, tsdf, weight, color, blockIdx.x, blocks_main, nbuf);
+    else
+        mv_chunks_body<U, true, REINT>(P, q_counts + 1, queue_risky, q_cap_risky, dimg, cpk, tsdf, weight, color,
+                                       blockIdx.x - blocks_main, gridDim.x - blocks_main, nbuf);
 }
 
 // ---------------------------------------------------------------------------- simple sweeps
@@ -1176,31 +1194,30 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         RFX_LAUNCH_CHECK();
         // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
         // chip); small volumes need fewer
-        using Kern = void (*)(MvParams, const unsigned*, const uint2*, unsigned, const float2*, const float*, float*, float*, float*);
-        const Kern k_main = P.reintegrate ? (Kern)mv_chunks_kernel<U, false, true> : (Kern)mv_chunks_kernel<U, false, false>;
-        const Kern k_risky = P.reintegrate ? (Kern)mv_chunks_kernel<U, true, true> : (Kern)mv_chunks_kernel<U, true, false>;
+        using Kern = void (*)(MvParams, const unsigned*, const uint2*, unsigned, const uint2*, unsigned, unsigned, const float2*, const float*,
+                              float*, float*, float*);
+        const Kern kern = P.reintegrate ? (Kern)mv_chunks_kernel<U, true> : (Kern)mv_chunks_kernel<U, false>;
         static int resident[2] = {0, 0};       // blocks per CU x CUs, [reintegrate]; benign if raced (same value)
         if (!resident[P.reintegrate]) {
             int per_cu = 0, dev = 0;
             hipDeviceProp_t prop;
             RFX_HIP_TRY(hipGetDevice(&dev));
             RFX_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-            RFX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_main), 256, 0));
+            RFX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
             resident[P.reintegrate] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        }
+        int blocks_risky_q = 0, blocks_main_q = 0;
+        if (rows_risky > 0) {
+            const int64_t max_items = std::min<int64_t>((int64_t)cap_risky, rows_risky * nch);
+            blocks_risky_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate] / 8, (max_items + 4 * U - 1) / (4 * U)));
         }
         if (rows_main > 0) {
             const int64_t max_items = std::min<int64_t>((int64_t)cap, rows_main * nch);
-            const int blocks_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate], (max_items + 4 * U - 1) / (4 * U)));
-            hipLaunchKernelGGL(k_main, dim3(blocks_q), dim3(256), 0, st, P, dmax_bits, queue, q_cap, dimg, color_packed, tsdf, weight, color);
-            RFX_LAUNCH_CHECK();
+            blocks_main_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate] - blocks_risky_q, (max_items + 4 * U - 1) / (4 * U)));
         }
-        if (rows_risky > 0) {
-            const int64_t max_items = std::min<int64_t>((int64_t)cap_risky, rows_risky * nch);
-            const int blocks_q = (int)std::max<int64_t>(1, std::min<int64_t>(256 * 2, (max_items + 4 * U - 1) / (4 * U)));
-            hipLaunchKernelGGL(k_risky, dim3(blocks_q), dim3(256), 0, st, P, dmax_bits + 1, queue_risky, q_cap_risky, dimg, color_packed, tsdf,
-                               weight, color);
-            RFX_LAUNCH_CHECK();
-        }
+        hipLaunchKernelGGL(kern, dim3(blocks_main_q + blocks_risky_q), dim3(256), 0, st, P, dmax_bits, queue, q_cap, queue_risky, q_cap_risky,
+                           (unsigned)blocks_main_q, dimg, color_packed, tsdf, weight, color);
+        RFX_LAUNCH_CHECK();
         return RFX_OK;
     }
 #endif

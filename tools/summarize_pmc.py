@@ -1,26 +1,52 @@
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r1_pmc_traffic.json.
+"""Summarise rocprofv3 --pmc passes into profiles/r2_pmc_traffic.json and a per-kernel SQ counter table.
 
-FETCH_SIZE/WRITE_SIZE are reported in KiB-units of 64-B requests per MI355X_MICROARCH.md (HBM section):
-hbm_bytes = counter * 1024, and on gfx950 FETCH_SIZE under-counts wide coalesced streaming reads by 2x
-(128-B requests tallied at 64 B); we record the raw and the doubled figure and say which applies."""
-import csv, json, sys, collections, os
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = {}
-for tag, path in (("FETCH_SIZE", "gpurun_out/pmc_fetch/pmc_counter_collection.csv"), ("WRITE_SIZE", "gpurun_out/pmc_write/pmc_counter_collection.csv")):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(root, path))):
-        if r["Counter_Name"] != tag:
+usage: python tools/summarize_pmc.py OUT_DIR COMMIT FETCH_CSV WRITE_CSV [SQ_CSV ...]
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950
+tallies the 128-byte requests of wide coalesced reads at 64 B: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; the raw
+sum is recorded next to it (gathers of 8/16-byte elements are closer to the raw figure)."""
+import collections, csv, json, os, sys
+out_dir, commit, fetch_csv, write_csv = sys.argv[1:5]
+sq_csvs = sys.argv[5:]
+
+
+def avg_by_kernel(path, want=None):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        if "rfx::" not in r["Kernel_Name"]:
             continue
-        acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        if "rfx::" not in k:
+        if want and r["Counter_Name"] not in want:
             continue
-        out.setdefault(k, {})[tag + "_KiB_avg"] = sum(v) / len(v)
-        out[k]["dispatches"] = len(v)
-for k, v in out.items():
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+kern = {}
+for tag, path in (("FETCH_SIZE", fetch_csv), ("WRITE_SIZE", write_csv)):
+    for k, d in avg_by_kernel(path, {tag}).items():
+        v = d[tag]
+        kern.setdefault(k, {})[tag + "_KiB_avg"] = sum(v) / len(v)
+        kern[k]["dispatches"] = len(v)
+for k, v in kern.items():
     f, w = v.get("FETCH_SIZE_KiB_avg", 0.0), v.get("WRITE_SIZE_KiB_avg", 0.0)
     v["hbm_bytes_raw"] = (f + w) * 1024
-    v["hbm_bytes_fetch_x2"] = (2 * f + w) * 1024
-json.dump(out, open(os.path.join(root, "profiles/r1_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_raw"]):
-    print(f"{k[:70]:70s} n={v['dispatches']:4d} fetch {v.get('FETCH_SIZE_KiB_avg',0)/1024:9.2f} MiB write {v.get('WRITE_SIZE_KiB_avg',0)/1024:9.2f} MiB")
+    v["hbm_bytes"] = (2 * f + w) * 1024
+json.dump({"measured_at_commit": commit, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 40 --warmup 11 --no-cpu-baseline (one pass per counter)",
+           "unit_note": "KiB counters; hbm_bytes = (2*FETCH + WRITE)*1024 (gfx950 FETCH correction), hbm_bytes_raw = (FETCH + WRITE)*1024; per launch averages",
+           "kernels": kern}, open(os.path.join(out_dir, "r2_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+lines = [f"# HBM traffic per launch (rocprofv3 --pmc, commit {commit}); MiB", "", "| kernel | launches | FETCH raw | FETCH x2 | WRITE |", "|---|---|---|---|---|"]
+for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
+    lines.append(f"| `{k}` | {v['dispatches']} | {v.get('FETCH_SIZE_KiB_avg', 0) / 1024:.2f} | {2 * v.get('FETCH_SIZE_KiB_avg', 0) / 1024:.2f} | {v.get('WRITE_SIZE_KiB_avg', 0) / 1024:.2f} |")
+if sq_csvs:
+    lines += ["", f"# SQ counters per launch (averages; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles)", ""]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for p in sq_csvs:
+        for k, d in avg_by_kernel(p).items():
+            for c, v in d.items():
+                acc[k][c] += v
+    names = sorted({c for d in acc.values() for c in d})
+    lines += ["| kernel | " + " | ".join(names) + " |", "|---|" + "---|" * len(names)]
+    for k, d in sorted(acc.items()):
+        lines.append(f"| `{k}` | " + " | ".join(f"{sum(d[c]) / len(d[c]):.3g}" if d.get(c) else "" for c in names) + " |")
+open(os.path.join(out_dir, "r2_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:60]))
