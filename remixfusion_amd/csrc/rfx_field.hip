@@ -766,20 +766,25 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- backward: workspace layout
-// per-point rows (fp32).  X1 = [emb32 | pos48 | cin | 0..]; G = [geo15 | ex_rgb3 | 0..];
-// dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..]
-constexpr int LD_X1 = 96, LD_H = 32, LD_G = 32, LD_DY2 = 16, LD_DX1 = 96;
+// per-point rows (fp32).  dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..], row-major, one row of LD_DX1 per point.
+// What only the weight-gradient kernel reads -- X1 = [emb32 | pos48 | cin | 0 0 0] (21 float4 pieces), G = [geo15 | ex_rgb3
+// | 0 0] (5), dY2 (4) -- is PIECE-MAJOR inside tiles of 64 points (row_piece() in rfx_field_mlp.h): piece q of point p sits at
+// tile (p / 64) * pieces * 256 + q * 256 + (p % 64) * 4 floats.  The chain kernel has lane = point, so each of its float4
+// stores is then one contiguous 1 KiB write per wave (a row-major row would make it 64 16-byte writes 384 B apart), and
+// the weight-gradient kernel's LDS image of a batch is piece-major as well, so its fills are contiguous reads.
+constexpr int LD_DX1 = 96;
+constexpr int PC_X1 = 21, PC_G = 5, PC_DY2 = 4;      // float4 pieces per point
 constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
-#ifndef DW_BLOCKS_N
-#define DW_BLOCKS_N 768      // three resident blocks per CU (170 VGPRs, 42.5 KB of LDS each); 512 -> 768: 57 -> 51 us at 1.3e5 points
-#endif
-constexpr int DW_BLOCKS = DW_BLOCKS_N;
+constexpr int DW_BLOCKS = 256;       // the weight-gradient kernel is persistent: at most one block per CU
+
+// B-operand (k-step) images of W1..W4 for the weight-gradient kernel's recompute of H1 / H3, 84 slots of 64 lanes
+constexpr int DWR_OFF1 = 0, DWR_OFF2 = 41, DWR_OFF3 = 49, DWR_OFF4 = 82, DWR_SLOTS = 84;
 
 struct BwdWs {
-    float *x1, *h1, *dh1, *g, *dy2, *h3, *dh3, *dx1, *demb_t, *partial;
+    float *x1, *g, *dy2, *dx1, *demb_t, *partial, *wcopy;
 };
 
-__host__ __device__ inline size_t ws_floats_per_point() { return LD_X1 + 3 * LD_H + LD_G + LD_DY2 + LD_H + LD_DX1; }
+__host__ __device__ inline size_t ws_floats_per_point() { return 4 * (PC_X1 + PC_G + PC_DY2) + LD_DX1; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -787,15 +792,12 @@ static BwdWs carve(void* ws, int64_t n) {
     BwdWs w;
     float* p = reinterpret_cast<float*>(ws);
     const size_t np = align_up((size_t)n, 64);
-    w.x1 = p; p += np * LD_X1;
-    w.h1 = p; p += np * LD_H;
-    w.dh1 = p; p += np * LD_H;
-    w.g = p; p += np * LD_G;
-    w.dy2 = p; p += np * LD_DY2;
-    w.h3 = p; p += np * LD_H;
-    w.dh3 = p; p += np * LD_H;
+    w.x1 = p; p += np * 4 * PC_X1;
+    w.g = p; p += np * 4 * PC_G;
+    w.dy2 = p; p += np * 4 * PC_DY2;
     w.dx1 = p; p += np * LD_DX1;
-    w.partial = p; p += (size_t)DW_BLOCKS * 4 * DW_TOTAL;
+    w.partial = p; p += (size_t)DW_BLOCKS * DW_TOTAL;
+    w.wcopy = p; p += DWR_SLOTS * 64;                  // k-step images of W1..W4 as the chain saw them
     w.demb_t = p;                                      // staged d_emb / points of the LDS scatter
     return w;
 }
@@ -835,15 +837,28 @@ __device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16&
 }
 
 // ---------------------------------------------------------------- backward kernel A (MFMA chain)
-// ROWS: also stage the per-point rows the weight-gradient kernel reads (X1, H1, dH1pre, G, dY2, H3, dH3pre); without them
+// ROWS: also stage what the weight-gradient kernel reads (X1, G, dY2; it recomputes H1, H3 and their gradients); without them
 // only dX1 is written, which is all the input-gradient stages (_scatter with dx01, _dx) need.
 // DXFULL: all of dX1 (d_emb, d_pos, d_cin, d_ex_rgb); without it only d_emb (columns 0..31, what the table scatter
 // reads) is computed and stored: two of the three dX1 M-tiles and two dX3 M-tiles of matrix work and 256 B/point less.
+__device__ __forceinline__ float dwr_image(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                           const float* __restrict__ w4, int slot, int l) {
+    const int lo = l & 31, h = l >> 5;
+    if (slot < DWR_OFF2) { const int k = 2 * slot + h; return k < N_IN1 ? w1[lo * N_IN1 + k] : 0.f; }           // B[k=in][n=hid] = W1[hid][in]
+    if (slot < DWR_OFF3) { const int k = 2 * (slot - DWR_OFF2) + h; return w2[k * N_H + lo]; }                    // B[k=out][n=hid] = W2[out][hid]
+    if (slot < DWR_OFF4) { const int k = 2 * (slot - DWR_OFF3) + h; return k < N_IN3 ? w3[lo * N_IN3 + k] : 0.f; }
+    const int k = 2 * (slot - DWR_OFF4) + h;
+    return k < N_OUT4 ? w4[k * N_H + lo] : 0.f;                                                                    // B[k=c][n=hid] = W4[c][hid]
+}
+
 template <bool POS16, bool ROWS, bool DXFULL>
 __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                              const float* __restrict__ draw4, BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     stage_weights(f, wl, ALL_SLOTS);
+    if (ROWS && blockIdx.x == 0) {        // the weight-gradient kernel recomputes H1 / H3 from the staged inputs: it needs the weights
+        for (int i = threadIdx.x; i < DWR_SLOTS * 64; i += blockDim.x) ws.wcopy[i] = dwr_image(f.w1, f.w2, f.w3, f.w4, i >> 6, i & 63);
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -857,19 +872,12 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
         Enc e;
         encode_point(f, x, e);
         // ---- stage X1 (emb part inside the forward; pos/cin after the forward has used them)
-        float* x1row = ws.x1 + p * LD_X1;
+        float* x1row = ws.x1 + (p >> 6) * (PC_X1 * ROW_PIECE) + (p & 63) * 4;        // piece-major, see the workspace layout
         Mlp m;
         mlp_forward_123<ROWS, POS16>(f, x, wl, lane, e, m, x1row, valid);    // stages emb and pos itself
-        if (ROWS && valid) {
-            st4(x1row, 80, e.cin, 0.f, 0.f, 0.f);
-            st4(x1row, 84, 0.f, 0.f, 0.f, 0.f); st4(x1row, 88, 0.f, 0.f, 0.f, 0.f); st4(x1row, 92, 0.f, 0.f, 0.f, 0.f);
-        }
+        if (ROWS && valid) st4(row_piece(x1row, 80), 0, e.cin, 0.f, 0.f, 0.f);
         const unsigned mask1 = positive_mask(m.h1[0], m.h1[1]);
         const unsigned mask3 = positive_mask(m.h3[0], m.h3[1]);
-        if (ROWS) {
-            store_tiles_as_rows(m.h1[0], m.h1[1], ws.h1 + p * LD_H, 0, true, valid);
-            store_tiles_as_rows(m.h3[0], m.h3[1], ws.h3 + p * LD_H, 0, true, valid);
-        }
         if (ROWS) {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
             float o[16];
 #pragma unroll
@@ -879,11 +887,10 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
                 o[krow(r, 0)] = a; o[krow(r, 1)] = b;
             }
             if (valid) {
-                float* grow = ws.g + p * LD_G;
-                st4(grow, 0, o[1], o[2], o[3], o[4]); st4(grow, 4, o[5], o[6], o[7], o[8]);
-                st4(grow, 8, o[9], o[10], o[11], o[12]); st4(grow, 12, o[13], o[14], o[15], e.ex[1]);
-                st4(grow, 16, e.ex[2], e.ex[3], 0.f, 0.f); st4(grow, 20, 0.f, 0.f, 0.f, 0.f);
-                st4(grow, 24, 0.f, 0.f, 0.f, 0.f); st4(grow, 28, 0.f, 0.f, 0.f, 0.f);
+                float* grow = ws.g + (p >> 6) * (PC_G * ROW_PIECE) + (p & 63) * 4;
+                st4(grow, 0, o[1], o[2], o[3], o[4]); st4(grow, ROW_PIECE, o[5], o[6], o[7], o[8]);
+                st4(grow, 2 * ROW_PIECE, o[9], o[10], o[11], o[12]); st4(grow, 3 * ROW_PIECE, o[13], o[14], o[15], e.ex[1]);
+                st4(grow, 4 * ROW_PIECE, e.ex[2], e.ex[3], 0.f, 0.f);
             }
         }
 
@@ -904,7 +911,6 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             d3[0][r] = ((mask3 >> r) & 1u) ? d3[0][r] : 0.f;
             d3[1][r] = ((mask3 >> (16 + r)) & 1u) ? d3[1][r] : 0.f;
         }
-        if (ROWS) store_tiles_as_rows(d3[0], d3[1], ws.dh3 + p * LD_H, 0, false, valid);
 
         // ---- dX3 = W3^T dH3pre, M-tile 1 first (rows 32..63: d_pos[32..47], d_geo[0..14], d_ex_r)
         f32x16 gx1[2] = {zero16(), zero16()};
@@ -931,7 +937,6 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             d1[0][r] = ((mask1 >> r) & 1u) ? d1[0][r] : 0.f;
             d1[1][r] = ((mask1 >> (16 + r)) & 1u) ? d1[1][r] : 0.f;
         }
-        if (ROWS) store_tiles_as_rows(d1[0], d1[1], ws.dh1 + p * LD_H, 0, false, valid);
         // own-point rows of gx1: rows q=0..15 -> d_pos[32..47] (colour path), q=16..30 -> d_geo, q=31 -> d_ex_r
         float gq[32];
 #pragma unroll
@@ -941,9 +946,9 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
             gq[krow(r, 0)] = a; gq[krow(r, 1)] = b;
         }
         if (ROWS && valid) {
-            float* yrow = ws.dy2 + p * LD_DY2;
-            st4(yrow, 0, dr.w, gq[16], gq[17], gq[18]); st4(yrow, 4, gq[19], gq[20], gq[21], gq[22]);
-            st4(yrow, 8, gq[23], gq[24], gq[25], gq[26]); st4(yrow, 12, gq[27], gq[28], gq[29], gq[30]);
+            float* yrow = ws.dy2 + (p >> 6) * (PC_DY2 * ROW_PIECE) + (p & 63) * 4;
+            st4(yrow, 0, dr.w, gq[16], gq[17], gq[18]); st4(yrow, ROW_PIECE, gq[19], gq[20], gq[21], gq[22]);
+            st4(yrow, 2 * ROW_PIECE, gq[23], gq[24], gq[25], gq[26]); st4(yrow, 3 * ROW_PIECE, gq[27], gq[28], gq[29], gq[30]);
         }
         float* dxrow = ws.dx1 + p * LD_DX1;
         // ---- dX1 = W1^T dH1pre: M-tile 0 = d_emb
@@ -1007,74 +1012,174 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
     }
 }
 
-// ---------------------------------------------------------------- backward kernel D: dW = dY^T X over points
-// A[i=out][k=pt] = dY[pt][out], B[k=pt][j=in] = X[pt][in]: both are coalesced row reads of the
-// staged [pt][.] arrays, so operands stream straight from memory into MFMA registers.
-__device__ __forceinline__ float ldrow(const float* base, int64_t pt, int ld, int col, int ncol, int64_t n) {
-    return (pt < n && col < ncol) ? base[pt * ld + col] : 0.f;
+// ---------------------------------------------------------------- backward kernel D: dW with H1 / H3 recomputed
+// The chain stages only what cannot be recomputed from a point's row: X1 (81), G = [geo15 | ex_rgb] (18), dY2 (16) -- 480 B
+// per point where round 1 also staged H1, dH1pre, H3, dH3pre (1 088 B) -- and this kernel rebuilds the hidden activations
+// and their gradients on the matrix cores, 32 points at a time, in the orientation the weight gradients need:
+//     H1pre [pt x hid] = X1 [pt x 81] . W1^T        A = X1 (lane = point), B = W1 (k-step image in LDS)
+//     dH1pre           = (H1pre > 0) . (dY2 [pt x 16] . W2)
+//     H3pre  [pt x hid] = X3 [pt x 66] . W3^T,  dH3pre = (H3pre > 0) . (dY4 [pt x 3] . W4)
+// A D tile [pt x hid] holds (register r, lane half h) -> point krow(r, h), lane & 31 -> hidden unit: as it stands it is the
+// A operand dY^T [hid x pt-pair] of dW = dY^T X and the B operand H [pt-pair x hid] of dW2 / dW4 -- no transposes.  The other
+// operand of each product is a lane = feature read of the batch image.
+//
+// One 32-point batch as this kernel keeps it in LDS, in 16-byte pieces, piece-major like the staged rows:
+//   X1 [21 pieces][33] | G [5][33] | dY2 [4][33] | dY4 [32]          (slot 32 of each piece is padding)
+// lane = point reads (ds_read_b128, recompute phase) are consecutive pieces; lane = feature reads (ds_read_b32, dW phase)
+// step 33 * 4 floats per four lanes, i.e. 4 banks: both conflict-free.  The image is filled by LDS-DMA
+// (global_load_lds_dwordx4: the 64 pieces of one wave-instruction land at consecutive LDS addresses, each from its own
+// lane's source address -- 32 consecutive pieces of the staged tile, then the pad), 16 instructions per batch and no
+// VGPRs, one batch ahead of the arithmetic.
+constexpr int DWR_PX = 0, DWR_PG = PC_X1 * 33, DWR_PY = DWR_PG + PC_G * 33, DWR_PD = DWR_PY + PC_DY2 * 33, DWR_PIECES = DWR_PD + 32;
+constexpr int DWR_BUF = 4096;                       // floats per staging buffer (16 wave-instructions x 1 KiB)
+constexpr size_t DWR_LDS = (size_t)(DWR_SLOTS * 64 + 4 * 2 * DWR_BUF) * sizeof(float);
+static_assert(DWR_PIECES <= 16 * 64 && 2 * DW_TOTAL <= 4 * 2 * DWR_BUF, "dW staging layout");
+
+// float offset of column `col` of point row 0 in a piece-major image section that starts at piece `sec`
+__device__ __forceinline__ int dwr_col(int sec, int col) { return (sec + (col >> 2) * 33) * 4 + (col & 3); }
+
+// pieces [half * 512, half * 512 + 512) of a batch image: each of the two waves that share a batch fetches half of it
+__device__ __forceinline__ void dwr_fetch(const BwdWs& ws, const float* __restrict__ draw4, int64_t p0, int64_t n, int lane,
+                                          float* buf, int half) {
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)buf + half * 8192);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (half * 8 + i) * 64 + lane;
+        int q, row, pcs;
+        const float* base;
+        if (c < DWR_PG) { q = c / 33; row = c - 33 * q; base = ws.x1; pcs = PC_X1; }
+        else if (c < DWR_PY) { const int d = c - DWR_PG; q = d / 33; row = d - 33 * q; base = ws.g; pcs = PC_G; }
+        else if (c < DWR_PD) { const int d = c - DWR_PY; q = d / 33; row = d - 33 * q; base = ws.dy2; pcs = PC_DY2; }
+        else { q = -1; row = c < DWR_PIECES ? c - DWR_PD : 0; base = draw4; pcs = 0; }
+        // the pad slot and a ragged last batch re-read a valid point (finite values; masked or dropped below)
+        const int64_t pt = std::min<int64_t>(p0 + (row < 32 ? row : 0), n - 1);
+        const float* src = q < 0 ? base + pt * 4 : base + (pt >> 6) * (pcs * ROW_PIECE) + q * ROW_PIECE + (pt & 63) * 4;
+        // as inline asm: behind the builtin hipcc drains the DMA (vmcnt(0)) at the next ds_read of any LDS address, which
+        // would serialise the prefetch with the batch it is meant to overlap
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds0 + (unsigned)(i * 1024)) : "memory");
+    }
 }
 
-__global__ __launch_bounds__(256, 2) void field_dw_partial_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
-                                                               float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, lo = lane & 31, h = lane >> 5;
-    const int wv = threadIdx.x >> 6;
-    // points are dealt to (block, wave) in contiguous slabs of 2*STEP points
-    f32x16 a1[3], a3[3], a2, a4;
+// One batch, one side.  SIDE 0: H1pre, dH1pre -> dW1 (acc[0..2]), dW2 (acc[3]).  SIDE 1: H3pre, dH3pre -> dW3, dW4.
+template <int SIDE>
+__device__ __forceinline__ void dwr_batch(const float* __restrict__ buf, const float* __restrict__ wl, bool vl, int lane, f32x16 (&acc)[4]) {
+    const int lo = lane & 31, h = lane >> 5;
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(buf);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 hh = zero16(), tt = zero16();
+    if (SIDE == 0) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { a1[j] = zero16(); a3[j] = zero16(); }
-    a2 = zero16(); a4 = zero16();
-    const int64_t n_pairs = (n + 1) / 2;
-    const int64_t n_w = (int64_t)gridDim.x * 4;
-    const int64_t per = (n_pairs + n_w - 1) / n_w;
-    const int64_t w_id = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t s0 = w_id * per, s1 = std::min<int64_t>(n_pairs, s0 + per);
-#pragma unroll 4
-    for (int64_t s = s0; s < s1; ++s) {
-        const int64_t pt = 2 * s + h;
-        const float dh1 = ldrow(ws.dh1, pt, LD_H, lo, 32, n);
-        const float dh3 = ldrow(ws.dh3, pt, LD_H, lo, 32, n);
-        const float dy2 = ldrow(ws.dy2, pt, LD_DY2, lo, 16, n);
-        const float dy4 = ldrow(draw4, pt, 4, lo, 3, n);
-        const float x1a = ldrow(ws.x1, pt, LD_X1, lo, 96, n);
-        const float x1b = ldrow(ws.x1, pt, LD_X1, 32 + lo, 96, n);
-        const float x1c = ldrow(ws.x1, pt, LD_X1, 64 + lo, 96, n);
-        const float gg = ldrow(ws.g, pt, LD_G, lo, 32, n);
-        const float h1 = ldrow(ws.h1, pt, LD_H, lo, 32, n);
-        const float h3 = ldrow(ws.h3, pt, LD_H, lo, 32, n);
-        a1[0] = mfma32(dh1, x1a, a1[0]); a1[1] = mfma32(dh1, x1b, a1[1]); a1[2] = mfma32(dh1, x1c, a1[2]);
-        a2 = mfma32(dy2, h1, a2);
-        // X3 = [pos48 | geo15 ex3]: pos = X1 cols 32..79 -> needs cols 32+j; built from x1b/x1c shifted:
-        // N-tile 0 of X3 = X1 cols 32..63 = x1b; N-tile 1 = [X1 cols 64..79 | G cols 0..15]; N-tile 2 = G cols 16..17
-        const float x3b = lo < 16 ? ldrow(ws.x1, pt, LD_X1, 64 + lo, 96, n) : ldrow(ws.g, pt, LD_G, lo - 16, 32, n);
-        const float x3c = ldrow(ws.g, pt, LD_G, 16 + lo, 18, n);
-        a3[0] = mfma32(dh3, x1b, a3[0]); a3[1] = mfma32(dh3, x3b, a3[1]); a3[2] = mfma32(dh3, x3c, a3[2]);
-        a4 = mfma32(dy4, h3, a4);
-        (void)gg;
+        for (int q = 0; q < 21; ++q) {                              // H1pre = X1 . W1^T, 41 k-steps
+            float4 v = b4[DWR_PX + q * 33 + lo]; if (!vl) v = z4;   // columns 4q .. 4q+3 of the lane's point
+            hh = mfma32(h ? v.y : v.x, wl[(DWR_OFF1 + 2 * q) * 64 + lane], hh);
+            if (2 * q + 1 < 41) hh = mfma32(h ? v.w : v.z, wl[(DWR_OFF1 + 2 * q + 1) * 64 + lane], hh);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                               // T = dY2 . W2, 8
+            float4 v = b4[DWR_PY + q * 33 + lo]; if (!vl) v = z4;
+            tt = mfma32(h ? v.y : v.x, wl[(DWR_OFF2 + 2 * q) * 64 + lane], tt);
+            tt = mfma32(h ? v.w : v.z, wl[(DWR_OFF2 + 2 * q + 1) * 64 + lane], tt);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {                              // H3pre = [pos48 | geo15 | ex3] . W3^T, 33
+            float4 v = b4[DWR_PX + (8 + q) * 33 + lo]; if (!vl) v = z4;   // X1 columns 32..79: the OneBlob part
+            hh = mfma32(h ? v.y : v.x, wl[(DWR_OFF3 + 2 * q) * 64 + lane], hh);
+            hh = mfma32(h ? v.w : v.z, wl[(DWR_OFF3 + 2 * q + 1) * 64 + lane], hh);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float4 v = b4[DWR_PG + q * 33 + lo]; if (!vl) v = z4;
+            hh = mfma32(h ? v.y : v.x, wl[(DWR_OFF3 + 24 + 2 * q) * 64 + lane], hh);
+            if (q < 4) hh = mfma32(h ? v.w : v.z, wl[(DWR_OFF3 + 24 + 2 * q + 1) * 64 + lane], hh);
+        }
+        float4 v = b4[DWR_PD + lo]; if (!vl) v = z4;                // T3 = dY4 . W4, 2
+        tt = mfma32(h ? v.y : v.x, wl[(DWR_OFF4 + 0) * 64 + lane], tt);
+        tt = mfma32(h ? 0.f : v.z, wl[(DWR_OFF4 + 1) * 64 + lane], tt);
     }
-    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  The four waves of the block are summed in
-    // LDS in a fixed order -- waves 0 and 1 store into two images, waves 2 and 3 add to them, the write-out adds the two
-    // images -- then the block writes ONE partial.
-    __shared__ float acc2[2][DW_TOTAL];
+    // masks: dHpre, H.  A point past n has zero rows here, so it adds nothing below
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tt[r] = hh[r] > 0.f ? tt[r] : 0.f; hh[r] = fmaxf(hh[r], 0.f); }
+    // weight gradients: register r <-> the point pair (krow(r,0), krow(r,1)) of this batch.  Columns past a row's end read
+    // other finite parts of the image: they only reach output columns / rows the epilogue drops
+    const int oa = dwr_col(DWR_PX, lo), ob = dwr_col(DWR_PX, 32 + lo), oc = dwr_col(DWR_PX, 64 + lo);
+    const int oy = dwr_col(DWR_PY, lo & 15), og = dwr_col(DWR_PG, lo >= 16 ? lo - 16 : 0), oh = dwr_col(DWR_PG, 16 + (lo & 3));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* prow = buf + krow(r, h) * 4;
+        if (SIDE == 0) {
+            const float x1a = prow[oa], x1b = prow[ob], x1c = prow[oc];
+            const float dy2 = prow[oy];
+            acc[0] = mfma32(tt[r], x1a, acc[0]); acc[1] = mfma32(tt[r], x1b, acc[1]); acc[2] = mfma32(tt[r], x1c, acc[2]);
+            acc[3] = mfma32(dy2, hh[r], acc[3]);
+        } else {
+            const float x1b = prow[ob], x1c = prow[oc];
+            const float gb = prow[og], gc = prow[oh];
+            const float dy4 = lo < 3 ? prow[DWR_PD * 4 + (lo & 3)] : 0.f;
+            const float x3b = lo < 16 ? x1c : gb;                   // X3 columns 32..63 = [pos 32..47 | geo 0..14, ex_r]
+            acc[0] = mfma32(tt[r], x1b, acc[0]); acc[1] = mfma32(tt[r], x3b, acc[1]); acc[2] = mfma32(tt[r], gc, acc[2]);
+            acc[3] = mfma32(dy4, hh[r], acc[3]);
+        }
+    }
+}
+
+// 8 waves: wave w and wave w + 4 (scheduled onto the same SIMD) share the batches of slot w & 3 -- the first takes the
+// H1 side, the second the H3 side -- so that each SIMD has two waves' worth of independent MFMA chains and LDS reads.
+__global__ __launch_bounds__(512) void field_dw_recompute_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
+                                                              float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float dwr_lds[];
+    float* wl = dwr_lds;                                     // [DWR_SLOTS][64] weight images
+    float* stage = dwr_lds + DWR_SLOTS * 64;                 // [slot][2][DWR_BUF]; after the loop: acc2 [2][DW_TOTAL]
+    const int lane = threadIdx.x & 63, lo = lane & 31, h = lane >> 5;
+    const int wv = threadIdx.x >> 6, slot = wv & 3, side = wv >> 2;
+    float* mine = stage + slot * 2 * DWR_BUF;
+    const int64_t n_b = (n + 31) / 32, n_s = (int64_t)gridDim.x * 4;
+    const int64_t n_it = (n_b + n_s - 1) / n_s;              // every wave of the block runs the same number of rounds (barriers inside)
+    int64_t bt = (int64_t)blockIdx.x * 4 + slot;             // batches bt, bt + n_s, ...
+    if (bt < n_b) dwr_fetch(ws, draw4, bt * 32, n, lane, mine, side);
+    for (int i = threadIdx.x; i < DWR_SLOTS * 16; i += 512)
+        reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(ws.wcopy)[i];
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = zero16();
+    int cur = 0;
+    for (int64_t it = 0; it < n_it; ++it, bt += n_s, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my half of this round's batch has landed ...
+        __syncthreads();                                      // ... and so has everybody's; the other buffer is free again
+        if (bt + n_s < n_b) dwr_fetch(ws, draw4, (bt + n_s) * 32, n, lane, mine + (cur ^ 1) * DWR_BUF, side);
+        if (bt < n_b) {
+            const bool vl = bt * 32 + lo < n;
+            if (side == 0) dwr_batch<0>(mine + cur * DWR_BUF, wl, vl, lane, acc);
+            else dwr_batch<1>(mine + cur * DWR_BUF, wl, vl, lane, acc);
+        }
+    }
+    // D tile: lane (col = in index lo, half h), reg r -> out row krow(r,h).  The four slots of the block are summed in
+    // LDS in a fixed order (over the staging buffers, which every wave is done with), then the block writes ONE partial.
+    __syncthreads();
+    float* acc2 = stage;
     for (int turn = 0; turn < 2; ++turn) {
-        if ((wv >> 1) == turn) {
-            float* acc = acc2[wv & 1];
+        if ((slot >> 1) == turn) {
+            float* a = acc2 + (slot & 1) * DW_TOTAL;
+            const int in_n = side ? N_IN3 : N_IN1, out_n = side ? N_OUT4 : N_OUT2;
+            float* big = a + (side ? N_H * N_IN1 + N_OUT2 * N_H : 0);                       // dW1 | dW3  [N_H][in_n]
+            float* small = a + (side ? N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 : N_H * N_IN1);   // dW2 | dW4  [out_n][N_H]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = krow(r, h);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int i1 = 32 * j + lo;
-                    if (i1 < N_IN1) { float& d = acc[o * N_IN1 + i1]; d = turn ? d + a1[j][r] : a1[j][r]; }
-                    if (i1 < N_IN3) { float& d = acc[N_H * N_IN1 + N_OUT2 * N_H + o * N_IN3 + i1]; d = turn ? d + a3[j][r] : a3[j][r]; }
+                    if (i1 < in_n) { float& d = big[o * in_n + i1]; d = turn ? d + acc[j][r] : acc[j][r]; }
                 }
-                if (o < N_OUT2) { float& d = acc[N_H * N_IN1 + o * N_H + lo]; d = turn ? d + a2[r] : a2[r]; }
-                if (o < N_OUT4) { float& d = acc[N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + o * N_H + lo]; d = turn ? d + a4[r] : a4[r]; }
+                if (o < out_n) { float& d = small[o * N_H + lo]; d = turn ? d + acc[3][r] : acc[3][r]; }
             }
         }
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * DW_TOTAL;
-    for (int i = threadIdx.x; i < DW_TOTAL; i += 256) out[i] = acc2[0][i] + acc2[1][i];
+    for (int i = threadIdx.x; i < DW_TOTAL; i += 512) out[i] = acc2[i] + acc2[DW_TOTAL + i];
 }
 
 // deterministic second stage: block = 64 consecutive outputs x 16 slices of the partial list (a wave reads 256
@@ -1298,7 +1403,7 @@ int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, 
 size_t rfx_field_backward_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
     const size_t np = align_up((size_t)n, 64);
-    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * 4 * DW_TOTAL + scatter_scratch_floats(n, RFX_MAX_LEVELS)) * sizeof(float);
+    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * DW_TOTAL + DWR_SLOTS * 64 + scatter_scratch_floats(n, RFX_MAX_LEVELS)) * sizeof(float);
 }
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
@@ -1362,12 +1467,22 @@ static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, fl
     if (!draw4 || n < 0) return RFX_ERR_ARG;
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
-    hipLaunchKernelGGL(field_dw_partial_kernel, dim3(DW_BLOCKS), dim3(256), 0, st, ws, draw4, n, ws.partial);
+    // persistent: one block per CU (150 KB of LDS each), whole 32-point batches dealt round-robin to the wave pairs
+    static bool attr_set[64] = {};       // the attribute is per device; benign if raced
+    int dev = 0;
+    RFX_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(field_dw_recompute_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWR_LDS));
+        attr_set[dev] = true;
+    }
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(DW_BLOCKS, ((n + 31) / 32 + 3) / 4));
+    hipLaunchKernelGGL(field_dw_recompute_kernel, dim3(blocks), dim3(512), DWR_LDS, st, ws, draw4, n, ws.partial);
     RFX_LAUNCH_CHECK();
     if (overwrite)
-        hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS, dw1, dw2, dw3, dw4);
+        hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, blocks, dw1, dw2, dw3, dw4);
     else
-        hipLaunchKernelGGL(field_dw_reduce_kernel<false>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, DW_BLOCKS, dw1, dw2, dw3, dw4);
+        hipLaunchKernelGGL(field_dw_reduce_kernel<false>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, blocks, dw1, dw2, dw3, dw4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

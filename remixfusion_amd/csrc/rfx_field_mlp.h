@@ -335,6 +335,11 @@ __device__ __forceinline__ void sparse_pos_tiles(const float* __restrict__ wp, c
     }
 }
 
+// Backward staging: x1row points at the lane's own point inside a piece-major tile of 64 points (rfx_field.hip, workspace
+// layout): float4 piece q of the row is ROW_PIECE floats after piece q - 1, so a wave's store of one piece is contiguous.
+constexpr int ROW_PIECE = 256;
+__device__ __forceinline__ float* row_piece(float* row, int col) { return row + (col >> 2) * ROW_PIECE + (col & 3); }
+
 template <bool STAGE, bool POS16>
 __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
                                                 int lane, Enc& e, Mlp& m, float* x1row = nullptr,
@@ -350,7 +355,7 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const half2v p0 = __builtin_bit_cast(half2v, dw[2 * i]), p1 = __builtin_bit_cast(half2v, dw[2 * i + 1]);
-                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) = make_float4((float)p0[0], (float)p0[1], (float)p1[0], (float)p1[1]);
+                    *reinterpret_cast<float4*>(row_piece(x1row, N_EMB + 16 * d + 4 * i)) = make_float4((float)p0[0], (float)p0[1], (float)p1[0], (float)p1[1]);
                 }
             }
             // dwords 0..3 = k 0..7 (lane half 0's fragment), 4..7 = k 8..15; (a_i, b_i) pairs for the swap
@@ -412,7 +417,13 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
 #pragma unroll
         for (int g = 0; g < HG; ++g) {
             const int s = s0 + g;
-            if (STAGE && valid) reinterpret_cast<float2*>(x1row)[s] = v[g];
+            if (STAGE && valid) {
+                if (HG % 2 == 0) {      // levels 2i, 2i+1 are one piece
+                    if (g % 2 == 0) *reinterpret_cast<float4*>(row_piece(x1row, 2 * s)) = make_float4(v[g].x, v[g].y, v[(g + 1) % HG].x, v[(g + 1) % HG].y);
+                } else {
+                    *reinterpret_cast<float2*>(row_piece(x1row, 2 * s)) = v[g];
+                }
+            }
             float a = v[g].x, b = v[g].y;
             swap32(a, b);
             const float w = wl[(OFF1 + s) * 64 + lane];
@@ -433,7 +444,7 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
                 oneblob_dense_from_sparse(pb, d, full);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4*>(x1row + N_EMB + 16 * d + 4 * i) = make_float4(full[4 * i], full[4 * i + 1], full[4 * i + 2], full[4 * i + 3]);
+                    *reinterpret_cast<float4*>(row_piece(x1row, N_EMB + 16 * d + 4 * i)) = make_float4(full[4 * i], full[4 * i + 1], full[4 * i + 2], full[4 * i + 3]);
             }
         }
         sparse_pos_tiles(wl + (OFF1 + 16) * 64, pb, extra, m.h1[0], m.h1[1]);
