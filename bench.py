@@ -73,9 +73,10 @@ class KernelTimer:
         self.enabled = False
         self.every = 4
 
-    def wrap(self, lib, name):
+    def wrap(self, lib, name, record_as=None):
         fn = getattr(lib, name)
         timer = self
+        rec = record_as or name
 
         count = [0]
 
@@ -87,7 +88,7 @@ class KernelTimer:
             e0.record()
             rc = fn(*a)
             e1.record()
-            timer.records.setdefault(name, []).append((e0, e1, a))
+            timer.records.setdefault(rec, []).append((e0, e1, a))
             return rc
 
         setattr(lib, name, timed)
@@ -239,6 +240,11 @@ def main():
                  "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
                  "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):
         timer.wrap(lib, name)
+    # the optimisation steps run the forward / chain pair that shares its hash lookups (include/rfx.h): same work items,
+    # reported under the un-suffixed names (points per launch = argument 2 either way)
+    timer.wrap(lib, "rfx_field_forward_stash", "rfx_field_forward")
+    for name in ("rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights"):
+        timer.wrap(lib, name + "_stashed", name)
 
     cfg = synthetic_config(args.config)
     if args.first_iters is not None:

@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 2
+#define RFX_ABI_VERSION 3
 
 typedef void* rfx_stream;
 
@@ -232,6 +232,21 @@ int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, i
  * not follow it. */
 int rfx_field_backward_chain_weights(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* The forward / backward pair of ONE optimisation step shares its hash lookups: rfx_field_forward_stash is
+ * rfx_field_forward that also leaves the interpolated hash features of the n points in `workspace` (a buffer of
+ * rfx_field_backward_workspace_bytes(n)), and rfx_field_backward_chain_stashed is the chain stage that reads them instead
+ * of looking the table up again (the reference's autograd keeps the encoding output alive between forward and backward the
+ * same way: model/scene_rep.py:141-160 run_network -> tcnn backward).  Valid only while x01, n, the hash table and the
+ * workspace are what the forward saw (no optimiser step, no other _chain on that workspace in between); results are
+ * bit-identical to the un-stashed entry points. */
+int rfx_field_forward_stash(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, void* workspace,
+                            size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_chain_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_chain_inputs_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                            void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_field_backward_chain_weights_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                             void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_t n, float* d_hash, float* dx01,

@@ -104,6 +104,10 @@ PROTOTYPES = {
     "rfx_field_backward_chain": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
     "rfx_field_backward_chain_inputs": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
     "rfx_field_backward_chain_weights": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_forward_stash": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_chain_stashed": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_chain_inputs_stashed": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_chain_weights_stashed": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
     "rfx_field_backward_weights": (_i, [_l, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rfx_field_backward_scatter": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),
     "rfx_field_backward_dx": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _P, _sz, _P]),
@@ -162,7 +166,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 2:
+    if lib.rfx_abi_version() != 3:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

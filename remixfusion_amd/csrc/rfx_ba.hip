@@ -108,7 +108,8 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
                             b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->bbox,
                             b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, stream));     // rays, S1, points
     // ---- forward
-    RFX_TRY(rfx_field_forward(&b->field, w.x01, nS, w.raw, stream));
+    // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
+    RFX_TRY(rfx_field_forward_stash(&b->field, w.x01, nS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
     const float trunc_loss = b->trunc * b->sc_factor;
     float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
     int n_partials = 0;
@@ -125,9 +126,9 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
                                         b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw,
                                         stream));                                                                   // L1 finish + backward
     // the chain variant that produces exactly what the following stages read
-    if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    else RFX_TRY(rfx_field_backward_chain_inputs(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    else RFX_TRY(rfx_field_backward_chain_inputs_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     if (map_grads) {
         RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
         float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;

@@ -24,9 +24,11 @@
 namespace rfx {
 
 // ---------------------------------------------------------------- Q1 forward kernel
-template <bool POS16>
+// STASH: also leave the interpolated hash features in `emb` (piece-major tiles, see the backward workspace layout) for the
+// backward chain of the same iteration, which then needs no hash lookups of its own.
+template <bool POS16, bool STASH>
 __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
-                                                            float* __restrict__ raw4) {
+                                                            float* __restrict__ raw4, float* __restrict__ emb) {
     __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
     stage_weights(f, wl, FWD_SLOTS);
     const int lane = threadIdx.x & 63;
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f,
         Enc e;
         encode_point(f, x, e);
         Mlp m;
-        mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
+        mlp_forward_123<STASH ? 1 : 0, false, POS16>(f, x, wl, lane, e, m, STASH ? emb + (p >> 6) * (8 * ROW_PIECE) + (p & 63) * 4 : nullptr,
+                                                     nullptr, p < n);
         float raw[4];
         mlp_forward_4(wl, lane, e, m, raw);
         if (p < n) reinterpret_cast<float4*>(raw4)[p] = make_float4(raw[0], raw[1], raw[2], raw[3]);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_query_kernel(FieldK f, c
         encode_point(f, x, e);
         if (MODE == 1) e.cin = e.ex[0];          // scene_rep.py:294: ex_Trgb[...,:1] unscaled
         Mlp m;
-        mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
+        mlp_forward_123<0, false, POS16>(f, x, wl, lane, e, m);
         if (MODE == 0) {
             float a = m.h2[0][0], b = m.h2[1][0];
             swap32(a, b);
@@ -767,13 +770,13 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
 
 // ---------------------------------------------------------------- backward: workspace layout
 // per-point rows (fp32).  dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..], row-major, one row of LD_DX1 per point.
-// What only the weight-gradient kernel reads -- X1 = [emb32 | pos48 | cin | 0 0 0] (21 float4 pieces), G = [geo15 | ex_rgb3
-// | 0 0] (5), dY2 (4) -- is PIECE-MAJOR inside tiles of 64 points (row_piece() in rfx_field_mlp.h): piece q of point p sits at
+// What only the weight-gradient kernel reads -- emb32 (8 float4 pieces; also the forward's stash for the chain), X1' =
+// [pos48 | cin | 0 0 0] (13), G = [geo15 | ex_rgb3 | 0 0] (5), dY2 (4) -- is PIECE-MAJOR inside tiles of 64 points (row_piece() in rfx_field_mlp.h): piece q of point p sits at
 // tile (p / 64) * pieces * 256 + q * 256 + (p % 64) * 4 floats.  The chain kernel has lane = point, so each of its float4
 // stores is then one contiguous 1 KiB write per wave (a row-major row would make it 64 16-byte writes 384 B apart), and
 // the weight-gradient kernel's LDS image of a batch is piece-major as well, so its fills are contiguous reads.
 constexpr int LD_DX1 = 96;
-constexpr int PC_X1 = 21, PC_G = 5, PC_DY2 = 4;      // float4 pieces per point
+constexpr int PC_EMB = 8, PC_X1 = 13, PC_G = 5, PC_DY2 = 4;      // float4 pieces per point
 constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
 constexpr int DW_BLOCKS = 256;       // the weight-gradient kernel is persistent: at most one block per CU
 
@@ -781,10 +784,10 @@ constexpr int DW_BLOCKS = 256;       // the weight-gradient kernel is persistent
 constexpr int DWR_OFF1 = 0, DWR_OFF2 = 41, DWR_OFF3 = 49, DWR_OFF4 = 82, DWR_SLOTS = 84;
 
 struct BwdWs {
-    float *x1, *g, *dy2, *dx1, *demb_t, *partial, *wcopy;
+    float *emb, *x1, *g, *dy2, *dx1, *demb_t, *partial, *wcopy;
 };
 
-__host__ __device__ inline size_t ws_floats_per_point() { return 4 * (PC_X1 + PC_G + PC_DY2) + LD_DX1; }
+__host__ __device__ inline size_t ws_floats_per_point() { return 4 * (PC_EMB + PC_X1 + PC_G + PC_DY2) + LD_DX1; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -792,6 +795,7 @@ static BwdWs carve(void* ws, int64_t n) {
     BwdWs w;
     float* p = reinterpret_cast<float*>(ws);
     const size_t np = align_up((size_t)n, 64);
+    w.emb = p; p += np * 4 * PC_EMB;
     w.x1 = p; p += np * 4 * PC_X1;
     w.g = p; p += np * 4 * PC_G;
     w.dy2 = p; p += np * 4 * PC_DY2;
@@ -851,7 +855,9 @@ __device__ __forceinline__ float dwr_image(const float* __restrict__ w1, const f
     return k < N_OUT4 ? w4[k * N_H + lo] : 0.f;                                                                    // B[k=c][n=hid] = W4[c][hid]
 }
 
-template <bool POS16, bool ROWS, bool DXFULL>
+// STASHED: the hash features of these points are already in ws.emb (rfx_field_forward_stash ran on the same points, table and
+// workspace): the forward recompute skips its 128 gathers per point.
+template <bool POS16, bool ROWS, bool DXFULL, bool STASHED>
 __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                              const float* __restrict__ draw4, BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -871,11 +877,12 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
 
         Enc e;
         encode_point(f, x, e);
-        // ---- stage X1 (emb part inside the forward; pos/cin after the forward has used them)
-        float* x1row = ws.x1 + (p >> 6) * (PC_X1 * ROW_PIECE) + (p & 63) * 4;        // piece-major, see the workspace layout
+        // ---- stage X1 = [emb | pos, cin] (inside the forward), piece-major: see the workspace layout
+        float* emb_row = ws.emb + (p >> 6) * (PC_EMB * ROW_PIECE) + (p & 63) * 4;
+        float* x1row = ws.x1 + (p >> 6) * (PC_X1 * ROW_PIECE) + (p & 63) * 4;
         Mlp m;
-        mlp_forward_123<ROWS, POS16>(f, x, wl, lane, e, m, x1row, valid);    // stages emb and pos itself
-        if (ROWS && valid) st4(row_piece(x1row, 80), 0, e.cin, 0.f, 0.f, 0.f);
+        mlp_forward_123<STASHED ? 2 : (ROWS ? 1 : 0), ROWS, POS16>(f, x, wl, lane, e, m, emb_row, x1row, valid);
+        if (ROWS && valid) st4(row_piece(x1row, 48), 0, e.cin, 0.f, 0.f, 0.f);
         const unsigned mask1 = positive_mask(m.h1[0], m.h1[1]);
         const unsigned mask3 = positive_mask(m.h3[0], m.h3[1]);
         if (ROWS) {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
 // (global_load_lds_dwordx4: the 64 pieces of one wave-instruction land at consecutive LDS addresses, each from its own
 // lane's source address -- 32 consecutive pieces of the staged tile, then the pad), 16 instructions per batch and no
 // VGPRs, one batch ahead of the arithmetic.
-constexpr int DWR_PX = 0, DWR_PG = PC_X1 * 33, DWR_PY = DWR_PG + PC_G * 33, DWR_PD = DWR_PY + PC_DY2 * 33, DWR_PIECES = DWR_PD + 32;
+constexpr int DWR_PX = 0, DWR_PG = (PC_EMB + PC_X1) * 33, DWR_PY = DWR_PG + PC_G * 33, DWR_PD = DWR_PY + PC_DY2 * 33, DWR_PIECES = DWR_PD + 32;
 constexpr int DWR_BUF = 4096;                       // floats per staging buffer (16 wave-instructions x 1 KiB)
 constexpr size_t DWR_LDS = (size_t)(DWR_SLOTS * 64 + 4 * 2 * DWR_BUF) * sizeof(float);
 static_assert(DWR_PIECES <= 16 * 64 && 2 * DW_TOTAL <= 4 * 2 * DWR_BUF, "dW staging layout");
@@ -1047,7 +1054,7 @@ __device__ __forceinline__ void dwr_fetch(const BwdWs& ws, const float* __restri
         const int c = (half * 8 + i) * 64 + lane;
         int q, row, pcs;
         const float* base;
-        if (c < DWR_PG) { q = c / 33; row = c - 33 * q; base = ws.x1; pcs = PC_X1; }
+        if (c < DWR_PG) { q = c / 33; row = c - 33 * q; base = q < PC_EMB ? ws.emb : ws.x1; pcs = q < PC_EMB ? PC_EMB : PC_X1; q -= q < PC_EMB ? 0 : PC_EMB; }
         else if (c < DWR_PY) { const int d = c - DWR_PG; q = d / 33; row = d - 33 * q; base = ws.g; pcs = PC_G; }
         else if (c < DWR_PD) { const int d = c - DWR_PY; q = d / 33; row = d - 33 * q; base = ws.dy2; pcs = PC_DY2; }
         else { q = -1; row = c < DWR_PIECES ? c - DWR_PD : 0; base = draw4; pcs = 0; }
@@ -1360,17 +1367,27 @@ int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, f
     return RFX_OK;
 }
 
-int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream) {
+static int launch_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, float* emb, rfx_stream stream) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
     if (!x01 || !raw4 || n < 0) return RFX_ERR_ARG;
-    if (n == 0) return RFX_OK;
-    if (k.pos_fp16) hipLaunchKernelGGL(field_forward_kernel<true>, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
-    else hipLaunchKernelGGL(field_forward_kernel<false>, dim3(wave_grid(n, 256 * 4)), dim3(256), 0, as_stream(stream), k, x01, n, raw4);
+    const dim3 grid(wave_grid(n, 256 * 4));
+    hipStream_t st = as_stream(stream);
+    if (emb) {
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, true>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        else hipLaunchKernelGGL((field_forward_kernel<false, true>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+    } else {
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, false>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        else hipLaunchKernelGGL((field_forward_kernel<false, false>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+    }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+int rfx_field_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, rfx_stream stream) {
+    return launch_forward(f, x01, n, raw4, nullptr, stream);
 }
 
 int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream) {
@@ -1407,8 +1424,17 @@ size_t rfx_field_backward_workspace_bytes(int64_t n) {
 }
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
+int rfx_field_forward_stash(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, void* workspace, size_t workspace_bytes,
+                            rfx_stream stream) {
+    if (n == 0) return RFX_OK;
+    if (n < 0) return RFX_ERR_ARG;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
+    return launch_forward(f, x01, n, raw4, carve(workspace, n).emb, stream);
+}
+
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
-                                 size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull) {
+                                 size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull, bool stashed = false) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
@@ -1419,19 +1445,21 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
     BwdWs ws = carve(workspace, n);
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
     using Kern = void (*)(FieldK, const float*, int64_t, const float*, BwdWs);
-    // [pos_fp16][variant]: 0 = rows + full dX1 (_chain), 1 = full dX1 only (_chain_inputs), 2 = rows + d_emb (_chain_weights)
-    static const Kern kern[2][3] = {
-        {field_backward_kernel<false, true, true>, field_backward_kernel<false, false, true>, field_backward_kernel<false, true, false>},
-        {field_backward_kernel<true, true, true>, field_backward_kernel<true, false, true>, field_backward_kernel<true, true, false>}};
+    // [pos_fp16 | stashed][variant]: 0 = rows + full dX1 (_chain), 1 = full dX1 only (_chain_inputs), 2 = rows + d_emb (_chain_weights)
+    static const Kern kern[4][3] = {
+        {field_backward_kernel<false, true, true, false>, field_backward_kernel<false, false, true, false>, field_backward_kernel<false, true, false, false>},
+        {field_backward_kernel<true, true, true, false>, field_backward_kernel<true, false, true, false>, field_backward_kernel<true, true, false, false>},
+        {field_backward_kernel<false, true, true, true>, field_backward_kernel<false, false, true, true>, field_backward_kernel<false, true, false, true>},
+        {field_backward_kernel<true, true, true, true>, field_backward_kernel<true, false, true, true>, field_backward_kernel<true, true, false, true>}};
     static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
     if (!attr_set) {
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
             for (int v = 0; v < 3; ++v)
                 RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int variant = rows ? (dxfull ? 0 : 2) : 1;
-    hipLaunchKernelGGL(kern[k.pos_fp16 ? 1 : 0][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
+    hipLaunchKernelGGL(kern[(k.pos_fp16 ? 1 : 0) + (stashed ? 2 : 0)][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1449,6 +1477,21 @@ int rfx_field_backward_chain_inputs(const rfx_field_desc* f, const float* x01, i
 int rfx_field_backward_chain_weights(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream) {
     return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, false);
+}
+
+int rfx_field_backward_chain_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, true, true);
+}
+
+int rfx_field_backward_chain_inputs_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                            void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, false, true, true);
+}
+
+int rfx_field_backward_chain_weights_stashed(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
+                                             void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, true, false, true);
 }
 
 static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,

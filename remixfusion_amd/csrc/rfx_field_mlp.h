@@ -181,7 +181,7 @@ struct Mlp {
 };
 
 // Hash-grid levels are looked up and fed to the matrix cores level by level (level l = k-step l),
-// so the 32 features are never all live.  STAGE: also write them to x1row (backward staging).
+// so the 32 features are never all live (EMB / POSST below: backward staging).
 // consumes e.cin / e.ex; computes OneBlob itself (POS16: packed fp16 fragments in e.pos16, else the nine non-zero fp32 bins,
 // multiplied on the VALU: sparse_pos_tiles)
 // (historic note, dense fp32 form: e.pos in
@@ -335,14 +335,18 @@ __device__ __forceinline__ void sparse_pos_tiles(const float* __restrict__ wp, c
     }
 }
 
-// Backward staging: x1row points at the lane's own point inside a piece-major tile of 64 points (rfx_field.hip, workspace
-// layout): float4 piece q of the row is ROW_PIECE floats after piece q - 1, so a wave's store of one piece is contiguous.
+// Backward staging: emb_row / pos_row point at the lane's own point inside a piece-major tile of 64 points (rfx_field.hip,
+// workspace layout): float4 piece q of the row is ROW_PIECE floats after piece q - 1, so a wave's store (or load) of one
+// piece is contiguous.
+//   EMB 0: look the hash features up.  1: look them up and store them to emb_row (8 pieces).  2: load them from emb_row,
+//          where an earlier kernel (the forward of the same iteration, or EMB 1) left them: no gathers, no interpolation.
+//   POSST: store the dense fp32 OneBlob row to pos_row (12 pieces).
 constexpr int ROW_PIECE = 256;
 __device__ __forceinline__ float* row_piece(float* row, int col) { return row + (col >> 2) * ROW_PIECE + (col & 3); }
 
-template <bool STAGE, bool POS16>
+template <int EMB, bool POSST, bool POS16>
 __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
-                                                int lane, Enc& e, Mlp& m, float* x1row = nullptr,
+                                                int lane, Enc& e, Mlp& m, float* emb_row = nullptr, float* pos_row = nullptr,
                                                 bool valid = true) {
     m.h1[0] = zero16(); m.h1[1] = zero16();
     if (POS16) {
@@ -351,11 +355,11 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         for (int d = 0; d < 3; ++d) {
             unsigned dw[8];
             oneblob_dim_packed16(x[d], dw);
-            if (STAGE && valid) {
+            if (POSST && valid) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const half2v p0 = __builtin_bit_cast(half2v, dw[2 * i]), p1 = __builtin_bit_cast(half2v, dw[2 * i + 1]);
-                    *reinterpret_cast<float4*>(row_piece(x1row, N_EMB + 16 * d + 4 * i)) = make_float4((float)p0[0], (float)p0[1], (float)p1[0], (float)p1[1]);
+                    *reinterpret_cast<float4*>(row_piece(pos_row, 16 * d + 4 * i)) = make_float4((float)p0[0], (float)p0[1], (float)p1[0], (float)p1[1]);
                 }
             }
             // dwords 0..3 = k 0..7 (lane half 0's fragment), 4..7 = k 8..15; (a_i, b_i) pairs for the swap
@@ -380,8 +384,21 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
     // keeping all 16 x 5 of them live in SGPRs.
     constexpr int HG = HASH_GROUP;
     static_assert(16 % HG == 0, "HASH_GROUP must divide the 16 levels");
+    if (EMB == 2) {
+        float4 q[8];                  // levels 2i, 2i+1 are piece i of the stashed row: eight contiguous loads, issued together
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const float4*>(emb_row + i * ROW_PIECE);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float a = (s & 1) ? q[s >> 1].z : q[s >> 1].x, b = (s & 1) ? q[s >> 1].w : q[s >> 1].y;
+            swap32(a, b);
+            const float w = wl[(OFF1 + s) * 64 + lane];
+            m.h1[0] = mfma32(w, a, m.h1[0]);
+            m.h1[1] = mfma32(w, b, m.h1[1]);
+        }
+    }
 #pragma unroll 1
-    for (int s0 = 0; s0 < 16; s0 += HG) {
+    for (int s0 = 0; s0 < (EMB == 2 ? 0 : 16); s0 += HG) {
         float2 v[HG];
 #if defined(FIELD_DBG) && FIELD_DBG == 4
 #pragma unroll
@@ -417,11 +434,11 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
 #pragma unroll
         for (int g = 0; g < HG; ++g) {
             const int s = s0 + g;
-            if (STAGE && valid) {
+            if (EMB == 1 && valid) {
                 if (HG % 2 == 0) {      // levels 2i, 2i+1 are one piece
-                    if (g % 2 == 0) *reinterpret_cast<float4*>(row_piece(x1row, 2 * s)) = make_float4(v[g].x, v[g].y, v[(g + 1) % HG].x, v[(g + 1) % HG].y);
+                    if (g % 2 == 0) *reinterpret_cast<float4*>(row_piece(emb_row, 2 * s)) = make_float4(v[g].x, v[g].y, v[(g + 1) % HG].x, v[(g + 1) % HG].y);
                 } else {
-                    *reinterpret_cast<float2*>(row_piece(x1row, 2 * s)) = v[g];
+                    *reinterpret_cast<float2*>(row_piece(emb_row, 2 * s)) = v[g];
                 }
             }
             float a = v[g].x, b = v[g].y;
@@ -437,14 +454,14 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
 #pragma unroll
         for (int d = 0; d < 3; ++d) oneblob_dim_sparse(x[d], d, pb);
         extra = __any(pb.rest[0] != 0.0f || pb.rest[1] != 0.0f || pb.rest[2] != 0.0f) != 0;
-        if (STAGE && valid) {       // dense fp32 row for the weight-gradient kernel
+        if (POSST && valid) {       // dense fp32 row for the weight-gradient kernel
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 float full[16];
                 oneblob_dense_from_sparse(pb, d, full);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4*>(row_piece(x1row, N_EMB + 16 * d + 4 * i)) = make_float4(full[4 * i], full[4 * i + 1], full[4 * i + 2], full[4 * i + 3]);
+                    *reinterpret_cast<float4*>(row_piece(pos_row, 16 * d + 4 * i)) = make_float4(full[4 * i], full[4 * i + 1], full[4 * i + 2], full[4 * i + 3]);
             }
         }
         sparse_pos_tiles(wl + (OFF1 + 16) * 64, pb, extra, m.h1[0], m.h1[1]);

@@ -100,32 +100,38 @@ __global__ void rba_set_init_pose_kernel(const float* __restrict__ c2w, int cam,
 // pose, and for a non-keyframe its pose relative to the newest keyframe, delta = c2w @ inverse(kf_c2w) (general 4x4 inverse, like torch's .inverse()).
 __global__ void frame_pose_kernel(const float* __restrict__ c2w, const float* __restrict__ kf, float* __restrict__ est_out,
                                   float* __restrict__ rel_out) {
-    __shared__ float inv[16];
-    const int t = threadIdx.x;
-    if (t < 16) est_out[t] = c2w[t];
+    // one wave, two memory round trips: the pose element of lane t and (scalar loads) the keyframe pose are fetched
+    // together; every lane inverts the keyframe pose itself and takes its row of c2w from the other lanes' registers
+    const int t = threadIdx.x & 15;
+    const float cv = c2w[t];
+    if (threadIdx.x < 16) est_out[t] = cv;
     if (!rel_out) return;
-    if (t == 0) {       // 4x4 inverse from its 2x2 sub-determinants (all indices static: registers, no scratch)
-        const float a00 = kf[0], a01 = kf[1], a02 = kf[2], a03 = kf[3], a10 = kf[4], a11 = kf[5], a12 = kf[6], a13 = kf[7];
-        const float a20 = kf[8], a21 = kf[9], a22 = kf[10], a23 = kf[11], a30 = kf[12], a31 = kf[13], a32 = kf[14], a33 = kf[15];
-        const float s0 = a00 * a11 - a10 * a01, s1 = a00 * a12 - a10 * a02, s2 = a00 * a13 - a10 * a03;
-        const float s3 = a01 * a12 - a11 * a02, s4 = a01 * a13 - a11 * a03, s5 = a02 * a13 - a12 * a03;
-        const float c5 = a22 * a33 - a32 * a23, c4 = a21 * a33 - a31 * a23, c3 = a21 * a32 - a31 * a22;
-        const float c2 = a20 * a33 - a30 * a23, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
-        const float id = 1.0f / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
-        inv[0] = (a11 * c5 - a12 * c4 + a13 * c3) * id;   inv[1] = (-a01 * c5 + a02 * c4 - a03 * c3) * id;
-        inv[2] = (a31 * s5 - a32 * s4 + a33 * s3) * id;   inv[3] = (-a21 * s5 + a22 * s4 - a23 * s3) * id;
-        inv[4] = (-a10 * c5 + a12 * c2 - a13 * c1) * id;  inv[5] = (a00 * c5 - a02 * c2 + a03 * c1) * id;
-        inv[6] = (-a30 * s5 + a32 * s2 - a33 * s1) * id;  inv[7] = (a20 * s5 - a22 * s2 + a23 * s1) * id;
-        inv[8] = (a10 * c4 - a11 * c2 + a13 * c0) * id;   inv[9] = (-a00 * c4 + a01 * c2 - a03 * c0) * id;
-        inv[10] = (a30 * s4 - a31 * s2 + a33 * s0) * id;  inv[11] = (-a20 * s4 + a21 * s2 - a23 * s0) * id;
-        inv[12] = (-a10 * c3 + a11 * c1 - a12 * c0) * id; inv[13] = (a00 * c3 - a01 * c1 + a02 * c0) * id;
-        inv[14] = (-a30 * s3 + a31 * s1 - a32 * s0) * id; inv[15] = (a20 * s3 - a21 * s1 + a22 * s0) * id;
+    // 4x4 inverse from its 2x2 sub-determinants (all indices static: registers, no scratch)
+    const float a00 = kf[0], a01 = kf[1], a02 = kf[2], a03 = kf[3], a10 = kf[4], a11 = kf[5], a12 = kf[6], a13 = kf[7];
+    const float a20 = kf[8], a21 = kf[9], a22 = kf[10], a23 = kf[11], a30 = kf[12], a31 = kf[13], a32 = kf[14], a33 = kf[15];
+    const float s0 = a00 * a11 - a10 * a01, s1 = a00 * a12 - a10 * a02, s2 = a00 * a13 - a10 * a03;
+    const float s3 = a01 * a12 - a11 * a02, s4 = a01 * a13 - a11 * a03, s5 = a02 * a13 - a12 * a03;
+    const float c5 = a22 * a33 - a32 * a23, c4 = a21 * a33 - a31 * a23, c3 = a21 * a32 - a31 * a22;
+    const float c2 = a20 * a33 - a30 * a23, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
+    const float id = 1.0f / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    const int c = t & 3;                 // the lane's column of the inverse: rows 0..3
+    float i0, i1, i2, i3;
+    if (c == 0) {
+        i0 = (a11 * c5 - a12 * c4 + a13 * c3) * id;   i1 = (-a10 * c5 + a12 * c2 - a13 * c1) * id;
+        i2 = (a10 * c4 - a11 * c2 + a13 * c0) * id;   i3 = (-a10 * c3 + a11 * c1 - a12 * c0) * id;
+    } else if (c == 1) {
+        i0 = (-a01 * c5 + a02 * c4 - a03 * c3) * id;  i1 = (a00 * c5 - a02 * c2 + a03 * c1) * id;
+        i2 = (-a00 * c4 + a01 * c2 - a03 * c0) * id;  i3 = (a00 * c3 - a01 * c1 + a02 * c0) * id;
+    } else if (c == 2) {
+        i0 = (a31 * s5 - a32 * s4 + a33 * s3) * id;   i1 = (-a30 * s5 + a32 * s2 - a33 * s1) * id;
+        i2 = (a30 * s4 - a31 * s2 + a33 * s0) * id;   i3 = (-a30 * s3 + a31 * s1 - a32 * s0) * id;
+    } else {
+        i0 = (-a21 * s5 + a22 * s4 - a23 * s3) * id;  i1 = (a20 * s5 - a22 * s2 + a23 * s1) * id;
+        i2 = (-a20 * s4 + a21 * s2 - a23 * s0) * id;  i3 = (a20 * s3 - a21 * s1 + a22 * s0) * id;
     }
-    __syncthreads();
-    if (t < 16) {
-        const int r = t >> 2, c = t & 3;
-        rel_out[t] = c2w[r * 4] * inv[c] + c2w[r * 4 + 1] * inv[4 + c] + c2w[r * 4 + 2] * inv[8 + c] + c2w[r * 4 + 3] * inv[12 + c];
-    }
+    const int r4 = t & 12;
+    const float r0 = __shfl(cv, r4), r1 = __shfl(cv, r4 + 1), r2 = __shfl(cv, r4 + 2), r3 = __shfl(cv, r4 + 3);
+    if (threadIdx.x < 16) rel_out[t] = r0 * i0 + r1 * i1 + r2 * i2 + r3 * i3;
 }
 
 struct RbaW {

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, RENDER_WAVES) void render_rays_kernel(FieldK f
             Enc e;
             encode_point(f, x, e);
             Mlp m;
-            mlp_forward_123<false, POS16>(f, x, wl, lane, e, m);
+            mlp_forward_123<0, false, POS16>(f, x, wl, lane, e, m);
             float raw[4];
             mlp_forward_4(wl, lane, e, m, raw);
             rv[c] = make_float4(raw[0], raw[1], raw[2], raw[3]);

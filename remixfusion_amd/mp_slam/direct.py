@@ -258,7 +258,11 @@ class DirectIterations:
         check(lib.rfx_ray_points(p.o, p.d, p.z, n, S, model._bbox6, model._bbox_f64, p.x01, st), "rfx_ray_points")
         desc = model._field_desc(clamp)
         dref = C.byref(desc)
-        check(lib.rfx_field_forward(dref, p.x01, n * S, p.raw, st), "rfx_field_forward")
+        # the forward leaves its hash features in the backward workspace; the chain below reads them instead of looking
+        # the table up again (nothing else touches the workspace or the table in between)
+        ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
+        wsp, wb = ws.data_ptr(), ws.numel() * 4
+        check(lib.rfx_field_forward_stash(dref, p.x01, n * S, p.raw, wsp, wb, st), "rfx_field_forward_stash")
         trunc, sc = float(tr["trunc"]), float(cfg["data"]["sc_factor"])
         check(lib.rfx_composite_forward(p.raw, p.z, n, S, trunc, sc, p.rgb_map, p.depth_map, None, st), "rfx_composite_forward")
         depth_trunc, rgb_on = float(cfg["cam"]["depth_trunc"]), int(tr["rgb_missing"] > 0)
@@ -279,10 +283,8 @@ class DirectIterations:
         wvec = model._loss_weights(dev)
         check(lib.rfx_mapping_loss_backward(p.raw, p.z, p.rgb_map, p.depth_map, p.tgt, p.td, n, S, trunc, sc, trunc * sc, depth_trunc,
                                             rgb_on, p.lc + 16, wvec.data_ptr(), None, None, p.d_raw, st), "rfx_mapping_loss_backward")
-        ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
-        wsp, wb = ws.data_ptr(), ws.numel() * 4
-        chain = (lib.rfx_field_backward_chain_inputs if not map_grads else
-                 lib.rfx_field_backward_chain if want_ray_grads else lib.rfx_field_backward_chain_weights)
+        chain = (lib.rfx_field_backward_chain_inputs_stashed if not map_grads else
+                 lib.rfx_field_backward_chain_stashed if want_ray_grads else lib.rfx_field_backward_chain_weights_stashed)
         check(chain(dref, p.x01, n * S, p.d_raw, wsp, wb, st), "rfx_field_backward_chain")
         if map_grads:
             t.dt.zero_()

@@ -82,7 +82,9 @@ class ShardedIterations(DirectIterations):
             sd = model._sampler_desc()
             check(lib.rfx_sample_z(C.byref(sd), p.td, p.u if tr["perturb"] > 0.0 else None, n_loc, p.z, st), "rfx_sample_z")
             check(lib.rfx_ray_points(p.o, p.d, p.z, n_loc, S, model._bbox6, model._bbox_f64, p.x01, st), "rfx_ray_points")
-            check(lib.rfx_field_forward(dref, p.x01, n_loc * S, p.raw, st), "rfx_field_forward")
+            ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n_loc * S), dev)
+            wsp, wb = ws.data_ptr(), ws.numel() * 4
+            check(lib.rfx_field_forward_stash(dref, p.x01, n_loc * S, p.raw, wsp, wb, st), "rfx_field_forward_stash")   # see direct.py
             check(lib.rfx_composite_forward(p.raw, p.z, n_loc, S, trunc, sc, p.rgb_map, p.depth_map, None, st), "rfx_composite_forward")
         # ---- loss of the WHOLE batch: local sums -> all-reduce -> finalize
         if self._tot8 is None or self._tot8.device != dev:
@@ -110,10 +112,8 @@ class ShardedIterations(DirectIterations):
             check(lib.rfx_mapping_loss_backward(p.raw, p.z, p.rgb_map, p.depth_map, p.tgt, p.td, n_loc, S, trunc, sc, trunc * sc,
                                                 depth_trunc, rgb_on, p.lc + 16, wvec.data_ptr(), None, None, p.d_raw, st),
                   "rfx_mapping_loss_backward")
-            ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n_loc * S), dev)
-            wsp, wb = ws.data_ptr(), ws.numel() * 4
-            chain = (lib.rfx_field_backward_chain_inputs if not map_grads else
-                     lib.rfx_field_backward_chain if want_pose_grads else lib.rfx_field_backward_chain_weights)
+            chain = (lib.rfx_field_backward_chain_inputs_stashed if not map_grads else
+                     lib.rfx_field_backward_chain_stashed if want_pose_grads else lib.rfx_field_backward_chain_weights_stashed)
             check(chain(dref, p.x01, n_loc * S, p.d_raw, wsp, wb, st), "rfx_field_backward_chain")
             if map_grads:
                 dws = p.dws

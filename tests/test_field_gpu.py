@@ -543,6 +543,66 @@ def test_prestaged_weight_image_equals_in_kernel_staging():
     assert torch.equal(after, raw)
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+def test_stashed_forward_and_chains_are_bit_identical_to_the_recomputing_ones(fp16):
+    """rfx_field_forward_stash leaves the hash features in the workspace and the three _stashed chains read them instead
+    of looking the table up again: same raw, same dW, same dx01 (bit for bit), same d_hash (atomic order aside)."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    cfg, m = _model(hash_scale=0.5)
+    m.embedpos_fn.fp16 = fp16
+    n = 9001                                       # ragged last tile of 64
+    x = _points(n, seed=6, lo=0.02, hi=0.98).cuda().contiguous()
+    draw = torch.randn((n, 4), generator=torch.Generator().manual_seed(12)).cuda().contiguous()
+    desc = m._field_desc(False)
+    assert bool(desc.pos_fp16) == fp16
+    st = L.stream_ptr(x.device)
+    nbytes = int(lib.rfx_field_backward_workspace_bytes(n))
+    table = m.embed_res_fn.params
+
+    def run(chain, stashed, want_w, want_hash, want_dx):
+        ws = torch.full((nbytes // 4 + 16,), float("nan"), device="cuda")
+        wsp = (ws.data_ptr() + 15) // 16 * 16
+        raw = torch.empty((n, 4), device="cuda")
+        if stashed:
+            L.check(lib.rfx_field_forward_stash(C.byref(desc), L.ptr(x), n, L.ptr(raw), wsp, nbytes, st), "forward_stash")
+        else:
+            L.check(lib.rfx_field_forward(C.byref(desc), L.ptr(x), n, L.ptr(raw), st), "forward")
+        dws = [torch.zeros_like(w) for w in m.decoder_res.fused_weights()]
+        d_hash, dx = torch.zeros_like(table), torch.zeros((n, 3), device="cuda")
+        L.check(chain(C.byref(desc), L.ptr(x), n, L.ptr(draw), wsp, nbytes, st), "chain")
+        if want_w:
+            L.check(lib.rfx_field_backward_weights(n, L.ptr(draw), *[L.ptr(g) for g in dws], wsp, nbytes, st), "weights")
+        if want_hash or want_dx:
+            L.check(lib.rfx_field_backward_scatter(C.byref(desc), L.ptr(x), n, L.ptr(d_hash) if want_hash else None,
+                                                   L.ptr(dx) if want_dx else None, wsp, nbytes, st), "scatter")
+        if want_dx:
+            L.check(lib.rfx_field_backward_dx(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(dx), wsp, nbytes, st), "dx")
+        torch.cuda.synchronize()
+        return raw, dws, d_hash, dx
+
+    for plain, stash, w, h, d in ((lib.rfx_field_backward_chain, lib.rfx_field_backward_chain_stashed, True, True, True),
+                                  (lib.rfx_field_backward_chain_weights, lib.rfx_field_backward_chain_weights_stashed, True, True, False),
+                                  (lib.rfx_field_backward_chain_inputs, lib.rfx_field_backward_chain_inputs_stashed, False, False, True)):
+        r0, w0, h0, x0 = run(plain, False, w, h, d)
+        r1, w1, h1, x1 = run(stash, True, w, h, d)
+        assert torch.equal(r0, r1) and bool(torch.isfinite(r1).all())
+        for a, b in zip(w0, w1):
+            assert torch.equal(a, b) and bool(torch.isfinite(b).all())
+        if w:
+            assert float(w1[0].abs().max()) > 0
+        assert bool(torch.isfinite(h1).all()) and float((h0 - h1).abs().max()) <= 1e-5 * max(float(h0.abs().max()), 1e-30)
+        assert torch.equal(x0, x1) and bool(torch.isfinite(x1).all())
+        if d:
+            assert float(x1.abs().max()) > 0
+    # a workspace that is too small or misaligned is refused, like everywhere else
+    raw = torch.empty((n, 4), device="cuda")
+    ws = torch.empty(nbytes // 4 + 16, device="cuda")
+    assert lib.rfx_field_forward_stash(C.byref(desc), L.ptr(x), n, L.ptr(raw), ws.data_ptr(), nbytes - 16, st) == -4
+    assert lib.rfx_field_forward_stash(C.byref(desc), L.ptr(x), n, L.ptr(raw), None, nbytes, st) == -4
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_backward_chain_variants_agree_with_the_full_chain(clamp):
     """rfx_field_backward_chain_weights (map phase: rows + d_emb) and rfx_field_backward_chain_inputs (pose phase: dX1

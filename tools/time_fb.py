@@ -27,7 +27,10 @@ for n_rays in (int(a) for a in (sys.argv[1:] or ["2048", "2222", "2307"])):
                      ("chain", lambda: lib.rfx_field_backward_chain(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st)),
                      ("chain_weights", lambda: lib.rfx_field_backward_chain_weights(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st)),
                      ("dW", lambda: lib.rfx_field_backward_weights(n, L.ptr(draw), L.ptr(dw), L.ptr(dw) + 4 * 2592, L.ptr(dw) + 4 * 3104, L.ptr(dw) + 4 * 5216, L.ptr(ws), ws.numel() * 4, st)),
-                     ("chain_inputs", lambda: lib.rfx_field_backward_chain_inputs(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st))):
+                     ("chain_inputs", lambda: lib.rfx_field_backward_chain_inputs(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st)),
+                     ("fwd_stash", lambda: lib.rfx_field_forward_stash(C.byref(desc), L.ptr(x), n, L.ptr(raw), L.ptr(ws), ws.numel() * 4, st)),
+                     ("chain_w_st", lambda: lib.rfx_field_backward_chain_weights_stashed(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st)),
+                     ("chain_in_st", lambda: lib.rfx_field_backward_chain_inputs_stashed(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(ws), ws.numel() * 4, st))):
         for _ in range(3): fn()
         evs = []
         for _ in range(30):

@@ -7,7 +7,7 @@ c = sqlite3.connect(sys.argv[1]); skip = int(sys.argv[2]) if len(sys.argv) > 2 e
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]; ks = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(c.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-v1 = [i for i, r in enumerate(rows) if 'mv_integrate_kernel' in r[0]]
+v1 = [i for i, r in enumerate(rows) if 'mv_rows_kernel' in r[0]]
 i0, i1 = v1[skip], v1[-1]
 frames = len(v1) - 1 - skip
 win = rows[i0:i1]
