@@ -485,7 +485,8 @@ def main():
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
         pmc, tag = pmc_all.get("kernels", {}), pmc_all.get("measured_at_commit", "unknown")
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
-                        ("field_forward", ("rfx::field_forward_kernel<false>",)), ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false>",)),
+                        ("field_forward", ("rfx::field_forward_kernel<false, true>",)),
+                        ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false, true>",)),
                         ("field_backward_weights", ("rfx::field_dw_recompute_kernel", "rfx::field_dw_reduce_kernel")),
                         ("render_rays", ("rfx::render_rays_kernel<false>",)),
                         ("tsdf_integrate", ("rfx::mv_chunks_kernel", "rfx::mv_rows_kernel", "rfx::mv_prepass_kernel"))):
