@@ -193,7 +193,19 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None) -> int:
+    """the HIP stream torch is currently issuing to on `device` (a torch.device, an index, or None = current device)"""
+    if _raw_stream is not None:          # same value as current_stream().cuda_stream without building a Stream object
+        if isinstance(device, torch.device):
+            idx = device.index
+        else:
+            idx = device
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return _raw_stream(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 

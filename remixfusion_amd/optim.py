@@ -18,7 +18,19 @@ class Adam(torch.optim.Adam):
     def __init__(self, params, **kw):
         kw.pop("fused", None)
         kw.pop("foreach", None)
+        self._views = {}                # parameter -> (its state's `step` tensor, numpy view of it)
         super().__init__(params, **kw)
+
+    def _patch_step_function(self) -> None:
+        # torch wraps Optimizer.step in a hook dispatcher + profiler range (~25 us per call, a quarter of a pose iteration's
+        # host time here).  step() below runs un-wrapped and hands over to the wrapped torch path itself whenever a step
+        # hook is registered, so hooks keep firing.
+        self._zero_grad_profile_name = f"Optimizer.zero_grad#{self.__class__.__name__}.zero_grad"
+
+    def _hooked(self) -> bool:
+        from torch.optim import optimizer as _o
+        return bool(self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
+                    or getattr(_o, "_global_optimizer_pre_hooks", None) or getattr(_o, "_global_optimizer_post_hooks", None))
 
     def _native(self) -> bool:
         for g in self.param_groups:
@@ -34,10 +46,18 @@ class Adam(torch.optim.Adam):
                     return False
         return True
 
-    @torch.no_grad()
     def step(self, closure=None):
+        if self._hooked():
+            return torch.optim.Optimizer.profile_hook_step(type(self)._step_impl)(self, closure)
+        out = self._step_impl(closure)
+        self._optimizer_step_code()
+        return out
+
+    @torch.no_grad()
+    def _step_impl(self, closure=None):
         if not self._native():
-            return super().step(closure)
+            torch_step = torch.optim.Adam.step             # un-wrapped: step() above has dealt with the hooks already
+            return getattr(torch_step, "__wrapped__", torch_step)(self, closure)
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -54,10 +74,16 @@ class Adam(torch.optim.Adam):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)         # host counter, like torch's default Adam
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if st["step"].is_cuda:                                           # state loaded from a fused-Adam checkpoint
-                    st["step"] = st["step"].cpu()
-                st["step"] += 1
-                k = float(st["step"])
+                # `step` stays the host tensor torch's Adam keeps, but is bumped through a numpy view of it: a CPU-tensor
+                # `+= 1` costs ~7 us per parameter, which added up to more host time than the launch itself
+                stp = st["step"]
+                ent = self._views.get(p)
+                if ent is None or ent[0] is not stp:                             # fresh state, or one loaded from a checkpoint
+                    if stp.is_cuda or stp.dtype != torch.float32:                # (e.g. saved by a fused / capturable Adam)
+                        stp = st["step"] = stp.detach().to("cpu", torch.float32)
+                    ent = self._views[p] = (stp, stp.numpy())
+                k = int(ent[1].item()) + 1
+                ent[1][...] = k
                 bc1, bc2 = 1.0 - b1 ** k, 1.0 - b2 ** k
                 t = _lib.AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                                     b1, b2, 1.0 - b1, 1.0 - b2, g["eps"], g["weight_decay"], -(g["lr"] / bc1), math.sqrt(bc2))
@@ -67,6 +93,9 @@ class Adam(torch.optim.Adam):
             for i in range(0, len(ts), _lib.ADAM_MAX_TENSORS):
                 part = ts[i:i + _lib.ADAM_MAX_TENSORS]
                 arr = (_lib.AdamTensor * len(part))(*part)
-                with torch.cuda.device(dev):
+                if torch.cuda.current_device() == dev.index:
                     _lib.check(lib.rfx_adam_step(arr, len(part), stream), "rfx_adam_step")
+                else:
+                    with torch.cuda.device(dev):
+                        _lib.check(lib.rfx_adam_step(arr, len(part), stream), "rfx_adam_step")
         return loss
