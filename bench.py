@@ -58,6 +58,9 @@ def parse():
                     help="opt in to OneBlob outputs rounded to fp16 on the fp16 matrix pipe (NOT the reference's precision, which "
                          "is fp32: model/encodings.py:73); reported in dtype/config")
     ap.add_argument("--no-one-scene", action="store_true", help="N>1: skip the strong-scaling run of ONE sharded scene")
+    ap.add_argument("--stagewise-every", type=int, default=-1,
+                    help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
+                         "default: about three such iterations in the timed region, spaced so that both phases are sampled)")
     ap.add_argument("--unused-gradients", action="store_true",
                     help="pose iterations also compute the map gradients the reference's backward produces and then zeroes "
                          "(mapping.unused_gradients); results are the same, only slower")
@@ -289,7 +292,13 @@ def main():
     # stage by stage instead (same kernels, same order) so that the HIP events of KernelTimer see the individual calls.
     direct = pipe.mapper._direct_iterations() if pipe.mapper is not None else None
     if direct is not None:
-        direct.stagewise_every = 8
+        # An instrumented iteration costs ~0.15 ms more than the one-call form (a score of Python-level calls, event records
+        # and the wait for V1's stream), so only about three of them fall into the timed region: the spacing is a third of the
+        # region's iterations (2 per frame), made = 3 mod 10, which walks through the 5 map + 5 pose phases of the mapper's
+        # schedule so that any three consecutive samples contain both a map and a pose iteration.
+        n_it = 2 * args.steps
+        auto = (n_it // 3) // 10 * 10 + 3 if n_it >= 39 else max(1, n_it // 3)
+        direct.stagewise_every = auto if args.stagewise_every < 0 else args.stagewise_every
         direct.before_stagewise = pipe.sync_volume      # time the entry points without V1 running on the other stream
         timer.every = 1
     for i in range(1, 1 + args.warmup):

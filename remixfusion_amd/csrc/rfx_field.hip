@@ -1451,12 +1451,14 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
         {field_backward_kernel<true, true, true, false>, field_backward_kernel<true, false, true, false>, field_backward_kernel<true, true, false, false>},
         {field_backward_kernel<false, true, true, true>, field_backward_kernel<false, false, true, true>, field_backward_kernel<false, true, false, true>},
         {field_backward_kernel<true, true, true, true>, field_backward_kernel<true, false, true, true>, field_backward_kernel<true, true, false, true>}};
-    static bool attr_set = false;   // raising the dynamic-LDS limit is idempotent; benign if raced
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device; raising the dynamic-LDS limit is idempotent, so a race is benign
+    int dev = 0;
+    RFX_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         for (int a = 0; a < 4; ++a)
             for (int v = 0; v < 3; ++v)
                 RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern[a][v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int variant = rows ? (dxfull ? 0 : 2) : 1;
     hipLaunchKernelGGL(kern[(k.pos_fp16 ? 1 : 0) + (stashed ? 2 : 0)][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
