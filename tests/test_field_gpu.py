@@ -194,7 +194,8 @@ def test_point_queries_match_oracle():
     _close(emb.reshape(-1, 32), FO.query_sdf_res(fp, x, embed=True), 1e-5, 1e-6, "embed=True")
 
 
-@pytest.mark.parametrize("clamp,n", [(False, 3001), (True, 3001), (True, 9001)])    # n >= 4096: LDS-privatised scatter
+# n >= 4096: LDS-privatised scatter; 7, 33, 65, 129: ragged 32-point batches / 64-point tiles of the staged rows
+@pytest.mark.parametrize("clamp,n", [(False, 3001), (True, 3001), (True, 9001), (False, 7), (True, 33), (False, 65), (True, 129)])
 def test_field_backward_matches_autograd_of_oracle(clamp, n):
     cfg, m = _model(hash_scale=0.5)
     cfg["mapping"]["clamp"] = 1.5
@@ -223,7 +224,8 @@ def test_field_backward_matches_autograd_of_oracle(clamp, n):
                               (w3.grad, fp.W3.grad, fq.W3.grad, "dW3"), (w4.grad, fp.W4.grad, fq.W4.grad, "dW4")):
         _grad_close(got, r32, r64, nm)
     _grad_close(m.embed_res_fn.params.grad, fp.hash_table.grad, fq.hash_table.grad, "d_hash", _level_groups(fp.hash_meta))
-    assert float((m.embed_res_fn.params.grad != 0).float().mean()) > 0.01
+    if n >= 1000:
+        assert float((m.embed_res_fn.params.grad != 0).float().mean()) > 0.01
     _grad_close(xg.grad, xo.grad, xq.grad, "dx01", k=8.0)
     assert m.GBV.params.grad is None
 
