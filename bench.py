@@ -58,6 +58,7 @@ def parse():
                     help="opt in to OneBlob outputs rounded to fp16 on the fp16 matrix pipe (NOT the reference's precision, which "
                          "is fp32: model/encodings.py:73); reported in dtype/config")
     ap.add_argument("--no-one-scene", action="store_true", help="N>1: skip the strong-scaling run of ONE sharded scene")
+    ap.add_argument("--one-scene-timeout", type=float, default=300.0, help="N>1: seconds the strong-scaling run may take")
     ap.add_argument("--stagewise-every", type=int, default=-1,
                     help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
                          "default: about three such iterations in the timed region, spaced so that both phases are sampled)")
@@ -208,6 +209,30 @@ def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
                          "batches shared out, all-reduce of 64 B of loss sums and of the gradients per iteration",
             "collectives_per_frame": "broadcast 16*H*W B (depth + rgb); per BA iteration all-reduce 64 B + gradients "
                                      f"({int(pipe.model.embed_res_fn.params.numel() * 4 / 1e6 * 10) / 10} MB hash table, 21 KB decoder)"}
+
+
+def guarded_one_scene(args, cfg, dist, rank, world, device, n_frames, out):
+    """run_one_scene under a watchdog thread.  A stalled collective cannot be interrupted from Python, so on a timeout the
+    thread itself prints rank 0's line (`out`, with the reason under "one_scene") and ends the process; an exception on
+    this rank is reported the same way (the other ranks then run into their own watchdogs)."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(args.one_scene_timeout):
+            return
+        if out is not None:
+            out["one_scene"] = {"error": f"did not finish within {args.one_scene_timeout} s; the weak-scaling figures of this line are unaffected"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = run_one_scene(args, cfg, dist, rank, world, device, n_frames)
+    except Exception as e:          # noqa: BLE001 -- reported in the JSON line
+        res = {"error": f"{type(e).__name__}: {e}"[:400]}
+    done.set()
+    return res
 
 
 def main():
@@ -362,12 +387,15 @@ def main():
         render = rays_d.shape[0] * args.render_frames / (time.perf_counter() - t1)
         timer.enabled = False
 
-    # ---- N > 1: ONE scene over the N GPUs (strong scaling): same stream, same schedule as the N = 1 workload
+    # ---- N > 1: ONE scene over the N GPUs (strong scaling): same stream, same schedule as the N = 1 workload.  It runs
+    # LAST and under a watchdog (guarded_one_scene): if its collectives ever stall, the weak-scaling line assembled below
+    # is still printed.  Ranks other than 0 go straight into it and wait there for rank 0.
     one_scene = None
-    if dist is not None and not args.no_one_scene:
-        one_scene = run_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames)
+    want_one_scene = dist is not None and not args.no_one_scene
 
     if rank != 0:
+        if want_one_scene:
+            guarded_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames, None)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -516,7 +544,7 @@ def main():
         roofline = next(iter(extra_rooflines.values()))
 
     base = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the host baseline is reported at N = 1 only
         m = cfg["mapping"]
         n_rays = m["sample"] + max(m["sample"] // 8, m["min_pixels_cur"])
         tv_pts = (tr["smooth_pts"] - 1) ** 3
@@ -542,9 +570,9 @@ def main():
         "iterations_timed": iters,
         "cpu_baseline": base,
     }
-    if one_scene is not None:
-        out["one_scene"] = one_scene
-    print(json.dumps(out))
+    if want_one_scene:
+        out["one_scene"] = guarded_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames, out)
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
