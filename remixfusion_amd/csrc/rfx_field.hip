@@ -121,13 +121,15 @@ __global__ __launch_bounds__(256) void grid_encode_forward_lp_kernel(rfx_grid_de
 __global__ __launch_bounds__(256) void grid_encode_dx_lp_kernel(rfx_grid_desc g, const float* __restrict__ table,
                                                                 const float* __restrict__ x01, int64_t n,
                                                                 const float* __restrict__ dfeat, int ld, int lp_shift,
-                                                                float* __restrict__ dx01) {
+                                                                float* __restrict__ dx01, const int* __restrict__ perm,
+                                                                const int* __restrict__ n_sel) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = gid >> lp_shift;
     const int l = (int)(gid & ((1 << lp_shift) - 1));
+    const int64_t px = (perm && p < n) ? perm[p] : p;          // dfeat row p belongs to point px
     float dx[3] = {0.f, 0.f, 0.f};
-    if (p < n && l < g.n_levels) {
-        const float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
+    if (p < n && (!n_sel || p < *n_sel) && l < g.n_levels) {
+        const float x[3] = {x01[px * 3], x01[px * 3 + 1], x01[px * 3 + 2]};
         const float2 gv = reinterpret_cast<const float2*>(dfeat + p * (int64_t)ld)[l];
         const float gg[2] = {gv.x, gv.y};
         lookup_dx<2>(table, get_level(g, l), x, gg, dx);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void grid_encode_dx_lp_kernel(rfx_grid_desc g,
     for (int o = 1; o < (1 << lp_shift); o <<= 1) {          // whole waves reach this (no early return above)
         dx[0] += __shfl_xor(dx[0], o); dx[1] += __shfl_xor(dx[1], o); dx[2] += __shfl_xor(dx[2], o);
     }
-    if (p < n && l == 0) { dx01[p * 3] = dx[0]; dx01[p * 3 + 1] = dx[1]; dx01[p * 3 + 2] = dx[2]; }
+    if (p < n && l == 0) { dx01[px * 3] = dx[0]; dx01[px * 3 + 1] = dx[1]; dx01[px * 3 + 2] = dx[2]; }    // zeros past n_sel
 }
 
 static inline int lp_shift_of(int n_levels) {
@@ -145,11 +147,11 @@ static inline int lp_shift_of(int n_levels) {
 }
 
 static void launch_encode_dx(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat, int ld,
-                             float* dx01, hipStream_t st) {
+                             float* dx01, hipStream_t st, const int* perm = nullptr, const int* n_sel = nullptr) {
     const int sh = lp_shift_of(g.n_levels);
     const int64_t threads = n << sh;
     hipLaunchKernelGGL(grid_encode_dx_lp_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, g, table, x01, n, dfeat, ld,
-                       sh, dx01);
+                       sh, dx01, perm, n_sel);
 }
 
 // dfeat rows have stride `ld` floats (>= L*F) so that the field backward can point it at its workspace.
@@ -163,12 +165,14 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
                                                                    const float* __restrict__ x01, int64_t n,
                                                                    const float* __restrict__ dfeat, int ld,
                                                                    float* __restrict__ dtable, float* __restrict__ dx01,
-                                                                   int dx_accumulate) {
+                                                                   int dx_accumulate, const int* __restrict__ perm = nullptr,
+                                                                   const int* __restrict__ n_sel = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = p < n;                       // whole waves stay alive for the shuffles
+    const bool valid = p < n && (!n_sel || p < *n_sel);        // whole waves stay alive for the shuffles
+    const int64_t px = (perm && p < n) ? perm[p] : p;          // dfeat row p belongs to point px
     float x[3] = {0.5f, 0.5f, 0.5f};
-    if (valid) { x[0] = x01[p * 3]; x[1] = x01[p * 3 + 1]; x[2] = x01[p * 3 + 2]; }
+    if (valid) { x[0] = x01[px * 3]; x[1] = x01[px * 3 + 1]; x[2] = x01[px * 3 + 2]; }
     const float* gr = dfeat + (valid ? p : 0) * (int64_t)ld;
     float dx[3] = {0.f, 0.f, 0.f};
     for (int l = 0; l < g.n_levels; ++l) {
@@ -208,9 +212,9 @@ __global__ __launch_bounds__(256) void grid_encode_backward_kernel(rfx_grid_desc
             lookup_dx<2>(table, lv, x, gg, dx);
         }
     }
-    if (dx01 && valid) {
-        if (dx_accumulate) { dx01[p * 3] += dx[0]; dx01[p * 3 + 1] += dx[1]; dx01[p * 3 + 2] += dx[2]; }
-        else { dx01[p * 3] = dx[0]; dx01[p * 3 + 1] = dx[1]; dx01[p * 3 + 2] = dx[2]; }
+    if (dx01 && p < n) {            // rows past n_sel belong to points without a gradient: they get zeros
+        if (dx_accumulate) { dx01[px * 3] += dx[0]; dx01[px * 3 + 1] += dx[1]; dx01[px * 3 + 2] += dx[2]; }
+        else { dx01[px * 3] = dx[0]; dx01[px * 3 + 1] = dx[1]; dx01[px * 3 + 2] = dx[2]; }
     }
 }
 
@@ -249,7 +253,21 @@ struct ScatterPlan {
     int chunks;          // slices of the point list
     int K;               // points per thread and chunk; a chunk covers K * SCATTER_THREADS points
     int64_t slots;       // chunks * K * SCATTER_THREADS
+    // The first source may be shorter on the device than on the host (the field backward puts the points with a non-zero
+    // loss gradient first and counts them, n_sel): the kernels then deal out min(n_a, *n_sel) points, K_eff <= K per thread.
+    int64_t n_a, n_b;
+    const int* n_sel;
 };
+
+struct ScatterShare { int64_t n_a, per_a, per_b; int K; };
+__device__ __forceinline__ ScatterShare scatter_share(const ScatterPlan& p) {
+    ScatterShare s;
+    s.n_a = p.n_sel ? min(p.n_a, (int64_t)*p.n_sel) : p.n_a;
+    s.per_a = (s.n_a + p.chunks - 1) / p.chunks;
+    s.per_b = (p.n_b + p.chunks - 1) / p.chunks;
+    s.K = (int)((s.per_a + s.per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
+    return s;
+}
 
 // How many slices to cut the point list into.  One block per CU (128 KB of LDS), so the launch runs in
 // ceil(segments * chunks / 256) rounds of blocks that each cost (points / chunks) * t_point + t_fixed (zeroing and
@@ -289,22 +307,27 @@ __device__ __forceinline__ unsigned lds_slot(unsigned r, unsigned pm) { return r
 // that one sweep over the table segments serves both.
 struct ScatterSrc {
     const float* dfeat; int ld; const float* x01; int64_t n;
+    const int* perm;          // row p of dfeat belongs to point perm[p] of x01 (null: p)
+    const int* n_sel;         // device-side row count, <= n (null: n)
 };
 
-__global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, ScatterSrc b, int64_t per_a, int64_t per_b, int n_levels,
-                                                            int K, int64_t slots, float* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, ScatterSrc b, ScatterPlan plan, int n_levels,
+                                                            float* __restrict__ scratch) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slots = plan.slots;
     if (s >= slots) return;
-    const int64_t per = (int64_t)K * SCATTER_THREADS;
+    const ScatterShare sh = scatter_share(plan);
+    const int64_t per = (int64_t)plan.K * SCATTER_THREADS;
     const int64_t c = s / per, r = s % per;
-    const int64_t j = (r % SCATTER_THREADS) * K + r / SCATTER_THREADS;      // point j of chunk c
+    if (r / SCATTER_THREADS >= sh.K) return;                                // iterations the sweep never reads
+    const int64_t j = (r % SCATTER_THREADS) * sh.K + r / SCATTER_THREADS;   // point j of chunk c
     // every chunk takes an equal share of BOTH sources (a lattice dumped into one chunk would make that
     // chunk's blocks the tail of the launch: its points collide on the coarse levels)
-    const bool in_a = j < per_a;
+    const bool in_a = j < sh.per_a;
     const ScatterSrc src = in_a ? a : b;
-    const int64_t jj = in_a ? j : j - per_a;
-    const int64_t p = c * (in_a ? per_a : per_b) + jj;
-    const bool live = jj < (in_a ? per_a : per_b) && p < src.n;
+    const int64_t jj = in_a ? j : j - sh.per_a;
+    const int64_t p = c * (in_a ? sh.per_a : sh.per_b) + jj;
+    const bool live = jj < (in_a ? sh.per_a : sh.per_b) && p < (in_a ? sh.n_a : b.n);
     float2* __restrict__ planes = reinterpret_cast<float2*>(scratch);
     float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
     if (live) {
@@ -323,7 +346,8 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
             const float2* __restrict__ row = reinterpret_cast<const float2*>(rowf);
             for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
         }
-        xs[s] = src.x01[p * 3]; xs[slots + s] = src.x01[p * 3 + 1]; xs[2 * slots + s] = src.x01[p * 3 + 2];
+        const int64_t px = src.perm ? src.perm[p] : p;
+        xs[s] = src.x01[px * 3]; xs[slots + s] = src.x01[px * 3 + 1]; xs[2 * slots + s] = src.x01[px * 3 + 2];
     } else {
         for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
         xs[s] = 0.5f; xs[slots + s] = 0.5f; xs[2 * slots + s] = 0.5f;
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
     const float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
     int64_t s = (int64_t)chunk * plan.K * SCATTER_THREADS + threadIdx.x;
+    const int K_eff = scatter_share(plan).K;         // <= plan.K (the slot stride): see ScatterPlan
 
     Cell cur;                       // cell of the running register accumulation
     bool open = false;
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     auto fetch = [&](int i0) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const bool live = i0 + j < plan.K;
+            const bool live = i0 + j < K_eff;
             const int64_t sj = s + (int64_t)j * SCATTER_THREADS;
             gv_n[j] = live ? gvp[sj] : make_float2(0.f, 0.f);
             xn[j][0] = live ? xs[sj] : 0.5f; xn[j][1] = live ? xs[slots + sj] : 0.5f; xn[j][2] = live ? xs[2 * slots + sj] : 0.5f;
@@ -390,12 +415,12 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
         s += (int64_t)NB * SCATTER_THREADS;
     };
     fetch(0);
-    for (int i = 0; i < plan.K; i += NB) {
+    for (int i = 0; i < K_eff; i += NB) {
         float2 gvb[NB];
         float xb[NB][3];
 #pragma unroll
         for (int j = 0; j < NB; ++j) { gvb[j] = gv_n[j]; xb[j][0] = xn[j][0]; xb[j][1] = xn[j][1]; xb[j][2] = xn[j][2]; }
-        if (i + NB < plan.K) fetch(i + NB);
+        if (i + NB < K_eff) fetch(i + NB);
         if (lv.hashed && lv.size >= (sizeof(ACC) == 8 ? 8u : 16u) * SEG) {
             // hashed level cut into many segments (>= 16 with float accumulators, >= 8 with double ones, whose atomics are
             // cheap enough that merging runs in registers no longer pays): nearly every corner falls into another
@@ -483,10 +508,12 @@ __device__ __forceinline__ bool bin_load(const ScatterSrc& a, const ScatterSrc& 
     const bool in_a = j < a.n;
     const ScatterSrc& s = in_a ? a : b;
     const int64_t p = in_a ? j : j - a.n;
-    if (p >= s.n) return false;
+    if (p >= s.n || (s.n_sel && p >= *s.n_sel)) return false;
     gv = reinterpret_cast<const float2*>(s.dfeat + p * (int64_t)s.ld)[level];
-    x[0] = s.x01[p * 3]; x[1] = s.x01[p * 3 + 1]; x[2] = s.x01[p * 3 + 2];
-    return gv.x != 0.f || gv.y != 0.f;
+    if (gv.x == 0.f && gv.y == 0.f) return false;
+    const int64_t px = s.perm ? s.perm[p] : p;
+    x[0] = s.x01[px * 3]; x[1] = s.x01[px * 3 + 1]; x[2] = s.x01[px * 3 + 2];
+    return true;
 }
 
 // LDS atomics to ONE address from all 64 lanes serialise (a dense level's neighbouring points fall into the same segment):
@@ -671,7 +698,8 @@ static int launch_binned_level(const rfx_grid_desc& g, int l, const ScatterSrc& 
 // LDS path is taken when the table is small enough to sweep segment by segment; otherwise direct atomics.
 static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
-                               const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0) {
+                               const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0, const int* perm = nullptr,
+                               const int* n_sel = nullptr) {
     ScatterPlan plan;
     const int64_t n_all = n + n_b;
     const bool staged_ok = scratch && n_all >= SCATTER_MIN_POINTS;
@@ -695,14 +723,15 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     if (!staged_ok || total > SCATTER_MAX_SEGMENTS) {
         if (n > 0)
             hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
-                               dfeat, ld, dtable, (float*)nullptr, 0);
+                               dfeat, ld, dtable, (float*)nullptr, 0, perm, n_sel);
         if (n_b > 0)
             hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, g, table, x01_b,
-                               n_b, dfeat_b, ld_b, dtable, (float*)nullptr, 0);
+                               n_b, dfeat_b, ld_b, dtable, (float*)nullptr, 0, (const int*)nullptr, (const int*)nullptr);
         RFX_LAUNCH_CHECK();
         return RFX_OK;
     }
-    const ScatterSrc a{dfeat, ld, x01, n}, b{dfeat_b, ld_b, x01_b, n_b};
+    const ScatterSrc a{dfeat, ld, x01, n, perm, n_sel}, b{dfeat_b, ld_b, x01_b, n_b, nullptr, nullptr};
+    plan.n_a = n; plan.n_b = n_b; plan.n_sel = n_sel;
     const size_t scratch_floats = scatter_scratch_floats(n_all, g.n_levels);
     if (total > 0) {
         scatter_shape(n_all, total, &plan.chunks, &plan.K);
@@ -710,8 +739,8 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
         plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
         plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
         if ((size_t)plan.slots * (2 * g.n_levels + 3) > scratch_floats) return RFX_ERR_WORKSPACE;
-        hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, per_a, per_b,
-                           g.n_levels, plan.K, plan.slots, scratch);
+        hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, plan, g.n_levels,
+                           scratch);
         RFX_LAUNCH_CHECK();
         const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
         static bool attr_set[64] = {};       // the attribute is per device
@@ -784,10 +813,23 @@ constexpr int DW_BLOCKS = 256;       // the weight-gradient kernel is persistent
 constexpr int DWR_OFF1 = 0, DWR_OFF2 = 41, DWR_OFF3 = 49, DWR_OFF4 = 82, DWR_SLOTS = 84;
 
 struct BwdWs {
-    float *emb, *x1, *g, *dy2, *dx1, *demb_t, *partial, *wcopy;
+    float *emb, *embc, *x1, *g, *dy2, *dx1, *demb_t, *partial, *wcopy;
+    int *perm, *sel_hdr, *sel_counts;
 };
 
-__host__ __device__ inline size_t ws_floats_per_point() { return 4 * (PC_EMB + PC_X1 + PC_G + PC_DY2) + LD_DX1; }
+// Selection (round 2): about 37 % of a mapping batch's sample points -- those behind the surface by more than the truncation
+// -- have an exactly zero loss gradient d_raw, and contribute exactly nothing to any gradient.  For launches of at least
+// SEL_MIN_POINTS the chain stage first builds a stable partition of the points (non-zero d_raw rows first) in the workspace:
+// perm[q] = point staged at row q, sel_hdr[0] = number of non-zero rows.  Every later stage works on the first sel_hdr[0]
+// rows (the count stays on the device: no host round trip), reads x01 / d_raw through perm and writes dx01 through it (zeros
+// for the rest).  Same sums as without it, up to the order of the additions.
+constexpr int64_t SEL_MIN_POINTS = 16384;
+constexpr int SEL_PPB = 1024;                  // points per block of the two selection kernels
+static inline bool sel_on(int64_t n) { return n >= SEL_MIN_POINTS; }
+struct Sel { const int* perm; const int* n_sel; };
+
+
+__host__ __device__ inline size_t ws_floats_per_point() { return 4 * (2 * PC_EMB + PC_X1 + PC_G + PC_DY2) + LD_DX1 + 1; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -795,13 +837,17 @@ static BwdWs carve(void* ws, int64_t n) {
     BwdWs w;
     float* p = reinterpret_cast<float*>(ws);
     const size_t np = align_up((size_t)n, 64);
-    w.emb = p; p += np * 4 * PC_EMB;
+    w.emb = p; p += np * 4 * PC_EMB;             // the forward's stash: rows in the caller's point order
+    w.embc = p; p += np * 4 * PC_EMB;            // the same rows in the chain's (selected) order, for the weight gradients
     w.x1 = p; p += np * 4 * PC_X1;
     w.g = p; p += np * 4 * PC_G;
     w.dy2 = p; p += np * 4 * PC_DY2;
     w.dx1 = p; p += np * LD_DX1;
     w.partial = p; p += (size_t)DW_BLOCKS * DW_TOTAL;
     w.wcopy = p; p += DWR_SLOTS * 64;                  // k-step images of W1..W4 as the chain saw them
+    w.perm = reinterpret_cast<int*>(p); p += np;
+    w.sel_hdr = reinterpret_cast<int*>(p); p += 16;
+    w.sel_counts = reinterpret_cast<int*>(p); p += align_up(np / SEL_PPB + 1, 4);
     w.demb_t = p;                                      // staged d_emb / points of the LDS scatter
     return w;
 }
@@ -840,6 +886,70 @@ __device__ __forceinline__ unsigned positive_mask(const f32x16& a, const f32x16&
     return m;
 }
 
+// ---------------------------------------------------------------- selection: points with a non-zero loss gradient first
+__device__ __forceinline__ bool sel_flag(const float* __restrict__ draw4, int64_t p, int64_t n) {
+    if (p >= n) return false;
+    const float4 d = reinterpret_cast<const float4*>(draw4)[p];
+    return d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f;
+}
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ draw4, int64_t n, int* __restrict__ counts) {
+    __shared__ int part[4];
+    const int64_t p0 = (int64_t)blockIdx.x * SEL_PPB;
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < SEL_PPB / 256; ++r) c += __popcll(__ballot(sel_flag(draw4, p0 + r * 256 + threadIdx.x, n)));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// stable partition: block b's non-zero points go to rows [sum of earlier blocks' counts, ...), its zero points to the rows
+// after all non-zero ones, both in point order (so the result does not depend on scheduling)
+__global__ __launch_bounds__(256) void sel_scatter_kernel(const float* __restrict__ draw4, int64_t n, const int* __restrict__ counts,
+                                                          int n_blocks, int* __restrict__ perm, int* __restrict__ hdr) {
+    __shared__ int red[2][4];
+    __shared__ int wave_cnt[SEL_PPB / 256][4];
+    int before = 0, total = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        const int c = counts[i];
+        total += c;
+        if (i < (int)blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = before; red[1][wv] = total; }
+    const int64_t p0 = (int64_t)blockIdx.x * SEL_PPB;
+    bool f[SEL_PPB / 256];
+    unsigned long long m[SEL_PPB / 256];
+#pragma unroll
+    for (int r = 0; r < SEL_PPB / 256; ++r) {
+        f[r] = sel_flag(draw4, p0 + r * 256 + threadIdx.x, n);
+        m[r] = __ballot(f[r]);
+        if (lane == 0) wave_cnt[r][wv] = __popcll(m[r]);
+    }
+    __syncthreads();
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = total;
+    int nz_run = before;                                         // non-zero rows placed so far (this block's share included)
+    int64_t seen = p0;                                           // points placed so far
+#pragma unroll
+    for (int r = 0; r < SEL_PPB / 256; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wv) {
+                const int64_t p = p0 + r * 256 + threadIdx.x;
+                const int rank = __popcll(m[r] & ((1ull << lane) - 1ull));
+                if (p < n) perm[f[r] ? nz_run + rank : total + (int)(seen - nz_run) + (lane - rank)] = (int)p;
+            }
+            nz_run += wave_cnt[r][w];
+            seen += 64;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward kernel A (MFMA chain)
 // ROWS: also stage what the weight-gradient kernel reads (X1, G, dY2; it recomputes H1, H3 and their gradients); without them
 // only dX1 is written, which is all the input-gradient stages (_scatter with dx01, _dx) need.
@@ -858,8 +968,8 @@ __device__ __forceinline__ float dwr_image(const float* __restrict__ w1, const f
 // STASHED: the hash features of these points are already in ws.emb (rfx_field_forward_stash ran on the same points, table and
 // workspace): the forward recompute skips its 128 gathers per point.
 template <bool POS16, bool ROWS, bool DXFULL, bool STASHED>
-__global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
-                                                             const float* __restrict__ draw4, BwdWs ws) {
+__global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f, const float* __restrict__ x01, int64_t n_all,
+                                                             const float* __restrict__ draw4, BwdWs ws, Sel sel) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     stage_weights(f, wl, ALL_SLOTS);
     if (ROWS && blockIdx.x == 0) {        // the weight-gradient kernel recomputes H1 / H3 from the staged inputs: it needs the weights
@@ -868,21 +978,26 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n = sel.n_sel ? (int64_t)*sel.n_sel : n_all;       // rows to process: the selected points (see Sel)
     for (int64_t base = wave * 64; base < n; base += n_waves * 64) {
-        const int64_t p = base + lane;
+        const int64_t p = base + lane;                                // row of the staged arrays
         const bool valid = p < n;
+        const int64_t src = sel.perm ? (int64_t)sel.perm[valid ? p : n - 1] : p;      // the point it holds
         float x[3];
-        load_point(x01, p, n, x);
-        float4 dr = valid ? reinterpret_cast<const float4*>(draw4)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        load_point(x01, src, valid ? n_all : 0, x);
+        float4 dr = valid ? reinterpret_cast<const float4*>(draw4)[src] : make_float4(0.f, 0.f, 0.f, 0.f);
 
         Enc e;
         encode_point(f, x, e);
         // ---- stage X1 = [emb | pos, cin] (inside the forward), piece-major: see the workspace layout
-        float* emb_row = ws.emb + (p >> 6) * (PC_EMB * ROW_PIECE) + (p & 63) * 4;
+        // the stash is in the caller's point order (src); what this kernel stages is in its own row order (p)
+        float* embc_row = ws.embc + (p >> 6) * (PC_EMB * ROW_PIECE) + (p & 63) * 4;
+        float* stash_row = ws.emb + (src >> 6) * (PC_EMB * ROW_PIECE) + (src & 63) * 4;
         float* x1row = ws.x1 + (p >> 6) * (PC_X1 * ROW_PIECE) + (p & 63) * 4;
         Mlp m;
-        mlp_forward_123<STASHED ? 2 : (ROWS ? 1 : 0), ROWS, POS16>(f, x, wl, lane, e, m, emb_row, x1row, valid);
-        if (ROWS && valid) st4(row_piece(x1row, 48), 0, e.cin, 0.f, 0.f, 0.f);
+        mlp_forward_123<STASHED ? 2 : (ROWS ? 1 : 0), ROWS, POS16>(f, x, wl, lane, e, m, STASHED ? stash_row : embc_row, x1row, valid,
+                                                                   (STASHED && ROWS) ? embc_row : nullptr);
+        if (ROWS && valid) st4(row_piece(x1row, 48), 0, e.cin, dr.x, dr.y, dr.z);      // [cin | dY4]: the weight gradients' inputs
         const unsigned mask1 = positive_mask(m.h1[0], m.h1[1]);
         const unsigned mask3 = positive_mask(m.h3[0], m.h3[1]);
         if (ROWS) {   // G = [geo15 | ex_rgb]: h2 rows 0..15 = (sdf, geo0..14)
@@ -1031,13 +1146,14 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
 // operand of each product is a lane = feature read of the batch image.
 //
 // One 32-point batch as this kernel keeps it in LDS, in 16-byte pieces, piece-major like the staged rows:
-//   X1 [21 pieces][33] | G [5][33] | dY2 [4][33] | dY4 [32]          (slot 32 of each piece is padding)
+//   X1 [21 pieces][33] | G [5][33] | dY2 [4][33]          (slot 32 of each piece is padding; X1 = emb 32 | pos 48 | cin, dY4)
 // lane = point reads (ds_read_b128, recompute phase) are consecutive pieces; lane = feature reads (ds_read_b32, dW phase)
 // step 33 * 4 floats per four lanes, i.e. 4 banks: both conflict-free.  The image is filled by LDS-DMA
 // (global_load_lds_dwordx4: the 64 pieces of one wave-instruction land at consecutive LDS addresses, each from its own
 // lane's source address -- 32 consecutive pieces of the staged tile, then the pad), 16 instructions per batch and no
 // VGPRs, one batch ahead of the arithmetic.
-constexpr int DWR_PX = 0, DWR_PG = (PC_EMB + PC_X1) * 33, DWR_PY = DWR_PG + PC_G * 33, DWR_PD = DWR_PY + PC_DY2 * 33, DWR_PIECES = DWR_PD + 32;
+constexpr int DWR_PX = 0, DWR_PG = (PC_EMB + PC_X1) * 33, DWR_PY = DWR_PG + PC_G * 33, DWR_PIECES = DWR_PY + PC_DY2 * 33;
+constexpr int DWR_COL_DY4 = 81;        // X1 image columns 81..83: the colour part of d_raw (the chain stages it next to cin)
 constexpr int DWR_BUF = 4096;                       // floats per staging buffer (16 wave-instructions x 1 KiB)
 constexpr size_t DWR_LDS = (size_t)(DWR_SLOTS * 64 + 4 * 2 * DWR_BUF) * sizeof(float);
 static_assert(DWR_PIECES <= 16 * 64 && 2 * DW_TOTAL <= 4 * 2 * DWR_BUF, "dW staging layout");
@@ -1046,21 +1162,20 @@ static_assert(DWR_PIECES <= 16 * 64 && 2 * DW_TOTAL <= 4 * 2 * DWR_BUF, "dW stag
 __device__ __forceinline__ int dwr_col(int sec, int col) { return (sec + (col >> 2) * 33) * 4 + (col & 3); }
 
 // pieces [half * 512, half * 512 + 512) of a batch image: each of the two waves that share a batch fetches half of it
-__device__ __forceinline__ void dwr_fetch(const BwdWs& ws, const float* __restrict__ draw4, int64_t p0, int64_t n, int lane,
-                                          float* buf, int half) {
+__device__ __forceinline__ void dwr_fetch(const BwdWs& ws, int64_t p0, int64_t n, int lane, float* buf, int half) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)buf + half * 8192);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = (half * 8 + i) * 64 + lane;
         int q, row, pcs;
         const float* base;
-        if (c < DWR_PG) { q = c / 33; row = c - 33 * q; base = q < PC_EMB ? ws.emb : ws.x1; pcs = q < PC_EMB ? PC_EMB : PC_X1; q -= q < PC_EMB ? 0 : PC_EMB; }
+        if (c < DWR_PG) { q = c / 33; row = c - 33 * q; base = q < PC_EMB ? ws.embc : ws.x1; pcs = q < PC_EMB ? PC_EMB : PC_X1; q -= q < PC_EMB ? 0 : PC_EMB; }
         else if (c < DWR_PY) { const int d = c - DWR_PG; q = d / 33; row = d - 33 * q; base = ws.g; pcs = PC_G; }
-        else if (c < DWR_PD) { const int d = c - DWR_PY; q = d / 33; row = d - 33 * q; base = ws.dy2; pcs = PC_DY2; }
-        else { q = -1; row = c < DWR_PIECES ? c - DWR_PD : 0; base = draw4; pcs = 0; }
+        else if (c < DWR_PIECES) { const int d = c - DWR_PY; q = d / 33; row = d - 33 * q; base = ws.dy2; pcs = PC_DY2; }
+        else { q = 0; row = 0; base = ws.dy2; pcs = PC_DY2; }        // past the image: any valid piece
         // the pad slot and a ragged last batch re-read a valid point (finite values; masked or dropped below)
         const int64_t pt = std::min<int64_t>(p0 + (row < 32 ? row : 0), n - 1);
-        const float* src = q < 0 ? base + pt * 4 : base + (pt >> 6) * (pcs * ROW_PIECE) + q * ROW_PIECE + (pt & 63) * 4;
+        const float* src = base + (pt >> 6) * (pcs * ROW_PIECE) + q * ROW_PIECE + (pt & 63) * 4;
         // as inline asm: behind the builtin hipcc drains the DMA (vmcnt(0)) at the next ds_read of any LDS address, which
         // would serialise the prefetch with the batch it is meant to overlap
         unsigned keep;
@@ -1102,9 +1217,9 @@ __device__ __forceinline__ void dwr_batch(const float* __restrict__ buf, const f
             hh = mfma32(h ? v.y : v.x, wl[(DWR_OFF3 + 24 + 2 * q) * 64 + lane], hh);
             if (q < 4) hh = mfma32(h ? v.w : v.z, wl[(DWR_OFF3 + 24 + 2 * q + 1) * 64 + lane], hh);
         }
-        float4 v = b4[DWR_PD + lo]; if (!vl) v = z4;                // T3 = dY4 . W4, 2
-        tt = mfma32(h ? v.y : v.x, wl[(DWR_OFF4 + 0) * 64 + lane], tt);
-        tt = mfma32(h ? 0.f : v.z, wl[(DWR_OFF4 + 1) * 64 + lane], tt);
+        float4 v = b4[DWR_PX + (DWR_COL_DY4 / 4) * 33 + lo]; if (!vl) v = z4;      // (cin, dY4): T3 = dY4 . W4, 2
+        tt = mfma32(h ? v.z : v.y, wl[(DWR_OFF4 + 0) * 64 + lane], tt);
+        tt = mfma32(h ? 0.f : v.w, wl[(DWR_OFF4 + 1) * 64 + lane], tt);
     }
     // masks: dHpre, H.  A point past n has zero rows here, so it adds nothing below
 #pragma unroll
@@ -1124,7 +1239,7 @@ __device__ __forceinline__ void dwr_batch(const float* __restrict__ buf, const f
         } else {
             const float x1b = prow[ob], x1c = prow[oc];
             const float gb = prow[og], gc = prow[oh];
-            const float dy4 = lo < 3 ? prow[DWR_PD * 4 + (lo & 3)] : 0.f;
+            const float dy4 = lo < 3 ? prow[dwr_col(DWR_PX, DWR_COL_DY4 + (lo & 3))] : 0.f;
             const float x3b = lo < 16 ? x1c : gb;                   // X3 columns 32..63 = [pos 32..47 | geo 0..14, ex_r]
             acc[0] = mfma32(tt[r], x1b, acc[0]); acc[1] = mfma32(tt[r], x3b, acc[1]); acc[2] = mfma32(tt[r], gc, acc[2]);
             acc[3] = mfma32(dy4, hh[r], acc[3]);
@@ -1134,7 +1249,7 @@ __device__ __forceinline__ void dwr_batch(const float* __restrict__ buf, const f
 
 // 8 waves: wave w and wave w + 4 (scheduled onto the same SIMD) share the batches of slot w & 3 -- the first takes the
 // H1 side, the second the H3 side -- so that each SIMD has two waves' worth of independent MFMA chains and LDS reads.
-__global__ __launch_bounds__(512) void field_dw_recompute_kernel(BwdWs ws, const float* __restrict__ draw4, int64_t n,
+__global__ __launch_bounds__(512) void field_dw_recompute_kernel(BwdWs ws, int64_t n_all, const int* __restrict__ n_sel,
                                                               float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float dwr_lds[];
     float* wl = dwr_lds;                                     // [DWR_SLOTS][64] weight images
@@ -1142,10 +1257,11 @@ __global__ __launch_bounds__(512) void field_dw_recompute_kernel(BwdWs ws, const
     const int lane = threadIdx.x & 63, lo = lane & 31, h = lane >> 5;
     const int wv = threadIdx.x >> 6, slot = wv & 3, side = wv >> 2;
     float* mine = stage + slot * 2 * DWR_BUF;
+    const int64_t n = n_sel ? (int64_t)*n_sel : n_all;         // the selected rows (see Sel)
     const int64_t n_b = (n + 31) / 32, n_s = (int64_t)gridDim.x * 4;
     const int64_t n_it = (n_b + n_s - 1) / n_s;              // every wave of the block runs the same number of rounds (barriers inside)
     int64_t bt = (int64_t)blockIdx.x * 4 + slot;             // batches bt, bt + n_s, ...
-    if (bt < n_b) dwr_fetch(ws, draw4, bt * 32, n, lane, mine, side);
+    if (bt < n_b) dwr_fetch(ws, bt * 32, n, lane, mine, side);
     for (int i = threadIdx.x; i < DWR_SLOTS * 16; i += 512)
         reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(ws.wcopy)[i];
     f32x16 acc[4];
@@ -1155,7 +1271,7 @@ __global__ __launch_bounds__(512) void field_dw_recompute_kernel(BwdWs ws, const
     for (int64_t it = 0; it < n_it; ++it, bt += n_s, cur ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my half of this round's batch has landed ...
         __syncthreads();                                      // ... and so has everybody's; the other buffer is free again
-        if (bt + n_s < n_b) dwr_fetch(ws, draw4, (bt + n_s) * 32, n, lane, mine + (cur ^ 1) * DWR_BUF, side);
+        if (bt + n_s < n_b) dwr_fetch(ws, (bt + n_s) * 32, n, lane, mine + (cur ^ 1) * DWR_BUF, side);
         if (bt < n_b) {
             const bool vl = bt * 32 + lo < n;
             if (side == 0) dwr_batch<0>(mine + cur * DWR_BUF, wl, vl, lane, acc);
@@ -1219,11 +1335,12 @@ __global__ __launch_bounds__(1024) void field_dw_reduce_kernel(const float* __re
 // dX1 rows and draw4 (residual adds: d ex_rgb += draw.rgb, d tres += draw.sdf).
 __global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                        const float* __restrict__ draw4, const float* __restrict__ dx1,
-                                                       float* __restrict__ dx01) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+                                                       float* __restrict__ dx01, Sel sel) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // row of dX1
+    if (q >= n || (sel.n_sel && q >= *sel.n_sel)) return;                    // rows past n_sel: no gradient, dx01 stays as it is
+    const int64_t p = sel.perm ? (int64_t)sel.perm[q] : q;                   // the point it belongs to
     const float x[3] = {x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]};
-    const float* row = dx1 + p * LD_DX1;
+    const float* row = dx1 + q * LD_DX1;
     float dx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -1420,7 +1537,7 @@ int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, 
 size_t rfx_field_backward_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
     const size_t np = align_up((size_t)n, 64);
-    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * DW_TOTAL + DWR_SLOTS * 64 + scatter_scratch_floats(n, RFX_MAX_LEVELS)) * sizeof(float);
+    return (np * ws_floats_per_point() + (size_t)DW_BLOCKS * DW_TOTAL + DWR_SLOTS * 64 + 16 + align_up(np / SEL_PPB + 1, 4) + scatter_scratch_floats(n, RFX_MAX_LEVELS)) * sizeof(float);
 }
 
 // ---- the four stages of the Q1 backward as separate entry points (rfx_field_backward chains them)
@@ -1444,7 +1561,7 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
     if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
     BwdWs ws = carve(workspace, n);
     const size_t lds = (size_t)ALL_SLOTS * 64 * sizeof(float);
-    using Kern = void (*)(FieldK, const float*, int64_t, const float*, BwdWs);
+    using Kern = void (*)(FieldK, const float*, int64_t, const float*, BwdWs, Sel);
     // [pos_fp16 | stashed][variant]: 0 = rows + full dX1 (_chain), 1 = full dX1 only (_chain_inputs), 2 = rows + d_emb (_chain_weights)
     static const Kern kern[4][3] = {
         {field_backward_kernel<false, true, true, false>, field_backward_kernel<false, false, true, false>, field_backward_kernel<false, true, false, false>},
@@ -1461,7 +1578,15 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int variant = rows ? (dxfull ? 0 : 2) : 1;
-    hipLaunchKernelGGL(kern[(k.pos_fp16 ? 1 : 0) + (stashed ? 2 : 0)][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws);
+    Sel sel{nullptr, nullptr};
+    if (sel_on(n)) {            // points with a non-zero loss gradient first; the later stages read the same perm / count
+        const int nb = (int)((n + SEL_PPB - 1) / SEL_PPB);
+        hipLaunchKernelGGL(sel_count_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts);
+        hipLaunchKernelGGL(sel_scatter_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts, nb, ws.perm, ws.sel_hdr);
+        RFX_LAUNCH_CHECK();
+        sel = Sel{ws.perm, ws.sel_hdr};
+    }
+    hipLaunchKernelGGL(kern[(k.pos_fp16 ? 1 : 0) + (stashed ? 2 : 0)][variant], dim3(wave_grid(n, 256 * 2)), dim3(256), lds, as_stream(stream), k, x01, n, draw4, ws, sel);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1522,7 +1647,7 @@ static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, fl
         attr_set[dev] = true;
     }
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(DW_BLOCKS, ((n + 31) / 32 + 3) / 4));
-    hipLaunchKernelGGL(field_dw_recompute_kernel, dim3(blocks), dim3(512), DWR_LDS, st, ws, draw4, n, ws.partial);
+    hipLaunchKernelGGL(field_dw_recompute_kernel, dim3(blocks), dim3(512), DWR_LDS, st, ws, n, sel_on(n) ? ws.sel_hdr : nullptr, ws.partial);
     RFX_LAUNCH_CHECK();
     if (overwrite)
         hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, blocks, dw1, dw2, dw3, dw4);
@@ -1547,12 +1672,14 @@ int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
     if (d_hash) {
-        rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, ws.demb_t, as_stream(stream));
+        rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, ws.demb_t, as_stream(stream), nullptr, nullptr, 0, 0,
+                                 sel_on(n) ? ws.perm : nullptr, sel_on(n) ? ws.sel_hdr : nullptr);
         if (rc) return rc;
         RFX_LAUNCH_CHECK();
     }
     if (dx01) {
-        launch_encode_dx(k.hash, k.table, x01, n, ws.dx1, LD_DX1, dx01, as_stream(stream));
+        launch_encode_dx(k.hash, k.table, x01, n, ws.dx1, LD_DX1, dx01, as_stream(stream), sel_on(n) ? ws.perm : nullptr,
+                         sel_on(n) ? ws.sel_hdr : nullptr);
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;
@@ -1569,9 +1696,11 @@ int rfx_field_backward_scatter_merged(const rfx_field_desc* f, const float* x01,
     if (n > 0 && (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n))) return RFX_ERR_WORKSPACE;
     if (scatter_ws && (scatter_bytes < rfx_grid_encode_backward_workspace_bytes(n + extra_n, k.hash.n_levels) || ((uintptr_t)scatter_ws & 7)))
         return RFX_ERR_WORKSPACE;
-    const float* dx1 = n > 0 ? carve(workspace, n).dx1 : nullptr;
-    rc = launch_grid_scatter(k.hash, k.table, x01, n, dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
-                             extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n);
+    BwdWs ws{};
+    if (n > 0) ws = carve(workspace, n);
+    rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
+                             extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n, sel_on(n) ? ws.perm : nullptr,
+                             sel_on(n) ? ws.sel_hdr : nullptr);
     if (rc) return rc;
     RFX_LAUNCH_CHECK();
     return RFX_OK;
@@ -1587,7 +1716,7 @@ int rfx_field_backward_dx(const rfx_field_desc* f, const float* x01, int64_t n, 
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
     hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), k, x01, n, draw4,
-                       ws.dx1, dx01);
+                       ws.dx1, dx01, sel_on(n) ? Sel{ws.perm, ws.sel_hdr} : Sel{nullptr, nullptr});
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -339,7 +339,8 @@ __device__ __forceinline__ void sparse_pos_tiles(const float* __restrict__ wp, c
 // workspace layout): float4 piece q of the row is ROW_PIECE floats after piece q - 1, so a wave's store (or load) of one
 // piece is contiguous.
 //   EMB 0: look the hash features up.  1: look them up and store them to emb_row (8 pieces).  2: load them from emb_row,
-//          where an earlier kernel (the forward of the same iteration, or EMB 1) left them: no gathers, no interpolation.
+//          where an earlier kernel (the forward of the same iteration) left them: no gathers, no interpolation; emb_copy
+//          (optional) receives them again, at the row the caller stages this point at.
 //   POSST: store the dense fp32 OneBlob row to pos_row (12 pieces).
 constexpr int ROW_PIECE = 256;
 __device__ __forceinline__ float* row_piece(float* row, int col) { return row + (col >> 2) * ROW_PIECE + (col & 3); }
@@ -347,7 +348,7 @@ __device__ __forceinline__ float* row_piece(float* row, int col) { return row + 
 template <int EMB, bool POSST, bool POS16>
 __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3], const float* __restrict__ wl,
                                                 int lane, Enc& e, Mlp& m, float* emb_row = nullptr, float* pos_row = nullptr,
-                                                bool valid = true) {
+                                                bool valid = true, float* emb_copy = nullptr) {
     m.h1[0] = zero16(); m.h1[1] = zero16();
     if (POS16) {
         // OneBlob first: its lo-weight products must enter the empty accumulators (see above)
@@ -388,6 +389,10 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
         float4 q[8];                  // levels 2i, 2i+1 are piece i of the stashed row: eight contiguous loads, issued together
 #pragma unroll
         for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const float4*>(emb_row + i * ROW_PIECE);
+        if (emb_copy && valid) {      // the staged copy the weight-gradient kernel reads (the chain's own point order)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(emb_copy + i * ROW_PIECE) = q[i];
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             float a = (s & 1) ? q[s >> 1].z : q[s >> 1].x, b = (s & 1) ? q[s >> 1].w : q[s >> 1].y;

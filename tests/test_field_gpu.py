@@ -605,6 +605,60 @@ def test_stashed_forward_and_chains_are_bit_identical_to_the_recomputing_ones(fp
     assert lib.rfx_field_forward_stash(C.byref(desc), L.ptr(x), n, L.ptr(raw), None, nbytes, st) == -4
 
 
+@pytest.mark.parametrize("stashed", [False, True])
+def test_backward_on_selected_points_equals_the_sum_over_unselected_halves(stashed):
+    """From 16 384 points on, the chain stage puts the points with a non-zero loss gradient first and every later stage
+    works on those only (a third of a mapping batch has d_raw == 0 exactly).  Check against the same launch cut into two
+    halves that are too small for the selection: gradients are sums over points, so dW and d_hash must agree to fp32
+    summation order and dx01 -- one value per point -- bit for bit, zeros included."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    cfg, m = _model(hash_scale=0.5)
+    n = 20001
+    x = _points(n, seed=8, lo=0.02, hi=0.98).cuda().contiguous()
+    g = torch.Generator().manual_seed(13)
+    draw = torch.randn((n, 4), generator=g)
+    draw[torch.rand(n, generator=g) < 0.4] = 0.0                 # rows without a gradient, scattered through the batch
+    draw[5000:5300] = 0.0                                         # ... and whole tiles of them
+    draw = draw.cuda().contiguous()
+    desc = m._field_desc(True)
+    st = L.stream_ptr(x.device)
+    table = m.embed_res_fn.params
+
+    def run(xx, dd):
+        k = xx.shape[0]
+        nbytes = int(lib.rfx_field_backward_workspace_bytes(k))
+        ws = torch.full((nbytes // 4 + 16,), float("nan"), device="cuda")
+        wsp = (ws.data_ptr() + 15) // 16 * 16
+        raw = torch.empty((k, 4), device="cuda")
+        if stashed:
+            L.check(lib.rfx_field_forward_stash(C.byref(desc), L.ptr(xx), k, L.ptr(raw), wsp, nbytes, st), "forward_stash")
+        chain = lib.rfx_field_backward_chain_stashed if stashed else lib.rfx_field_backward_chain
+        dws = [torch.zeros_like(w) for w in m.decoder_res.fused_weights()]
+        d_hash, dx = torch.zeros_like(table), torch.full((k, 3), float("nan"), device="cuda")
+        L.check(chain(C.byref(desc), L.ptr(xx), k, L.ptr(dd), wsp, nbytes, st), "chain")
+        L.check(lib.rfx_field_backward_weights(k, L.ptr(dd), *[L.ptr(t) for t in dws], wsp, nbytes, st), "weights")
+        L.check(lib.rfx_field_backward_scatter(C.byref(desc), L.ptr(xx), k, L.ptr(d_hash), L.ptr(dx), wsp, nbytes, st), "scatter")
+        L.check(lib.rfx_field_backward_dx(C.byref(desc), L.ptr(xx), k, L.ptr(dd), L.ptr(dx), wsp, nbytes, st), "dx")
+        torch.cuda.synchronize()
+        return dws, d_hash, dx
+
+    h = n // 2
+    assert h < 16384 <= n
+    fw, fh, fx = run(x, draw)
+    aw, ah, ax = run(x[:h].contiguous(), draw[:h].contiguous())
+    bw, bh, bx = run(x[h:].contiguous(), draw[h:].contiguous())
+    assert torch.equal(fx, torch.cat([ax, bx])) and bool(torch.isfinite(fx).all())
+    zero_rows = (draw == 0).all(dim=1)
+    assert float(zero_rows.float().mean()) > 0.3 and bool((fx[zero_rows] == 0).all()) and float(fx[~zero_rows].abs().max()) > 0
+    for f_, a_, b_ in zip(fw, aw, bw):
+        ref = a_ + b_
+        assert bool(torch.isfinite(f_).all()) and float((f_ - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    ref = ah + bh
+    assert bool(torch.isfinite(fh).all()) and float((fh - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) and float(ref.abs().max()) > 0
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_backward_chain_variants_agree_with_the_full_chain(clamp):
     """rfx_field_backward_chain_weights (map phase: rows + d_emb) and rfx_field_backward_chain_inputs (pose phase: dX1
