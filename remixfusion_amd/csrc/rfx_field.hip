@@ -359,12 +359,20 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
 // with doubles the atomics stop being the bound, but every point is visited by twice as many blocks, so the index
 // arithmetic doubles.  Measured (tools/time_scatter.py, merged ray + TV points): T = 2^16 0.23 -> 0.15 ms with doubles,
 // T = 2^19 0.93 -> 1.21 ms, T = 2^21 1.5 -> 2.6 ms: doubles are used while no level is cut into 16 or more float segments.
+#ifdef SCATTER_PROF      // dev builds only (tools/scatter_prof.py): start / end clock of every block of the last sweep
+__device__ unsigned long long g_scatter_prof[2 * 8192];
+#endif
+
 template <typename ACC, unsigned SEG>
 __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_grid_desc g, ScatterPlan plan, int n_levels,
                                                                            const float* __restrict__ scratch,
                                                                            float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     ACC* acc = reinterpret_cast<ACC*>(acc_raw);
+#ifdef SCATTER_PROF
+    const unsigned pid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && pid < 8192) g_scatter_prof[2 * pid] = wall_clock64();
+#endif
     int l = 0;
     while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
     const int seg = blockIdx.x - plan.seg_start[l], chunk = blockIdx.y;
@@ -479,6 +487,10 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
         if (v != 0.f) atomicAdd(out + i, v);
 #endif
     }
+#ifdef SCATTER_PROF
+    __syncthreads();
+    if (threadIdx.x == 0 && pid < 8192) g_scatter_prof[2 * pid + 1] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- E1 backward, binned scatter (large tables)
@@ -1472,6 +1484,12 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
     }
     return RFX_OK;
 }
+
+#ifdef SCATTER_PROF
+extern "C" int rfx_debug_scatter_prof(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scatter_prof), sizeof(unsigned long long) * (size_t)std::min(n, 2 * 8192)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, float* out, rfx_stream stream) {
     if (n == 0) return RFX_OK;
