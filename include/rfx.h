@@ -216,11 +216,14 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
 
 /* The four stages rfx_field_backward runs, exposed so a caller can time / overlap them:
  *   _chain   : recompute forward + dX chain on the matrix cores; stages per-point rows in the workspace
- *   _weights : dW = dY^T X over points (streaming MFMA, deterministic two-stage sum), accumulates into dw*
- *   _scatter : hash-grid gradient scatter (wave-segmented float atomics) into d_hash; writes the hash
+ *   _weights : dW = dY^T X over points (matrix cores, hidden activations recomputed from the staged rows, deterministic
+ *              two-stage sum), accumulates into dw*; reads draw4 as the chain staged it (the argument is not read)
+ *   _scatter : hash-grid gradient scatter (LDS-privatised / binned, float atomics) into d_hash; writes the hash
  *              part of dx01 when dx01 != NULL
  *   _dx      : adds the OneBlob / GBV part of dL/dx01
- * All take the same workspace; _chain must run first. */
+ * All take the same workspace, x01, n and draw4; _chain must run first.  From 16 384 points on, _chain orders the points
+ * with a non-zero draw4 row first and the later stages work on those only (a point with draw4 == 0 contributes exactly
+ * nothing to any gradient; its dx01 row is written as zeros): same results up to the order of the additions. */
 int rfx_field_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4,
                              void* workspace, size_t workspace_bytes, rfx_stream stream);
 /* _chain for callers that want input gradients only (pose phase: map frozen): stages just the dX1 rows, which is all
