@@ -55,13 +55,14 @@ class Adam(torch.optim.Adam):
 
     @torch.no_grad()
     def _step_impl(self, closure=None):
-        if not self._native():
-            torch_step = torch.optim.Adam.step             # un-wrapped: step() above has dealt with the hooks already
-            return getattr(torch_step, "__wrapped__", torch_step)(self, closure)
         loss = None
-        if closure is not None:
+        if closure is not None:                 # first: the gradients it produces decide which implementation steps them
             with torch.enable_grad():
                 loss = closure()
+        if not self._native():
+            torch_step = torch.optim.Adam.step             # un-wrapped: step() above has dealt with the hooks already
+            getattr(torch_step, "__wrapped__", torch_step)(self, None)
+            return loss
         lib = _lib.load()
         per_device = {}
         for g in self.param_groups:
