@@ -41,4 +41,4 @@ def test_closure_is_evaluated_with_grad_enabled():
         return loss
 
     out = opt.step(closure)
-    assert float(out) == 5.0 and float(p.detach().max()) < 1.0
+    assert float(out.detach()) == 5.0 and float(p.detach().max()) < 1.0
