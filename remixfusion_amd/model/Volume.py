@@ -89,6 +89,14 @@ class moving_volume:
         if hasattr(self, "_capacity") and self._n() > self._capacity:
             raise _lib.RfxError("volume grew past its allocation (reference would overflow here)")
 
+    def _can_shift_in_place_of_copy(self) -> bool:
+        """copy_volume() followed at once by the re-gridding gather may be done as one gather between the two buffer sets
+        (update_tsdf_swap_rot_trans(source="front")): for the plain single-GPU volume with both sets allocated."""
+        return type(self).update_tsdf_swap_rot_trans is moving_volume.update_tsdf_swap_rot_trans and \
+            "update_tsdf_swap_rot_trans" not in self.__dict__ and "copy_volume" not in self.__dict__ and \
+            getattr(self, "tsdf_vol_gpu_back", None) is not None and getattr(self, "tsdf_vol_gpu", None) is not None and \
+            self.tsdf_vol_gpu_back.numel() == self.tsdf_vol_gpu.numel()
+
     def _vols(self):
         return self.tsdf_vol_gpu, self.weight_vol_gpu, self.color_vol_gpu
 
@@ -161,12 +169,19 @@ class moving_volume:
         check(_lib.load().rfx_tsdf_copy(ptr(t), ptr(w), ptr(c), ptr(tb), ptr(wb), ptr(cb), self._n(),
                                         stream_ptr(self.device)), "rfx_tsdf_copy")
 
-    def update_tsdf_swap_rot_trans(self, vol_bnds, old_bnds):
+    def update_tsdf_swap_rot_trans(self, vol_bnds, old_bnds, source="back"):
         """Re-grid the volume into new bounds, gathering from the back copy
-        (reference :796-855, kernel :128-194)."""
+        (reference :796-855, kernel :128-194).
+
+        source="front": the state copy_volume() + this call leave -- front = re-gridded volume, back = the volume as it
+        was -- without the copy: the gather reads the front buffers, writes the back ones (every voxel of the new grid is
+        written), and the two sets trade places.  Saves one 2 x 12 B/voxel sweep per move (1.9 ms at 800x800x600)."""
         self._set_geometry(vol_bnds)
         old_origin = old_bnds[:, 0].copy(order="C").astype(np.float32)
         old_dim = np.ceil((old_bnds[:, 1] - old_bnds[:, 0]) / self.voxel_size).copy(order="C").astype(int)
+        if source == "front":
+            (self.tsdf_vol_gpu, self.weight_vol_gpu, self.color_vol_gpu,
+             self.tsdf_vol_gpu_back, self.weight_vol_gpu_back, self.color_vol_gpu_back) = (*self._backs(), *self._vols())
         t, w, c = self._vols()
         tb, wb, cb = self._backs()
         d = self.vol_dim
@@ -342,8 +357,11 @@ class moving_volume:
                 tmp[a, 1] = round(tmp[a, 1], 0)
             if not (tmp == old_bnds).all():
                 flag = True
-                self.copy_volume()
-                self.update_tsdf_swap_rot_trans(tmp, old_bnds)
+                if self._can_shift_in_place_of_copy():
+                    self.update_tsdf_swap_rot_trans(tmp, old_bnds, source="front")
+                else:
+                    self.copy_volume()
+                    self.update_tsdf_swap_rot_trans(tmp, old_bnds)
 
         if version == "more":
             tmp = copy.deepcopy(self.vol_bnds)

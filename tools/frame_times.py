@@ -13,11 +13,11 @@ if len(sys.argv) > 1:          # a throwaway pipeline first, like bench.py's pro
     for i in range(1, 12): wp.step(i, wf[i])
     torch.cuda.synchronize(); del wp, wf; gc.collect()
 pipe = MappingPipeline(cfg, n_frames=140)
-orig = pipe.mv.update_tsdf_swap_rot_trans
-moves = []
+orig = pipe.mv._set_geometry          # called once per move (not update_tsdf_swap_rot_trans: an instance override would
+moves = []                            # switch the volume back to copy + gather)
 def spy(*a, **k):
     moves.append(pipe.frames_done + 1); return orig(*a, **k)
-pipe.mv.update_tsdf_swap_rot_trans = spy
+pipe.mv._set_geometry = spy
 frames = pipe.prefetch(list(range(130)))
 pipe.start(frames[0], first_iters=20)
 ts = []
@@ -27,5 +27,5 @@ for i in range(1, 130):
     torch.cuda.synchronize(); ts.append(time.time() - t0)
 print("volume moves at frames", moves)
 ts = np.array(ts) * 1e3
-for a in range(0, 40, 5):
+for a in list(range(0, 30, 5)) + [85]:
     print(a + 1, "-", a + 5, " ".join(f"{v:.2f}" for v in ts[a:a + 5]))
