@@ -20,6 +20,10 @@ edges = [0, 1e3, 3e3, 10e3, 30e3, 100e3, 1e9]
 for lo, hi in zip(edges[:-1], edges[1:]):
     g = [x for x in gaps if lo <= x < hi]
     print(f"  gaps {lo / 1e3:6.0f}-{hi / 1e3:8.0f} us: {len(g):6d}  total {sum(g) / 1e6:8.2f} ms ({sum(g) / (t1 - t0):.1%})")
+big = sorted(range(len(gaps)), key=lambda i: -gaps[i])[:6]
+for i in sorted(big):
+    if gaps[i] > 200e3:
+        print(f"  gap {gaps[i] / 1e3:7.0f} us at {(win[i][2] - t0) / 1e6:7.2f} ms: after {win[i][0][:60]} -> before {win[i + 1][0][:60]}")
 agg = {}
 for n, s, e in win:
     a = agg.setdefault(n, [0, 0]); a[0] += 1; a[1] += e - s
