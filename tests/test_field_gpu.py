@@ -659,6 +659,29 @@ def test_backward_on_selected_points_equals_the_sum_over_unselected_halves(stash
     assert bool(torch.isfinite(fh).all()) and float((fh - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) and float(ref.abs().max()) > 0
 
 
+def test_backward_with_no_gradient_anywhere_gives_exact_zeros():
+    """every row of d_raw zero (a batch of rays that all ended in free space): nothing is selected, and all gradients,
+    dx01 included, come out as exact zeros rather than stale workspace contents."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    cfg, m = _model(hash_scale=0.5)
+    n = 17000
+    x = _points(n, seed=9, lo=0.02, hi=0.98).cuda().contiguous()
+    draw = torch.zeros((n, 4), device="cuda")
+    desc = m._field_desc(False)
+    st = L.stream_ptr(x.device)
+    nbytes = int(lib.rfx_field_backward_workspace_bytes(n))
+    ws = torch.full((nbytes // 4 + 16,), float("nan"), device="cuda")
+    wsp = (ws.data_ptr() + 15) // 16 * 16
+    dws = [torch.zeros_like(w) for w in m.decoder_res.fused_weights()]
+    d_hash, dx = torch.zeros_like(m.embed_res_fn.params), torch.full((n, 3), float("nan"), device="cuda")
+    L.check(lib.rfx_field_backward(C.byref(desc), L.ptr(x), n, L.ptr(draw), L.ptr(d_hash), *[L.ptr(t) for t in dws], L.ptr(dx),
+                                   wsp, nbytes, st), "backward")
+    torch.cuda.synchronize()
+    assert all(bool((t == 0).all()) for t in dws) and bool((d_hash == 0).all()) and bool((dx == 0).all())
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_backward_chain_variants_agree_with_the_full_chain(clamp):
     """rfx_field_backward_chain_weights (map phase: rows + d_emb) and rfx_field_backward_chain_inputs (pose phase: dX1

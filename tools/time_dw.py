@@ -14,6 +14,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 136093
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 x = torch.rand((n, 3), device="cuda", generator=g).clamp(0.001, 0.999).contiguous()
 draw = torch.randn((n, 4), device="cuda", generator=g)
+zf = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # fraction of rows without a gradient (real batches: 0.37)
+if zf > 0:
+    draw[torch.rand(n, device="cuda", generator=g) < zf] = 0.0
 ws = torch.empty(int(lib.rfx_field_backward_workspace_bytes(n)) // 4 + 16, device="cuda")
 desc = m._field_desc(False)
 dw = torch.zeros(5312, device="cuda")
@@ -29,4 +32,4 @@ for name, fn in fns:
         assert rc == 0
     torch.cuda.synchronize()
     out.append(f"{name} {np.median([a.elapsed_time(b) for a, b in evs]) * 1e3:7.1f} us")
-print(f"points {n}: " + "  ".join(out))
+print(f"points {n} (zero rows {zf:.2f}): " + "  ".join(out))
