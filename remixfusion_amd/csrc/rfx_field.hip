@@ -717,11 +717,9 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     const bool staged_ok = scratch && n_all >= SCATTER_MIN_POINTS;
     // levels cut into many segments are binned (one at a time, below); the others share one LDS sweep
     bool binned[RFX_MAX_LEVELS] = {};
-    int n_binned = 0;
     unsigned largest = 0;
     for (int l = 0; l < g.n_levels; ++l) {
         binned[l] = staged_ok && level_is_binned(g, l);
-        n_binned += binned[l] ? 1 : 0;
         if (!binned[l]) largest = std::max(largest, g.size[l]);
     }
     const bool f64 = largest < 16u * SCATTER_SEG;           // see grid_scatter_lds_kernel

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
     if (z1 == 12345678) tsdf[0] = 0.f;   // keep the cull alive
     return;
 #endif
-    const int rx_l = x0 + lane / TY, ry_l = y0 + lane % TY;
+    const int ry_l = y0 + lane % TY;
     const bool risky_l = lane < ROWS && (P.literal_all || ry_l < P.risky_rows || ry_l >= P.dy - P.risky_rows);
     const int nchunk = (!risky_l && z1 > z0) ? (z1 - z0 + 63) >> 6 : 0;
     int incl = nchunk;
