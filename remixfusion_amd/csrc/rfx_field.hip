@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- backward: workspace layout
-// per-point rows (fp32).  dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3 | 0..], row-major, one row of LD_DX1 per point.
+// per-point rows (fp32).  dX1 = [d_emb32 | d_pos48 | d_cin | d_ex_rgb3], row-major, one row of LD_DX1 (96, 84 used) per point.
 // What only the weight-gradient kernel reads -- emb32 (8 float4 pieces; also the forward's stash for the chain), X1' =
 // [pos48 | cin | 0 0 0] (13), G = [geo15 | ex_rgb3 | 0 0] (5), dY2 (4) -- is PIECE-MAJOR inside tiles of 64 points (row_piece() in rfx_field_mlp.h): piece q of point p sits at
 // tile (p / 64) * pieces * 256 + q * 256 + (p % 64) * 4 floats.  The chain kernel has lane = point, so each of its float4
@@ -1138,7 +1138,6 @@ __global__ __launch_bounds__(256, BWD_WAVES) void field_backward_kernel(FieldK f
                         tq[4 * i + 3] + gq[4 * i + 3]);
                 // [80] d_cin, [81..83] d_ex_rgb from the colour net (the residual-add part is added by the dx kernel)
                 st4(dxrow, 80, tq[16], gq[31], cq[0], cq[1]);
-                st4(dxrow, 84, 0.f, 0.f, 0.f, 0.f); st4(dxrow, 88, 0.f, 0.f, 0.f, 0.f); st4(dxrow, 92, 0.f, 0.f, 0.f, 0.f);
             }
         }
     }
