@@ -59,6 +59,7 @@ def parse():
                          "is fp32: model/encodings.py:73); reported in dtype/config")
     ap.add_argument("--no-one-scene", action="store_true", help="N>1: skip the strong-scaling run of ONE sharded scene")
     ap.add_argument("--one-scene-timeout", type=float, default=300.0, help="N>1: seconds the strong-scaling run may take")
+    ap.add_argument("--no-mv-stream", action="store_true", help="V1 on the mapper's stream instead of a stream of its own (A/B)")
     ap.add_argument("--stagewise-every", type=int, default=-1,
                     help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
                          "default: about three such iterations in the timed region, spaced so that both phases are sampled)")
@@ -280,6 +281,8 @@ def main():
     cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
     if args.pos_fp16:
         cfg["pos"]["fp16_opt_in"] = True
+    if args.no_mv_stream:
+        cfg.setdefault("pipeline", {})["mv_stream"] = False
     n_frames = 1 + args.warmup + args.steps
     shard = make_shard(cfg, rank, world, dist) if world > 1 else None
     if shard is not None:
