@@ -214,24 +214,29 @@ def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
 
 def guarded_one_scene(args, cfg, dist, rank, world, device, n_frames, out):
     """run_one_scene under a watchdog thread.  A stalled collective cannot be interrupted from Python, so on a timeout the
-    thread itself prints rank 0's line (`out`, with the reason under "one_scene") and ends the process; an exception on
-    this rank is reported the same way (the other ranks then run into their own watchdogs)."""
+    thread itself prints rank 0's line (`out`, with the reason under "one_scene") and ends the process with a NON-ZERO
+    status (3) on every rank: a hang must not read as success.  An exception on this rank is reported in the JSON line
+    (rank 0) or on stderr (other ranks) and the process also ends with status 3 once the line is out: the peers are
+    inside a collective this rank will never join, so they end through their own watchdogs.  Nothing is restarted."""
     import threading
     done = threading.Event()
 
     def watchdog():
         if done.wait(args.one_scene_timeout):
             return
+        reason = f"rank {rank}: one-scene run did not finish within {args.one_scene_timeout} s (stalled collective?)"
+        print("[bench] " + reason, file=sys.stderr, flush=True)
         if out is not None:
-            out["one_scene"] = {"error": f"did not finish within {args.one_scene_timeout} s; the weak-scaling figures of this line are unaffected"}
+            out["one_scene"] = {"error": reason}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     threading.Thread(target=watchdog, daemon=True).start()
     try:
         res = run_one_scene(args, cfg, dist, rank, world, device, n_frames)
     except Exception as e:          # noqa: BLE001 -- reported in the JSON line
-        res = {"error": f"{type(e).__name__}: {e}"[:400]}
+        res = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:400]}
+        print("[bench] one-scene run failed: " + res["error"], file=sys.stderr, flush=True)
     done.set()
     return res
 

@@ -481,6 +481,14 @@ size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign 
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);
 /* workspace: dev, 256-byte aligned, >= rfx_ba_workspace_bytes(n_kf_samples + n_cur, S, tv_P, L*F, L). */
 int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* Where the iteration's intermediates live inside the workspace after a call (byte offsets from its base), so that a
+ * caller -- the parity tests -- can read the ray batch the call drew and every stage's result:
+ *   [0] rays_o [n,3]  [1] rays_d [n,3]  [2] target rgb [n,3]  [3] target depth [n]  [4] d_cam [n,3]  [5] pose index int32 [n]
+ *   [6] z_vals [n,S]  [7] x01 [n*S,3]   [8] raw [n*S,4]       [9] rgb_map [n,3]     [10] depth_map [n]
+ *   [11] TV lattice points [P^3,3]      [12] TV features [P^3, n_feat_total]         [13] d_raw [n*S,4]  [14] dx01 [n*S,3]
+ * Returns the number of offsets written (<= count), or RFX_ERR_ARG. */
+#define RFX_BA_LAYOUT_FIELDS 15
+int rfx_ba_workspace_layout(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels, size_t* offsets, int count);
 
 /* ---- optimizer step (M1) ------------------------------------------------------------------------------------
  * torch.optim.Adam as the reference builds it (mp_slam/slam.py:271-286; betas (0.9, 0.99), per-group lr / eps /

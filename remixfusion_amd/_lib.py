@@ -138,6 +138,7 @@ PROTOTYPES = {
     "rfx_adam_step": (_i, [C.POINTER(AdamTensor), C.c_int, _P]),
     "rfx_ba_workspace_bytes": (C.c_size_t, [_l, _i, _i, _i, _i]),
     "rfx_ba_forward_backward": (_i, [C.POINTER(BaDesc), _P, C.c_size_t, _P]),
+    "rfx_ba_workspace_layout": (_i, [_l, _i, _i, _i, _i, C.POINTER(C.c_size_t), _i]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),
     "rfx_rba_grads_floats": (C.c_size_t, [_l]),
     "rfx_frame_pose": (_i, [_P, _P, _P, _P, _P]),

@@ -80,6 +80,16 @@ size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat, int n
     return carve_ba(nullptr, n_rays, S, tv_P, n_feat, n_levels).total;
 }
 
+int rfx_ba_workspace_layout(int64_t n_rays, int S, int tv_P, int n_feat, int n_levels, size_t* offsets, int count) {
+    if (n_rays <= 0 || S <= 0 || tv_P <= 0 || n_feat <= 0 || n_levels <= 0 || !offsets || count <= 0) return RFX_ERR_ARG;
+    const BaWs w = carve_ba(reinterpret_cast<void*>((uintptr_t)256), n_rays, S, tv_P, n_feat, n_levels);   // any non-null base
+    const void* f[RFX_BA_LAYOUT_FIELDS] = {w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, w.raw, w.rgb_map, w.depth_map,
+                                           w.pts, w.feat, w.d_raw, w.dx};
+    const int k = std::min(count, (int)RFX_BA_LAYOUT_FIELDS);
+    for (int i = 0; i < k; ++i) offsets[i] = (size_t)((uintptr_t)f[i] - 256);
+    return k;
+}
+
 #define RFX_TRY(call)            \
     do {                         \
         int _rc = (call);        \

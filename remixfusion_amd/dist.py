@@ -376,7 +376,7 @@ def ShardedPipeline(config: Dict, dist, rank: int, world: int, device: str = "cu
                 broadcast_(dist, frames[i]["depth"], 0)
                 if rank != 0:
                     b = frames[i]
-                    b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
+                    b["rgb255"] = torch.floor(b["rgb"] * 255.0)
                     b["c2w_dev"] = b["c2w"].to(self.device)
                     self.dataset._cache[i] = {k: b[k] for k in ("frame_id", "c2w", "rgb", "depth", "direction")}
             if self.mv_stream is not None:

@@ -78,7 +78,7 @@ class MappingPipeline:
         out = {}
         for i in ids:
             b = self.dataset[i]
-            b["rgb255"] = torch.floor(b["rgb"] * 255.0 + 0.5)
+            b["rgb255"] = torch.floor(b["rgb"] * 255.0)
             b["c2w_dev"] = b["c2w"].to(self.device)     # a pageable H2D copy in the frame loop would drain the stream
             out[i] = b
         if self.mv_stream is not None:                  # the frames above were produced on the current stream
@@ -143,7 +143,7 @@ class MappingPipeline:
         if i > 0:
             self.mv.check_move_volume_new(i, pose_np, self.traj, version=self.config["volume"]["version"])
         if rgb255 is None:
-            rgb255 = torch.floor(batch["rgb"] * 255.0 + 0.5)
+            rgb255 = torch.floor(batch["rgb"] * 255.0)
         self.mv.integrate(rgb255, batch["depth"], self.K, pose_np, self.mv.vol_bnds)
 
     def sync_volume(self):

@@ -1,5 +1,6 @@
 """GPU parity: librfx field / render kernels (through the C ABI and the Python mirror) vs the torch
-CPU oracle.  fp32 tolerances: forward rel 1e-4; gradients rel 2e-3 (float atomics)."""
+CPU oracle.  fp32 tolerances: forward rel 1e-4; gradients per element rel 1e-4 + 4x the oracle's own
+fp32 summation noise (_grad_close); the size the bench runs at is covered by tests/test_timed_path_gpu.py."""
 import ctypes as C
 
 import numpy as np
@@ -298,7 +299,10 @@ def test_sampler_points_and_compositing(name):
     gr, gd = torch.randn((n, 3), generator=g), torch.randn((n,), generator=g)
     (rgb * gr.cuda()).sum().add((dep * gd.cuda()).sum()).backward()
     (rgb_ref * gr).sum().add((dep_ref * gd).sum()).backward()
-    _close(raw_g.grad, raw_o.grad, 2e-3, 1e-4, "d_raw")
+    raw_q = raw.double().requires_grad_(True)           # float64 oracle: the yardstick, and by difference the fp32 noise
+    rgb_q, dep_q = FO.raw2outputs(raw_q, z.cpu().double(), tr["trunc"], cfg["data"]["sc_factor"])
+    (rgb_q * gr.double()).sum().add((dep_q * gd.double()).sum()).backward()
+    _grad_close(raw_g.grad, raw_o.grad, raw_q.grad, "d_raw", k=8.0)
     w = m.sdf2weights(raw[..., 3].cuda(), z)
     _close(w, FO.sdf2weights(raw[..., 3], z.cpu(), tr["trunc"], cfg["data"]["sc_factor"]), 1e-4, 1e-6, "weights")
 
@@ -350,9 +354,16 @@ def test_mapping_losses_and_total_gradient_match_oracle():
     for p in m.parameters():
         p.grad = None
     FO.total_loss(ret, w).backward()
-    w1 = m.decoder_res.fused_weights()[0]
-    _close(w1.grad, fp.W1.grad, 5e-3, 5e-3 * float(fp.W1.grad.abs().max()), "dL/dW1")
-    _close(m.embed_res_fn.params.grad, fp.hash_table.grad, 5e-3, 2e-3 * float(fp.hash_table.grad.abs().max()), "dL/dhash")
+    fq = _f64_params(fp)
+    rend64 = FO.render_rays(fq, m.bounding_box.cpu().double(), o.double(), d.double(), z.double(), clamp=False, sc_factor=cfg["data"]["sc_factor"])
+    ref64 = FO.mapping_losses(rend64["rgb_res_map"], rend64["depth_res_map"], rend64["raw"], z.double(), tgt.double(), td.double(),
+                              depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"], trunc=tr["trunc"],
+                              sc_factor=cfg["data"]["sc_factor"])
+    FO.total_loss(ref64, w).backward()
+    for got, a, q, nm in zip(m.decoder_res.fused_weights(), (fp.W1, fp.W2, fp.W3, fp.W4), (fq.W1, fq.W2, fq.W3, fq.W4),
+                             ("dL/dW1", "dL/dW2", "dL/dW3", "dL/dW4")):
+        _grad_close(got.grad, a.grad, q.grad, nm)
+    _grad_close(m.embed_res_fn.params.grad, fp.hash_table.grad, fq.hash_table.grad, "dL/dhash", _level_groups(fp.hash_meta))
     m.eval()
     out = m.mapping(o.cuda(), d.cuda(), tgt.cuda(), td.cuda())
     assert set(out) == {"rgb_res_map", "depth_res_map", "z_vals", "raw"}
@@ -391,7 +402,7 @@ def test_product_mapping_matches_reference_golden(name):
             _close(ret[k], torch.from_numpy(g[f"{tag}_{k}"]), 1e-4, 1e-8, k)
         # fused renderer on the same rays (no jitter)
         rgb, dep = m.render_fused(o, d, td, jitter=False)
-        _close(rgb, torch.from_numpy(g[f"{tag}_rgb_res_map"]), 2e-4, 2e-5, "fused rgb") if not clamp else None
+        _close(rgb, torch.from_numpy(g[f"{tag}_rgb_res_map"]), 1e-4, 2e-5, "fused rgb") if not clamp else None
 
 
 def test_fused_mapping_node_equals_unfused_path_and_tv_node():
