@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 3
+#define RFX_ABI_VERSION 4
 
 typedef void* rfx_stream;
 
@@ -52,9 +52,10 @@ int rfx_last_hip_error(void);
  *   color_packed/depth: dev [H*W]; old_bnd[6] = x0,x1,y0,y1,z0,z1 (host, used iff reintegrate).
  *   index_decode: 0 = reproduce the reference's fp32 index decode (incl. its rounding
  *   artefacts next to slab boundaries when dx*dy*dz > 2^24), 1 = exact integer decode.
- *   workspace: dev, 8-byte aligned, >= rfx_tsdf_integrate_workspace_bytes(dx, dy, dz, H, W): the packed
- *   {depth, 1/lambda} image, its coarse max-depth tiles and the queue of 64-voxel chunks the frustum touches
- *   (8 B per chunk of the volume: 51 MB at 800x800x600).  ABI 2: the query takes the volume dimensions. */
+ *   workspace: dev, 16-byte aligned, >= rfx_tsdf_integrate_workspace_bytes(dx, dy, dz, H, W): the packed
+ *   {depth, 1/lambda} image, the fast path's classification image, a packed-colour image, coarse max-depth tiles and the
+ *   queue of 64-voxel chunks the frustum touches (32 B per chunk of the volume: 205 MB at 800x800x600; contents are
+ *   scratch, nothing is carried between calls).  ABI 2: the query takes the volume dimensions.  ABI 4: 32-byte items. */
 size_t rfx_tsdf_integrate_workspace_bytes(int dx, int dy, int dz, int H, int W);
 int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy, int dz,
                        const float origin[3], float voxel, const float K[9], const float c2w[16],
@@ -75,6 +76,16 @@ int rfx_tsdf_integrate_slab(float* tsdf, float* weight, float* color, int dx, in
                             float trunc, float obs_weight, int weight_clamp, int reintegrate,
                             const float old_bnd[6], int index_decode,
                             void* workspace, size_t workspace_bytes, rfx_stream stream);
+
+/* V1 with the colour packing of model/Volume.py:725-728 folded into the call: rgb255 dev [H*W,3] (0..255 valued floats,
+ * what the reference's host code packs with numpy before the upload) instead of color_packed; x0 = 0, x1 = dx for the
+ * whole volume.  Saves the rfx_pack_color launch in the frame loop; results are those of rfx_pack_color + V1. */
+int rfx_tsdf_integrate_rgb(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
+                           const float origin[3], float voxel, const float K[9], const float c2w[16],
+                           const float* rgb255, const float* depth, int H, int W,
+                           float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                           const float old_bnd[6], int index_decode,
+                           void* workspace, size_t workspace_bytes, rfx_stream stream);
 
 /* host-side colour packing of model/Volume.py:725-728 moved to the device:
  * rgb255 dev [n,3] (0..255 valued floats) -> packed dev [n] = floor(B*65536+G*256+R). */

@@ -90,6 +90,8 @@ PROTOTYPES = {
     "rfx_tsdf_shift_slab": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _F3, _P, _P, _P, _i, _i, _i, _i, _i, _F3, _f, _i, _P]),
     "rfx_tsdf_shift_source_planes": (_i, [_i, _i, _F3, _i, _F3, _f, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rfx_tsdf_trilerp": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _P, _l, _P, _P]),
+    "rfx_tsdf_integrate_rgb": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
+                                     _i, _P, _sz, _P]),
     "rfx_tsdf_filter": (_i, [_P, _P, _P, _l, _f, _P]),
     "rfx_tsdf_truncated_pc": (_i, [_P, _P, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _i, _P]),
     "rfx_gbv_integrate": (_i, [_P, _P, _i, _F6, _F9, _P, _P, _P, _i, _i, _f, _f, _P]),
@@ -167,7 +169,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 3:
+    if lib.rfx_abi_version() != 4:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

@@ -2,18 +2,21 @@
 //
 // Replaces the PyCUDA kernels of the reference (model/Volume.py:127-611, mp_slam/mapper.py:36-185).
 // The reference launches one thread per voxel of the whole box; for the integrate kernel ~97 %
-// of those threads exit at the frustum / depth tests.  Here V1 is a two-stage, frustum-culled
-// row walk:
-//   prepass  : one pass over the H*W frame -> packed {depth, 1/lambda} image (8 B/pixel,
-//              L2-resident) + max depth (for the far plane of the cull).
-//   integrate: one wave per TXxTY tile of (x,y) voxel rows.  Each row is a line in camera
-//              space, so frustum /\ row is one z-interval, computed conservatively per lane;
-//              the wave then walks the surviving intervals 64 voxels at a time with lanes
-//              along z (the contiguous axis): every volume access is a coalesced 256-B run.
-//              Two chunks are kept in flight per wave (loads of both issued before use).
+// of those threads exit at the frustum / depth tests.  Here V1 is a frustum-culled walk in three launches
+// ("queue form", documented at its section below):
+//   mv_frame_kernel  : one pass over the H*W frame -> packed colour, {depth, 1/lambda} image, the {F, G}
+//                      classification image of the fast path (8 B/pixel each, L2-resident) and coarse max-depth tiles.
+//   mv_rows_kernel   : one thread per (x,y) voxel row of the frustum's footprint.  Each row is a line in camera
+//                      space, so frustum /\ row is one z-interval; its 64-voxel chunks go to a work queue.
+//   mv_chunks_kernel : resident waves pull chunks off the queue, lanes along z (the contiguous axis): every volume
+//                      access is a coalesced 256-B run.  Free-space voxels (85 % of a frame's updates) are classified
+//                      by two compares against the {F, G} image and only move their weight; the truncation band is
+//                      compacted through LDS and evaluated by the reference's full expression tree.
+// mv_integrate_kernel (one wave per tile of rows, round 1) remains as the fallback for volumes whose every voxel decodes
+// literally (dy*dz >= 2^24).
 // Per-voxel arithmetic is evaluated exactly as the reference kernel text does (same operation
 // order, fmaf where nvcc -fmad=true contracts, IEEE div/sqrt), so results are bit-identical to
-// oracle/tsdf_oracle.c; the cull only removes voxels that provably fail the reference's tests.
+// oracle/tsdf_oracle.c; the cull and the fast path only remove work whose outcome is provably the reference's.
 #include "rfx_common.h"
 #include <algorithm>
 
@@ -27,10 +30,10 @@
 #define MV_U 2          // chunks in flight per wave (queue form: 2 -> 8 waves per SIMD; measured 72 us per call vs 81 at 4)
 #endif
 #ifndef MV_TD
-#define MV_TD 32      // pixels per side of a coarse max-depth tile
+#define MV_TD 16      // pixels per side of a coarse max-depth tile
 #endif
 #ifndef MV_ROWS_THREADS
-#define MV_ROWS_THREADS 1024     // mv_rows_kernel block: one queue atomic per block
+#define MV_ROWS_THREADS 1024     // mv_rows_kernel block: one queue atomic per block that has work
 #endif
 #define MV_HDR 4       // workspace header words before the coarse tiles: [0] queue count, [1] risky-queue count
 
@@ -64,42 +67,9 @@ struct MvParams {
     // first / last tile rows in y, which hold the literally-decoded boundary rows and are always walked
     int   win_x0[3], win_y0[3], win_wx[3], win_wy[3];
     int   alias_margin;   // voxels within this index distance of an x-slab boundary may decode to another cell (decode_split)
+    float edge_eps;       // fast path: an approximately projected coordinate closer than this to a rounding boundary (k + 0.5)
+                          // may round to another pixel than the reference's: such lanes take the exact projection
 };
-
-// ---------------------------------------------------------------------------- prepass
-__global__ __launch_bounds__(256) void mv_prepass_kernel(const float* __restrict__ depth,
-                                                         float2* __restrict__ dimg,
-                                                         unsigned* __restrict__ dmax_bits, int H, int W,
-                                                         float fx, float fy, float cx, float cy, int colmajor) {
-    // one block per MV_TD x MV_TD pixel tile: packs {depth, 1/lambda} and stores the tile's max depth
-    // in dmax_bits[MV_HDR + tile] (plain store, no atomics).  dmax_bits[0], [1] are the work-queue counters of the
-    // queue-form integrate (mv_rows_kernel appends, mv_chunks_kernel reads): reset here.
-    if (blockIdx.x == 0 && threadIdx.x == 0) { dmax_bits[0] = 0u; dmax_bits[1] = 0u; }
-    const int tw = (W + MV_TD - 1) / MV_TD;
-    const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
-    float m = 0.0f;
-    for (int k = threadIdx.x; k < MV_TD * MV_TD; k += blockDim.x) {
-        const int py = ty * MV_TD + k / MV_TD, px = tx * MV_TD + k % MV_TD;
-        if (py >= H || px >= W) continue;
-        const int i = py * W + px;
-        const float d = depth[i];
-        const float vx = (((float)px) - cx) / fx;
-        const float vy = (((float)py) - cy) / fy;
-        const float lambda = sqrtf(madd(vx, vx, vy * vy) + 1.0f);
-        // A voxel row (world z) projects to a near-straight pixel walk.  Storing the image with the
-        // walk direction contiguous turns the per-lane gather of a 64-voxel chunk from 64 cache
-        // lines into ~12: column-major when the walk is mostly along image y.
-        dimg[colmajor ? px * H + py : i] = make_float2(d, 1.0f / lambda);
-        if (d > m) m = d;   // NaN never wins
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float wmax[4];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        dmax_bits[MV_HDR + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
-}
 
 // ---------------------------------------------------------------------------- per-voxel math
 struct RowConst {   // everything that is constant along z for exactly-decoded rows
@@ -417,40 +387,145 @@ __global__ __launch_bounds__(256) void mv_integrate_kernel(MvParams P, const flo
 }
 
 
-// ============================================================================ V1, queue form
-// Two launches behind the prepass instead of one wave per tile of rows:
-//   mv_rows_kernel   : one THREAD per (x,y) row of the frustum's footprint window.  Frustum clip -> z interval, far
-//                      clip from the coarse max-depth tiles (held in LDS), then the row's 64-voxel chunks (aligned to
-//                      256 B of the volume arrays) are appended to a work queue: one wave-aggregated atomic per wave.
-//   mv_chunks_kernel : a fixed grid of waves pulls U chunks at a time off the queue, lanes along z.  Every wave does the
-//                      same amount of work whatever the view (no wave is stuck with a deep tile while others idle), and
-//                      the volume reads are issued BEFORE the projection: the HBM round trip of tsdf/weight overlaps the
-//                      projection arithmetic and the L2 gather of {depth, 1/lambda}, instead of following them.
-// The per-voxel expression tree is integrate_lanes' (bit-identical results); the cull only removes voxels that provably
-// fail the reference's tests.
-// Queue item (uint2): x = rx | ry << 15 | risky << 30;  y = chunk | lo << 16 | hi << 22: lanes [lo, hi) of the chunk
-// lie inside the row's z interval.  Rows next to an x-slab boundary ("risky": the reference's fp32 index decode may
-// alias there, see decode_split) decode literally; their voxels within alias_margin indices of the boundary are
-// always walked, the others decode to their own cell and follow the row's interval like everyone else.
+// ============================================================================ V1, queue form (round 3)
+// Three launches per frame:
+//   mv_frame_kernel  : one block per 32x32-pixel tile.  Packs the colour image (when the caller hands over rgb), the
+//                      {depth, 1/lambda} image the exact path reads, the {F, G} CLASSIFICATION image the fast path reads
+//                      (two thresholds on the squared camera-space norm of a voxel, see below) and the tile's max depth.
+//   mv_rows_kernel   : one THREAD per (x,y) row of the frustum's footprint window.  Frustum clip -> z interval, far clip
+//                      from a max-depth pyramid over the coarse tiles (LDS; at most four reads per row), then the row's
+//                      64-voxel chunks (aligned to 256 B of the volume arrays) are appended to a work queue as 32-byte
+//                      items that carry everything that is constant along the row (camera-space row constants, byte
+//                      offset of the row): one returning atomic per 1 024-thread block.
+//   mv_chunks_kernel : a grid of resident waves pulls U items per trip (scalar loads), lanes along z.
+// Fast path of the chunk kernel (obs_weight > 0, no re-integration: every mapping frame), all of it branch-free: every
+// conditional memory operation is a raw buffer load / store whose per-lane offset is pushed out of range for the lanes
+// that must not take part (the range check drops them: no exec-mask regions, no scalar bookkeeping).  Per voxel:
+//   * camera point exactly as the reference forms it (5 operations);
+//   * APPROXIMATE projection (one v_rcp_f32 instead of two IEEE divisions).  The rounded pixel is the reference's unless
+//     the approximate coordinate lies within `edge_eps` of a rounding boundary; such lanes (~0.5 %) take the exact path;
+//   * one 8-byte gather of {F, G} at that pixel: with n2 = |cam|^2 (the very argument of the reference's square root)
+//         n2 < F  <=>  sdf > trunc for sure   (free space: dist = 1, no colour; F = 0 where that can never be decided)
+//         n2 > G  <=>  sdf < -trunc for sure, or the pixel has no depth (the reference returns)
+//     anything else is "near" and takes the exact path.  A free-space voxel that still holds tsdf = 1 keeps it
+//     ((1*w + obs*1) / (w + obs) is x / x), so only its weight moves -- and not even that at the clamp.
+//   * near lanes (truncation band, boundary pixels, voxels that were near a surface before) are compacted through LDS and
+//     evaluated 64 at a time by the reference's full expression tree (exact projection included).
+// Everything else (re-integration, de-integration, rows next to x-slab boundaries whose fp32 index decode may alias)
+// goes through the generic body: unconditional loads, exact projection, the same LDS compaction.
+// Bit-identical to oracle/tsdf_oracle.c: the fast path only ever decides what the exact expressions would decide, with
+// margins three orders above the rounding errors involved (derivation next to mv_frame_kernel).
+struct __attribute__((aligned(16))) MvItem {
+    unsigned xy;          // rx | ry << 15
+    unsigned cw;          // chunk | lo << 16 | hi << 22: lanes [lo, hi) of the chunk lie inside the row's z interval
+    float ax, ay, az;     // make_row(): everything of the camera point that is constant along the row
+    unsigned off_lo, off_hi;   // byte offset of the row's first voxel in a volume array (global index * 4)
+    unsigned pad;
+};
+static_assert(sizeof(MvItem) == 32, "queue item");
+
 constexpr int MV_ROWS_LDS_TILES = 4096;         // coarse tiles kept in LDS by mv_rows_kernel (16 KB); more -> global reads
 constexpr int MV_Q_MAX_DIM = 32767;
+constexpr int MV_PYR_FLOATS = MV_ROWS_LDS_TILES + 64;    // every level above the base together (a 1-D strip of tiles: ~n)
 
 __device__ __forceinline__ bool alias_zone(const MvParams& P, int ry, int z) {
     const int64_t off = (int64_t)ry * P.dz + z;                      // index distance from the slab's first voxel
     return off < P.alias_margin || (int64_t)P.dy * P.dz - off <= P.alias_margin;
 }
 
+// ---- frame kernel.  Thresholds of the classification image, for a pixel with depth d > 0 and rl = 1/lambda (the value
+// the reference multiplies the norm by):  sdf = rn(d - rl * norm), norm = sqrt_rn(n2).
+//   free  (sdf > trunc)  is implied by  rl * sqrt(n2) * (1 + 2^-23) <= d - trunc - delta, i.e. by
+//         n2 < F := ((d - trunc)(1 - 1e-5) - 1e-6)^2 / rl^2 * (1 - 1e-5)         (F = 0 when the bracket is not positive)
+//   untouched (sdf < -trunc) is implied by  n2 > G := ((d + trunc)(1 + 1e-5) + 1e-6)^2 / rl^2 * (1 + 1e-5)
+// The relative margins (1e-5) are ~100 fp32 ulps; the roundings in forming F, G, n2 and sdf are a handful of ulps each.
+// d <= 0 or NaN: F = 0, G = -1 (n2 > -1 always: untouched, the reference returns at `depth <= 0`).
+__global__ __launch_bounds__(256) void mv_frame_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
+                                                       float2* __restrict__ dimg, float2* __restrict__ fg,
+                                                       float* __restrict__ cpk, unsigned* __restrict__ hdr, int H, int W,
+                                                       float fx, float fy, float cx, float cy, float trunc, int colmajor) {
+    // one block per MV_TD x MV_TD pixel tile, one pixel per thread (the divisions and square roots of a pixel are one
+    // dependent chain: four pixels per thread, as in round 2, took four chains' time on a chip that had only 300 blocks)
+    static_assert(MV_TD == 16, "tile indexing below assumes 16x16 pixels, 256 threads");
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = 0u; hdr[1] = 0u; }
+    const int tw = (W + MV_TD - 1) / MV_TD;
+    const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
+    const int px = tx * MV_TD + (threadIdx.x & 15), py = ty * MV_TD + (threadIdx.x >> 4);
+    const bool in = px < W && py < H;
+    const int i = in ? py * W + px : 0;
+    const float d = depth[i];
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (rgb) { r = rgb[(int64_t)i * 3]; g = rgb[(int64_t)i * 3 + 1]; b = rgb[(int64_t)i * 3 + 2]; }
+    float m = 0.0f;
+    if (in) {
+        const float vx = (((float)px) - cx) / fx;
+        const float vy = (((float)py) - cy) / fy;
+        const float lambda = sqrtf(madd(vx, vx, vy * vy) + 1.0f);
+        const float rl = 1.0f / lambda;
+        float F = 0.0f, G = -1.0f;
+        if (d > 0.0f) {
+            const float inv = 1.0f / rl;
+            const float tf = (d - trunc) * (1.0f - 1e-5f) - 1e-6f;
+            if (tf > 0.0f) { const float a = tf * inv; F = a * a * (1.0f - 1e-5f); }
+            const float tg = (d + trunc) * (1.0f + 1e-5f) + 1e-6f;
+            const float bb = tg * inv;
+            G = bb * bb * (1.0f + 1e-5f);
+            m = d;             // NaN never gets here
+        }
+        // A voxel row (world z) projects to a near-straight pixel walk.  Storing the images with the walk direction
+        // contiguous turns the per-lane gather of a 64-voxel chunk from 64 cache lines into ~12: column-major when the
+        // walk is mostly along image y.
+        const int di = colmajor ? px * H + py : i;
+        dimg[di] = make_float2(d, rl);
+        fg[di] = make_float2(F, G);
+        if (rgb) cpk[i] = floorf(b * 65536.0f + g * 256.0f + r);   // np.floor(B*65536 + G*256 + R), left to right
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        hdr[MV_HDR + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+}
+
+// ---- rows kernel
 __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, const unsigned* __restrict__ dmax_bits,
-                                                       unsigned* __restrict__ q_counts, uint2* __restrict__ queue,
-                                                       unsigned q_cap, uint2* __restrict__ queue_risky, unsigned q_cap_risky,
-                                                       int blocks_main) {
-    __shared__ float tmax_lds[MV_ROWS_LDS_TILES];
+                                                       unsigned* __restrict__ q_counts, MvItem* __restrict__ queue,
+                                                       unsigned q_cap, MvItem* __restrict__ queue_risky, unsigned q_cap_risky,
+                                                       int blocks_main, int64_t slab_skip) {
+    // max-depth pyramid over the coarse tiles: level 0 = the tiles, level l+1 = 2x2 maxima of level l.  A row's
+    // projection is a straight segment; its bounding box is looked up at the level where it spans at most 2x2 cells.
+    __shared__ float pyr[MV_ROWS_LDS_TILES + MV_PYR_FLOATS];
+    __shared__ int lvl_off[16], lvl_w[16], lvl_h[16];
     const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     const int n_tiles = tw * th;
     const bool in_lds = n_tiles <= MV_ROWS_LDS_TILES;
+    int n_lvl = 1;
     if (in_lds) {
-        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) tmax_lds[i] = __uint_as_float(dmax_bits[MV_HDR + i]);
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) pyr[i] = __uint_as_float(dmax_bits[MV_HDR + i]);
+        if (threadIdx.x == 0) {
+            int o = 0, w = tw, h = th, l = 0;
+            for (;; ++l) {
+                lvl_off[l] = o; lvl_w[l] = w; lvl_h[l] = h;
+                if (w == 1 && h == 1) break;
+                o += w * h; w = (w + 1) >> 1; h = (h + 1) >> 1;
+            }
+            lvl_off[15] = l + 1;
+        }
         __syncthreads();
+        n_lvl = lvl_off[15];
+        for (int l = 1; l < n_lvl; ++l) {
+            const int w = lvl_w[l], h = lvl_h[l], pw = lvl_w[l - 1], ph = lvl_h[l - 1];
+            const float* __restrict__ src = pyr + lvl_off[l - 1];
+            for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+                const int y = i / w, x = i - y * w;
+                const int x1 = min(2 * x + 1, pw - 1), y1 = min(2 * y + 1, ph - 1);
+                pyr[lvl_off[l] + i] = fmaxf(fmaxf(src[2 * y * pw + 2 * x], src[2 * y * pw + x1]),
+                                            fmaxf(src[y1 * pw + 2 * x], src[y1 * pw + x1]));
+            }
+            __syncthreads();
+        }
     }
     const int lane = threadIdx.x & 63;
     // a block works on ONE window: [0, blocks_main) the frustum footprint, the rest the risky boundary rows (windows 1, 2
@@ -504,12 +579,21 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             const float ra = __builtin_amdgcn_rcpf(za), rb = __builtin_amdgcn_rcpf(zb);
             const float u0 = fx * (Ax + lo * Bx) * ra + cx, v0 = fy * (Ay + lo * By) * ra + cy;
             const float u1 = fx * (Ax + hi * Bx) * rb + cx, v1 = fy * (Ay + hi * By) * rb + cy;
-            const int tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)), tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
-            const int tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)), tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
+            int tu0 = max(0, (int)floorf((fminf(u0, u1) - 2.0f) / MV_TD)), tu1 = min(tw - 1, (int)floorf((fmaxf(u0, u1) + 2.0f) / MV_TD));
+            int tv0 = max(0, (int)floorf((fminf(v0, v1) - 2.0f) / MV_TD)), tv1 = min(th - 1, (int)floorf((fmaxf(v0, v1) + 2.0f) / MV_TD));
             float tm = 0.0f;
-            for (int tv = tv0; tv <= tv1; ++tv)
-                for (int tu = tu0; tu <= tu1; ++tu)
-                    tm = fmaxf(tm, in_lds ? tmax_lds[tv * tw + tu] : __uint_as_float(dmax_bits[MV_HDR + tv * tw + tu]));
+            if (tu1 >= tu0 && tv1 >= tv0) {
+                if (in_lds) {
+                    int l = 0;
+                    while (l + 1 < n_lvl && (tu1 - tu0 > 1 || tv1 - tv0 > 1)) { tu0 >>= 1; tu1 >>= 1; tv0 >>= 1; tv1 >>= 1; ++l; }
+                    const float* __restrict__ lv = pyr + lvl_off[l];
+                    const int w = lvl_w[l];
+                    tm = fmaxf(fmaxf(lv[tv0 * w + tu0], lv[tv0 * w + tu1]), fmaxf(lv[tv1 * w + tu0], lv[tv1 * w + tu1]));
+                } else {
+                    for (int tv = tv0; tv <= tv1; ++tv)
+                        for (int tu = tu0; tu <= tu1; ++tu) tm = fmaxf(tm, __uint_as_float(dmax_bits[MV_HDR + tv * tw + tu]));
+                }
+            }
             if (tm > 0.0f) {
                 // cam_z <= (deepest pixel + trunc) / (1 - ratio_eps), on the far side
                 clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz, eps_z);
@@ -555,14 +639,23 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
     __syncthreads();
     if (n_items == 0) return;
     unsigned pos = block_base + (unsigned)wave_total[wv] + (unsigned)(incl - n_items);
-    const unsigned head = (unsigned)rx | ((unsigned)ry << 15);
-    uint2* __restrict__ q = risky ? queue_risky : queue;
+    MvItem it;
+    it.xy = (unsigned)rx | ((unsigned)ry << 15);
+    {
+        const RowConst rc = make_row(P, (float)rx, (float)ry);
+        it.ax = rc.ax; it.ay = rc.ay; it.az = rc.az;
+        const uint64_t off = (uint64_t)((((int64_t)rx * P.dy + ry) * P.dz - slab_skip) * 4);     // slab-local byte offset
+        it.off_lo = (unsigned)off; it.off_hi = (unsigned)(off >> 32);
+        it.pad = 0u;
+    }
+    MvItem* __restrict__ q = risky ? queue_risky : queue;
     const unsigned cap = risky ? q_cap_risky : q_cap;
     for (int c = risky ? 0 : c0; c < (risky ? nch_row : c1); ++c) {
         const bool in_iv = c >= c0 && c < c1;
         if (!in_iv && !(risky && alias_chunk(c))) continue;
         const int lo_l = in_iv ? max(z0 - (c << 6), 0) : 0, hi_l = in_iv ? min(z1 - (c << 6), 64) : 0;
-        if (pos < cap) q[pos] = make_uint2(head, (unsigned)c | ((unsigned)lo_l << 16) | ((unsigned)hi_l << 22));
+        it.cw = (unsigned)c | ((unsigned)lo_l << 16) | ((unsigned)hi_l << 22);
+        if (pos < cap) q[pos] = it;
         ++pos;
     }
 }
@@ -581,6 +674,10 @@ __device__ __forceinline__ void div2_shared(float a0, float a1, float b, float& 
     x = a1 * r; t = fmaf(-b, x, a1);
     x = fmaf(t, r, x); t = fmaf(-b, x, a1);
     q1 = fmaf(t, r, x);
+}
+
+__device__ __forceinline__ bool div2_in_range(float cxv, float cyv, float czv) {
+    return czv > 1e-6f && czv < 1e3f && fabsf(cxv) < 1e3f && fabsf(cyv) < 1e3f;
 }
 
 // The voxel update proper (integrate_lanes' expression tree, Volume.py:285-334) for ONE voxel whose depth sample is known.
@@ -623,171 +720,269 @@ __device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, flo
     if (band || reset) color[idx] = new_c;
 }
 
-// Work split inside a wave.  ~85 % of the voxels a frame updates lie in FREE SPACE in front of the surface
-// (sdf > trunc): for them dist = min(1, sdf / trunc) = 1 whatever the exact sdf, and a voxel that has only ever seen
-// free space holds tsdf = 1, so its running average (1 * w_old + obs_weight * 1) / (w_old + obs_weight) is 1 again:
-// numerator and denominator are the SAME fp32 number.  Such a voxel needs no division, no correctly rounded square
-// root and no tsdf store -- only its weight moves, and not even that once it sits at the clamp.  A lane is classified
-// with a 1-ulp square root and a margin far above that error:
-//     sdf~ >  trunc + margin  and tsdf == 1  ->  free: weight update only
-//     sdf~ < -trunc - margin  or no depth    ->  untouched (the reference returns)
-//     anything else                          ->  "near": the reference's full expression tree
-// The near lanes of the U chunks a wave has in flight (a dozen per chunk: the truncation band along the row) are
-// compacted through LDS and then evaluated TOGETHER by update_voxel, so the expensive path runs on full waves, once
-// per trip, instead of once per chunk at a fifth of its lanes.  Fast path only for obs_weight > 0 without
-// re-integration (every mapping frame); otherwise every lane takes the full path.
-constexpr int MV_NEAR_FIELDS = 9;
+// pending exact-path records of one wave (< 64 kept + <= 64 new per item), field-major in LDS
+constexpr int MV_NEAR_FIELDS = 6;      // voxel index, camera point, tsdf, weight as loaded
+struct NearList {
+    float (*nb)[128];
+    int n;                 // wave-uniform fill
+};
 
-template <int U, bool RISKY, bool REINT>
-__device__ __forceinline__ void mv_chunks_body(const MvParams& P, const unsigned* __restrict__ q_count,
-                                               const uint2* __restrict__ queue, unsigned q_cap,
-                                               const float2* __restrict__ dimg, const float* __restrict__ cpk,
-                                               float* __restrict__ tsdf, float* __restrict__ weight,
-                                               float* __restrict__ color, unsigned block, unsigned n_blocks,
-                                               float (*nbuf)[MV_NEAR_FIELDS][128]) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float (*nb)[128] = nbuf[wv];                               // per wave: pending near lanes (< 64 kept + <= 64 new), field-major
-    int n_near = 0;        // wave-uniform fill of nb
-    // the reference's full update on the top min(64, n_near) pending records (one per lane)
-    auto drain = [&]() {
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS stores have landed
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        const int take = min(64, n_near), base = n_near - take;
-        if (lane < take) {
-            const int s = base + lane;
-            update_voxel(P, (int64_t)__float_as_int(nb[0][s]), nb[1][s], nb[2][s], nb[3][s], nb[4][s], nb[5][s],
-                         __float_as_int(nb[6][s]), nb[7][s], nb[8][s], cpk, tsdf, weight, color);
-        }
-        MV_STAT(6, (unsigned long long)take * (lane == 0));
-        n_near = base;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();             // reads done before the buffer is written again
-        asm volatile("" ::: "memory");
-    };
-    const unsigned n_waves = n_blocks * (blockDim.x >> 6);
-    const unsigned wave = __builtin_amdgcn_readfirstlane(block * (blockDim.x >> 6) + wv);
-    const unsigned n = min(*q_count, q_cap);
-    const bool fast = !REINT && P.obs_weight > 0.0f;
+// the reference's full update on the top min(64, n) pending records (one per lane): exact projection, depth sample, update
+__device__ __forceinline__ void near_drain(const MvParams& P, NearList& L, int lane, const float2* __restrict__ dimg,
+                                           const float* __restrict__ cpk, float* __restrict__ tsdf,
+                                           float* __restrict__ weight, float* __restrict__ color) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const int take = min(64, L.n), base = L.n - take;
+    const bool act = lane < take;
+    const int s = base + (act ? lane : 0);
+    const int64_t idx = (int64_t)__float_as_int(L.nb[0][s]);        // < 2^31 voxels (checked by the host)
+    const float cxv = L.nb[1][s], cyv = L.nb[2][s], czv = L.nb[3][s], cur = L.nb[4][s], wold = L.nb[5][s];
+    bool v = act && czv > 0.0f;
+    const bool generic = v && !div2_in_range(cxv, cyv, czv);
+    const float czs = v ? czv : 1.0f;
+    float qx, qy;
+    if (!__any(generic)) div2_shared(v ? cxv : 0.0f, v ? cyv : 0.0f, czs, qx, qy);
+    else { qx = cxv / czs; qy = cyv / czs; }                       // operands outside div2_shared's range: the compiler's division
+    const int px = f2i_rn(madd(P.K[0], qx, P.K[2]));
+    const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
+    v = v && px >= 0 && px < P.W && py >= 0 && py < P.H;
+    if (v) {
+        const int pix = py * P.W + px;
+        const float2 dl = dimg[P.dimg_colmajor ? px * P.H + py : pix];
+        update_voxel(P, idx, cxv, cyv, czv, dl.x, dl.y, pix, cur, wold, cpk, tsdf, weight, color);
+    }
+    MV_STAT(6, (unsigned long long)take * (lane == 0));
+    L.n = base;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();             // reads done before the buffer is written again
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void near_append(NearList& L, bool near_l, int lane, int idx, float cxv, float cyv, float czv,
+                                            float cur, float wold) {
+    const unsigned long long m = __ballot(near_l);
+    if (!m) return;
+    if (near_l) {
+        const int s = L.n + __popcll(m & ((1ull << lane) - 1ull));
+        L.nb[0][s] = __int_as_float(idx);
+        L.nb[1][s] = cxv; L.nb[2][s] = cyv; L.nb[3][s] = czv; L.nb[4][s] = cur; L.nb[5][s] = wold;
+    }
+    L.n += __popcll(m);
+}
+
+constexpr unsigned MV_OOB = 0x80000000u;      // a buffer offset beyond every descriptor's range: the access is dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mv_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+
+// ---- fast body (obs_weight > 0, no re-integration, exactly decoded rows)
+// Instruction budget (the kernel is bound by instruction issue, scalar and vector alike, not by memory: with every memory
+// operation removed it ran in 20 of 43 us): the volume reads are plain loads from a scalar base with a lane offset clamped
+// into the row (no descriptor to build per item), the weight store is the only operation under a lane mask, the
+// classification gather is a buffer load through ONE loop-invariant descriptor whose range check drops the lanes that
+// have no pixel, and the items are not fetched ahead (sixteen more live scalar registers spilled into vector lanes).
+template <int U>
+__device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned n, const MvItem* __restrict__ queue,
+                                               const float2* __restrict__ dimg, const float2* __restrict__ fg,
+                                               const float* __restrict__ cpk, float* __restrict__ tsdf,
+                                               float* __restrict__ weight, float* __restrict__ color, unsigned wave,
+                                               unsigned n_waves, NearList& L) {
+    const int lane = threadIdx.x & 63;
+    const float lane_f = (float)lane;
+    const __amdgpu_buffer_rsrc_t r_fg = mv_rsrc(fg, (unsigned)P.H * (unsigned)P.W * 8u);
+    // image byte offset = px * sx8 + py * sy8, formed in fp32 (exact below 2^24: the host sends H * W * 8 >= 2^24 elsewhere)
+    const float sx8 = P.dimg_colmajor ? 8.0f * (float)P.H : 8.0f, sy8 = P.dimg_colmajor ? 8.0f : 8.0f * (float)P.W;
+    const float edge = 0.5f - P.edge_eps;
+    const float hw = 0.5f * (float)(P.W - 1), hh = 0.5f * (float)(P.H - 1);      // pixel px is in the image <=> |px - hw| <= hw
     for (unsigned it = wave * U; it < n; it += n_waves * U) {
-        int64_t idx[U];
-        bool ok[U];
         float cxv[U], cyv[U], czv[U], cur[U], wold[U];
-        // ---- stage 0: the trip's U items in one scalar load (the queue is padded by U entries; an item past the end
-        //      is replaced by the trip's first).  Every load below is UNCONDITIONAL with an in-bounds address: a load under
-        //      a lane mask sits in its own basic block with its own s_waitcnt, which strings the U round trips together.
-        unsigned ixs[U], iys[U];
+        float2 fgv[U];
+        bool inside[U], exact[U];
+        int idx[U];
+        float* wp[U];
+        // ---- the trip's items (scalar loads, all issued before the first is used; an item past the end is replaced by
+        //      the trip's first and gets an empty lane interval)
+        MvItem items[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint2 item = queue[it + u];
-            ixs[u] = __builtin_amdgcn_readfirstlane(item.x); iys[u] = __builtin_amdgcn_readfirstlane(item.y);
-        }
+        for (int u = 0; u < U; ++u) items[u] = queue[it + u < n ? it + u : it];
+        // ---- stage 0: volume loads, camera point, approximate projection, classification gather.  Lane predicates are
+        //      combined with & (no short-circuit: a && here becomes a divergent branch with its scalar bookkeeping)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = it + u < n;
-            const unsigned ix = live ? ixs[u] : ixs[0], iy = live ? iys[u] : iys[0];
+            const MvItem& I = items[u];
+            const unsigned cw = (unsigned)__builtin_amdgcn_readfirstlane((int)I.cw);
+            const int c = (int)(cw & 0xffffu);
+            const int lo_l = (int)((cw >> 16) & 63u), len_l = live ? (int)((cw >> 22) & 127u) - lo_l : 0;     // hi >= lo
+            const uint64_t off = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)I.off_hi) << 32 |
+                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)I.off_lo)) + (uint64_t)c * 256u;
+            const float* __restrict__ tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(tsdf) + off);
+            wp[u] = reinterpret_cast<float*>(reinterpret_cast<char*>(weight) + off);
+            // lanes outside the row's interval read the nearest voxel inside it: the same 64-byte sectors as their
+            // neighbours, so a partial chunk costs the memory system only the sectors its interval touches
+            const unsigned lane_c = (unsigned)min(max(lane, lo_l), max(lo_l + len_l - 1, lo_l));
+            cur[u] = tp[lane_c];
+            wold[u] = wp[u][lane_c];
+            inside[u] = (unsigned)(lane - lo_l) < (unsigned)len_l;
+            idx[u] = (int)(off >> 2) + lane;
+            // camera point, exactly as the reference forms it
+            const float zf = lane_f + (float)(c << 6);
+            const float pz = madd(zf, P.voxel, P.origin[2]);
+            const float tz = pz - P.c2w[11];
+            const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, I.ax)));
+            const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, I.ay)));
+            const float az = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, I.az)));
+            cxv[u] = madd(P.c2w[8], tz, ax);
+            cyv[u] = madd(P.c2w[9], tz, ay);
+            czv[u] = madd(P.c2w[10], tz, az);
+            // approximate projection.  Its rounded pixel is the reference's unless a coordinate lies within edge_eps of a
+            // rounding boundary (bound: see edge_eps; it holds for every cz >= 1e-6, whatever cx and cy -- a quotient that
+            // overflows does so in the reference too and lands outside the image either way); those lanes, and lanes with
+            // 0 < cz < 1e-6, take the exact path
+            const float rz = __builtin_amdgcn_rcpf(czv[u]);
+            const float uu = madd(P.K[0], cxv[u] * rz, P.K[2]);
+            const float vv = madd(P.K[4], cyv[u] * rz, P.K[5]);
+            const float ur = rintf(uu), vr = rintf(vv);
+            const bool approx_ok = (fmaxf(fabsf(uu - ur), fabsf(vv - vr)) <= edge) & (czv[u] >= 1e-6f);
+            const bool in_img = (fabsf(ur - hw) <= hw) & (fabsf(vr - hh) <= hh);
+            exact[u] = inside[u] & (czv[u] > 0.0f) & !approx_ok;
+            const bool gather = inside[u] & approx_ok & in_img;
+            const unsigned goff = gather ? (unsigned)madd(ur, sx8, vr * sy8) : MV_OOB;
+            const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(r_fg, goff, 0, 0);
+            const unsigned g2x = g2[0], g2y = g2[1];        // (bit_cast of a vector element reads element 0 twice: clang 22)
+            fgv[u] = make_float2(__uint_as_float(g2x), __uint_as_float(g2y));
+            MV_STAT(2, live && lane == 0 ? 1 : 0);
+            MV_STAT(3, __popcll(__ballot(inside[u])) * (lane == 0));
+            MV_STAT(4, __popcll(__ballot(gather)) * (lane == 0));
+        }
+        // ---- stage 1: classify.  Lanes without a gather read F = G = 0: never free, always untouched.
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float n2 = madd(czv[u], czv[u], madd(cxv[u], cxv[u], cyv[u] * cyv[u]));
+            const bool free_l = n2 < fgv[u].x, one = cur[u] == 1.0f;
+            const bool free_1 = free_l & one;                              // free space and still 1: only the weight moves
+            const bool band = (n2 >= fgv[u].x) & (n2 <= fgv[u].y);         // neither provably free nor provably untouched
+            // fminf(w, 128) then "> 40 -> 40" of the reference is min(w, 40) for every input, NaN included
+            const float w_sum = wold[u] + P.obs_weight;
+            const float new_w = P.weight_clamp == 1 ? fminf(w_sum, 40.0f) : w_sum;
+            if (free_1 & (new_w != wold[u])) wp[u][(unsigned)lane] = new_w;           // tsdf stays 1 (see the header)
+            MV_STAT(5, __popcll(__ballot(free_1)) * (lane == 0));
+            const bool near_l = exact[u] | band | (free_l & !one);
+            near_append(L, near_l, lane, idx[u], cxv[u], cyv[u], czv[u], cur[u], wold[u]);
+            if (L.n >= 64) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
+        }
+    }
+}
+
+// ---- generic body: every lane of an item through the exact projection; free-space shortcut only when `fast`
+template <int U, bool RISKY, bool REINT>
+__device__ __forceinline__ void mv_chunks_generic(const MvParams& P, unsigned n, const MvItem* __restrict__ queue,
+                                                  const float2* __restrict__ dimg, const float* __restrict__ cpk,
+                                                  float* __restrict__ tsdf, float* __restrict__ weight,
+                                                  float* __restrict__ color, unsigned wave, unsigned n_waves, NearList& L,
+                                                  int64_t slab_skip) {
+    const int lane = threadIdx.x & 63;
+    const bool fast = !REINT && P.obs_weight > 0.0f;
+    for (unsigned it = wave * U; it < n; it += n_waves * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // every load below is UNCONDITIONAL with an in-bounds address (a load under a lane mask gets its own basic block
+            // and s_waitcnt, which strings the round trips together): an item past the end is replaced by the trip's first
+            const bool live = it + u < n;
+            const MvItem I = queue[live ? it + u : it];
+            const unsigned ix = (unsigned)__builtin_amdgcn_readfirstlane((int)I.xy), cw = (unsigned)__builtin_amdgcn_readfirstlane((int)I.cw);
             const int rx = ix & 0x7fff, ry = (ix >> 15) & 0x7fff;
-            const int c = iy & 0xffff, lo_l = (iy >> 16) & 63, hi_l = (iy >> 22) & 127;
+            const int c = cw & 0xffff, lo_l = (cw >> 16) & 63, hi_l = (cw >> 22) & 127;
             const int z = (c << 6) + lane;
             bool v = live && lane >= lo_l && lane < hi_l;
             if (RISKY) v = live && z < P.dz && (v || alias_zone(P, ry, z));
-            // the row's first voxel as a scalar base: per-lane addresses are base + 32-bit offsets
-            const int64_t row0 = ((int64_t)rx * P.dy + ry) * P.dz;
-            idx[u] = row0 + z;
+            const int64_t row0 = ((int64_t)rx * P.dy + ry) * P.dz - slab_skip;        // slab-local index of the row
+            const int64_t gidx = row0 + slab_skip + z;                                // global index: what the literal decode sees
             const int zc = min(z, P.dz - 1);
-            cur[u] = (tsdf + row0)[zc]; wold[u] = (weight + row0)[zc];
+            const float cur = (tsdf + row0)[zc], wold = (weight + row0)[zc];
             float fvx = (float)rx, fvy = (float)ry, fvz = (float)z;
-            if (RISKY) decode_literal(v ? (int)idx[u] : 0, P.dy, P.dz, fvx, fvy, fvz);
+            if (RISKY) decode_literal(v ? (int)gidx : 0, P.dy, P.dz, fvx, fvy, fvz);
             const RowConst rc = make_row(P, fvx, fvy);
             const float pz = madd(fvz, P.voxel, P.origin[2]);
             if (REINT) v = v && !outside_old(P, rc.px, rc.py, pz);
             const float tz = pz - P.c2w[11];
-            cxv[u] = madd(P.c2w[8], tz, rc.ax);
-            cyv[u] = madd(P.c2w[9], tz, rc.ay);
-            czv[u] = madd(P.c2w[10], tz, rc.az);
-            ok[u] = v;
+            const float cxv = madd(P.c2w[8], tz, rc.ax);
+            const float cyv = madd(P.c2w[9], tz, rc.ay);
+            const float czv = madd(P.c2w[10], tz, rc.az);
             MV_STAT(2, live && lane == 0 ? 1 : 0);
             MV_STAT(7, live && RISKY && lane == 0 ? 1 : 0);
             MV_STAT(3, __popcll(__ballot(v)) * (lane == 0));
-        }
-        // ---- stage 1: projection (correctly rounded quotients, see div2_shared), {depth, 1/lambda} gather
-        int pix[U];
-        float2 dl[U];
-        bool generic = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            generic = generic || (ok[u] && czv[u] > 0.0f && !(czv[u] > 1e-6f && czv[u] < 1e3f && fabsf(cxv[u]) < 1e3f && fabsf(cyv[u]) < 1e3f));
-        const bool any_generic = __any(generic) != 0;       // operands outside div2_shared's range: the compiler's division
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bool v = ok[u] && (czv[u] > 0.0f);
-            const float czs = v ? czv[u] : 1.0f;
-            float qx, qy;
-            if (!any_generic) div2_shared(v ? cxv[u] : 0.0f, v ? cyv[u] : 0.0f, czs, qx, qy);
-            else { qx = cxv[u] / czs; qy = cyv[u] / czs; }
-            const int px = f2i_rn(madd(P.K[0], qx, P.K[2]));
-            const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
-            v = v && px >= 0 && px < P.W && py >= 0 && py < P.H;
-            ok[u] = v;
-            MV_STAT(4, __popcll(__ballot(v)) * (lane == 0));
-            pix[u] = v ? py * P.W + px : 0;
-            const int dix = v ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0;
-            dl[u] = dimg[dix];
-        }
-        // ---- stage 2: classify; free-space lanes finish here, near lanes are appended to the wave's LDS list, which is
-        //      evaluated 64 records at a time (full waves of the expensive path, about once per sixteen chunks)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float d = dl[u].x;
-            const float norm_a = __builtin_amdgcn_sqrtf(madd(czv[u], czv[u], madd(cxv[u], cxv[u], cyv[u] * cyv[u])));
-            const float sdf_a = d - dl[u].y * norm_a;
-            // |sdf~ - sdf| <= ~2.5 ulp of max(norm, d) (1-ulp square root, two more roundings): margin = 5 ulp + 1e-7
-            const float margin = fmaf(6e-7f, norm_a + fabsf(d), 1e-7f);
-            const bool cand = ok[u] && (d > 0.0f) && (sdf_a >= -P.trunc - margin);          // else: provably untouched
-            const bool free_l = fast && cand && (sdf_a > P.trunc + margin) && (cur[u] == 1.0f);
-            const bool near_l = cand && !free_l;
-            if (free_l) {
-                float new_w = wold[u] + P.obs_weight;
-                if (P.weight_clamp == 1) {
-                    new_w = fminf(new_w, 128.0f);
-                    if (new_w > 40.0f) new_w = 40.0f;
+            bool near_l = v && czv > 0.0f;
+            if (fast) {
+                // exact pixel, then the free-space / untouched tests with a 1-ulp square root and a margin far above its error
+                const bool generic = near_l && !div2_in_range(cxv, cyv, czv);
+                const float czs = near_l ? czv : 1.0f;
+                float qx, qy;
+                if (!__any(generic)) div2_shared(near_l ? cxv : 0.0f, near_l ? cyv : 0.0f, czs, qx, qy);
+                else { qx = cxv / czs; qy = cyv / czs; }
+                const int px = f2i_rn(madd(P.K[0], qx, P.K[2]));
+                const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
+                const bool ok = near_l && px >= 0 && px < P.W && py >= 0 && py < P.H;
+                const float2 dl = dimg[ok ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0];
+                const float d = dl.x;
+                const float norm_a = __builtin_amdgcn_sqrtf(madd(czv, czv, madd(cxv, cxv, cyv * cyv)));
+                const float sdf_a = d - dl.y * norm_a;
+                // |sdf~ - sdf| <= ~2.5 ulp of max(norm, d) (1-ulp square root, two more roundings): margin = 5 ulp + 1e-7
+                const float margin = fmaf(6e-7f, norm_a + fabsf(d), 1e-7f);
+                const bool cand = ok && (d > 0.0f) && (sdf_a >= -P.trunc - margin);          // else: provably untouched
+                const bool free_l = cand && (sdf_a > P.trunc + margin) && (cur == 1.0f);
+                if (free_l) {
+                    float new_w = wold + P.obs_weight;
+                    if (P.weight_clamp == 1) {
+                        new_w = fminf(new_w, 128.0f);
+                        if (new_w > 40.0f) new_w = 40.0f;
+                    }
+                    if (new_w != wold) (weight + row0)[z] = new_w;       // tsdf stays 1 (see the header)
                 }
-                if (new_w != wold[u]) weight[idx[u]] = new_w;       // tsdf stays 1 (see above)
+                MV_STAT(5, __popcll(__ballot(free_l)) * (lane == 0));
+                near_l = cand && !free_l;
             }
-            MV_STAT(5, __popcll(__ballot(free_l)) * (lane == 0));
-            const unsigned long long m = __ballot(near_l);
-            if (m) {
-                if (near_l) {
-                    const int s = n_near + __popcll(m & ((1ull << lane) - 1ull));
-                    nb[0][s] = __int_as_float((int)idx[u]);        // < 2^31 voxels (checked by the host)
-                    nb[1][s] = cxv[u]; nb[2][s] = cyv[u]; nb[3][s] = czv[u];
-                    nb[4][s] = d; nb[5][s] = dl[u].y; nb[6][s] = __int_as_float(pix[u]);
-                    nb[7][s] = cur[u]; nb[8][s] = wold[u];
-                }
-                n_near += __popcll(m);
-                if (n_near >= 64) drain();
-            }
+            near_append(L, near_l, lane, (int)(row0 + z), cxv, cyv, czv, cur, wold);
+            if (L.n >= 64) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
         }
     }
-    while (n_near > 0) drain();
 }
 
 // one launch for both queues: blocks [0, blocks_main) pull the frustum rows' chunks, the rest the chunks of the rows next to
 // x-slab boundaries (literal index decode; a few thousand items -- a launch of their own cost 5 us behind the main one)
-template <int U, bool REINT>
-__global__ __launch_bounds__(256) void mv_chunks_kernel(MvParams P, const unsigned* __restrict__ q_counts,
-                                                        const uint2* __restrict__ queue, unsigned q_cap,
-                                                        const uint2* __restrict__ queue_risky, unsigned q_cap_risky,
-                                                        unsigned blocks_main,
-                                                        const float2* __restrict__ dimg, const float* __restrict__ cpk,
+// Residency: the grid is sized to the blocks that are resident at once (the items are dealt statically over gridDim, so a
+// block that has to wait for a slot doubles the kernel's time).  The hardware admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16))
+// 256-thread blocks per CU, which for 98+ SGPRs is one block fewer than hipOccupancyMaxActiveBlocksPerMultiprocessor
+// answers (MI355X_MICROARCH.md, "Residency and cooperative launch"): the kernel is held to 80 SGPRs, where both say 8.
+template <int U, bool FAST, bool REINT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void mv_chunks_kernel(MvParams P, const unsigned* __restrict__ q_counts,
+                                                        const MvItem* __restrict__ queue, unsigned q_cap,
+                                                        const MvItem* __restrict__ queue_risky, unsigned q_cap_risky,
+                                                        unsigned blocks_main, int64_t slab_skip,
+                                                        const float2* __restrict__ dimg, const float2* __restrict__ fg,
+                                                        const float* __restrict__ cpk,
                                                         float* __restrict__ tsdf, float* __restrict__ weight,
                                                         float* __restrict__ color) {
     __shared__ float nbuf[4][MV_NEAR_FIELDS][128];
-    if (blockIdx.x < blocks_main)
-        mv_chunks_body<U, false, REINT>(P, q_counts, queue, q_cap, dimg, cpk, tsdf, weight, color, blockIdx.x, blocks_main, nbuf);
-    else
-        mv_chunks_body<U, true, REINT>(P, q_counts + 1, queue_risky, q_cap_risky, dimg, cpk, tsdf, weight, color,
-                                       blockIdx.x - blocks_main, gridDim.x - blocks_main, nbuf);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    NearList L;
+    L.nb = nbuf[wv];
+    L.n = 0;
+    if (blockIdx.x < blocks_main) {
+        const unsigned n = min(q_counts[0], q_cap);
+        const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (unsigned)wv), n_waves = blocks_main * 4u;
+        if (FAST) mv_chunks_fast<U>(P, n, queue, dimg, fg, cpk, tsdf, weight, color, wave, n_waves, L);
+        else mv_chunks_generic<U, false, REINT>(P, n, queue, dimg, cpk, tsdf, weight, color, wave, n_waves, L, slab_skip);
+    } else {
+        const unsigned n = min(q_counts[1], q_cap_risky);
+        const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x - blocks_main) * 4u + (unsigned)wv);
+        mv_chunks_generic<U, true, REINT>(P, n, queue_risky, dimg, cpk, tsdf, weight, color, wave, (gridDim.x - blocks_main) * 4u, L,
+                                          slab_skip);
+    }
+    while (L.n > 0) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
 }
 
 // ---------------------------------------------------------------------------- simple sweeps
@@ -1071,8 +1266,9 @@ int rfx_debug_mv_stats(unsigned long long out[8], int reset) {
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 int rfx_last_hip_error(void) { return g_last_hip_error; }
 
-// workspace = [queue counter + coarse max-depth tiles | {depth, 1/lambda} image | work queue].  The queue is sized for the
-// worst case (every 64-voxel chunk of the volume), so an append can never overflow: 8 B per chunk, 51 MB at 800x800x600.
+// workspace = [queue counters + coarse max-depth tiles | {depth, 1/lambda} image | {F, G} classification image | packed
+// colour image (used when the caller hands over rgb) | work queue | queue of the rows next to x-slab boundaries].  The queue
+// is sized for the worst case (every 64-voxel chunk of the volume), so an append can never overflow: 32 B per chunk.
 static inline size_t mv_queue_capacity(int dx, int dy, int dz) { return (size_t)dx * dy * (size_t)((dz + 63) / 64); }
 constexpr size_t MV_QUEUE_PAD = 16;      // entries past the capacity that mv_chunks_kernel may read (never uses)
 // queue of the rows next to x-slab boundaries (they decode the voxel index literally): 2 * risky_rows rows per x
@@ -1083,36 +1279,36 @@ static inline size_t mv_risky_capacity(int dx, int dz) {
     return 2 * rr_max * (size_t)dx * (size_t)((dz + 63) / 64);
 }
 static inline size_t mv_image_bytes(int H, int W) { return ((size_t)H * W * sizeof(float2) + 255) / 256 * 256; }
+static inline size_t mv_cpk_bytes(int H, int W) { return ((size_t)H * W * sizeof(float) + 255) / 256 * 256; }
 
 size_t rfx_tsdf_integrate_workspace_bytes(int dx, int dy, int dz, int H, int W) {
     if (H <= 0 || W <= 0 || dx <= 0 || dy <= 0 || dz <= 0) return 0;
     const size_t tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
-    return mv_header_bytes(tiles) + mv_image_bytes(H, W) +
-           (mv_queue_capacity(dx, dy, dz) + mv_risky_capacity(dx, dz) + 2 * MV_QUEUE_PAD) * sizeof(uint2);
+    return mv_header_bytes(tiles) + 2 * mv_image_bytes(H, W) + mv_cpk_bytes(H, W) +
+           (mv_queue_capacity(dx, dy, dz) + mv_risky_capacity(dx, dz) + 2 * MV_QUEUE_PAD) * sizeof(MvItem);
 }
 
 // V1 on the x-planes [x0, x1) of a dx*dy*dz volume; tsdf/weight/color hold ONLY those planes (slab-local arrays).  Every
 // voxel is computed with its GLOBAL index and coordinates -- including the reference's fp32 index decode, which depends on
 // the global linear index -- so the slabs of a volume, integrated separately (one per GPU), are bit-identical to the whole.
-// The kernels index `base + global_idx` with base = slab pointer - x0*dy*dz: only rows inside the slab are ever touched.
+// Exactly one of color_packed / rgb255 is given: rgb255 ([H*W,3], 0..255 valued) is packed by the frame kernel.
 static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
                           const float origin[3], float voxel, const float K[9], const float c2w[16],
-                          const float* color_packed, const float* depth, int H, int W,
+                          const float* color_packed, const float* rgb255, const float* depth, int H, int W,
                           float trunc, float obs_weight, int weight_clamp, int reintegrate,
                           const float old_bnd[6], int index_decode,
                           void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    if (!tsdf || !weight || !color || !origin || !K || !c2w || !color_packed || !depth) return RFX_ERR_ARG;
+    if (!tsdf || !weight || !color || !origin || !K || !c2w || !depth) return RFX_ERR_ARG;
+    if ((color_packed == nullptr) == (rgb255 == nullptr)) return RFX_ERR_ARG;
     if (dx <= 0 || dy <= 0 || dz <= 0 || H <= 0 || W <= 0 || !(voxel > 0.0f)) return RFX_ERR_ARG;
+    if ((int64_t)H * W >= (1LL << 28)) return RFX_ERR_UNSUPPORTED;          // image byte offsets are 32-bit
     if (x0 < 0 || x1 > dx || x1 <= x0) return RFX_ERR_ARG;
     if (reintegrate && !old_bnd) return RFX_ERR_ARG;
     if ((int64_t)dx * dy * dz >= (1LL << 31)) return RFX_ERR_UNSUPPORTED;   // the reference indexes with int32
-    if (!workspace || workspace_bytes < rfx_tsdf_integrate_workspace_bytes(x1 - x0, dy, dz, H, W) || ((uintptr_t)workspace & 7)) return RFX_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < rfx_tsdf_integrate_workspace_bytes(x1 - x0, dy, dz, H, W) || ((uintptr_t)workspace & 15)) return RFX_ERR_WORKSPACE;
     if (K[0] == 0.0f || K[4] == 0.0f) return RFX_ERR_ARG;
     const bool whole = x0 == 0 && x1 == dx;
-    {
-        const int64_t skip = (int64_t)x0 * dy * dz;
-        tsdf -= skip; weight -= skip; color -= skip;
-    }
+    const int64_t skip = (int64_t)x0 * dy * dz;       // global index of the slab's first voxel
 
     MvParams P;
     for (int i = 0; i < 9; ++i) P.K[i] = K[i];
@@ -1129,6 +1325,13 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         const float hx = 0.5f / fabsf(K[0]), hy = 0.5f / fabsf(K[4]);
         P.ratio_eps = fminf(0.5f, (mvx + hx) * hx + (mvy + hy) * hy + 1e-5f);
     }
+    {   // |u~ - u| of the fast path's projection u~ = fma(fx, cx * rcp(cz), cx0) against the reference's fma(fx, cx / cz, cx0):
+        // the quotients differ by <= 2 ulp (1-ulp reciprocal, one rounding), i.e. by <= 2.4e-7 |q|, and |fx q| <= |u| + |cx0|;
+        // the two fma roundings add <= one ulp of |u| each.  In the image (|u| <= W + 1) that is <= 5e-7 (W + |cx0| + 1);
+        // taken 8x larger.  Coordinates far outside the image are not near any in-image rounding boundary that matters.
+        const float su = (float)W + fabsf(K[2]) + 1.0f, sv = (float)H + fabsf(K[5]) + 1.0f;
+        P.edge_eps = fminf(0.25f, 4e-6f * fmaxf(su, sv) + 1e-4f);
+    }
 
     // world z-axis in camera coordinates = third row of R; its image-space direction picks the layout
     P.dimg_colmajor = (fabsf(K[4] * c2w[9]) >= fabsf(K[0] * c2w[8])) ? 1 : 0;
@@ -1136,9 +1339,11 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
     unsigned* dmax_bits = reinterpret_cast<unsigned*>(workspace);
     const size_t n_tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
     float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + mv_header_bytes(n_tiles));
-    const int prepass_blocks = (int)n_tiles;
-    hipLaunchKernelGGL(mv_prepass_kernel, dim3(prepass_blocks), dim3(256), 0, st, depth, dimg,
-                       dmax_bits, H, W, K[0], K[4], K[2], K[5], P.dimg_colmajor);
+    float2* fgimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(dimg) + mv_image_bytes(H, W));
+    float* cpk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(fgimg) + mv_image_bytes(H, W));
+    const float* cpk = color_packed ? color_packed : cpk_ws;
+    hipLaunchKernelGGL(mv_frame_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, depth, rgb255, dimg, fgimg, cpk_ws, dmax_bits, H, W,
+                       K[0], K[4], K[2], K[5], trunc, P.dimg_colmajor);
     RFX_LAUNCH_CHECK();
     constexpr int TX = MV_TX, TY = MV_TY, U = MV_U;
     // Window of tiles the view frustum can touch: the frustum is convex, so its (x,y) footprint lies in
@@ -1168,8 +1373,8 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
 #ifndef MV_NO_QUEUE
     if (!P.literal_all && dx <= MV_Q_MAX_DIM && dy <= MV_Q_MAX_DIM && dz <= 64 * 65535) {
         // queue form: windows in ROWS.  [0] = the frustum footprint without the risky boundary rows, [1],[2] = those rows
-        // (every x: their alias zones are walked whatever the view); they go to a queue of their own, whose kernel
-        // instance carries the literal index decode.
+        // (every x: their alias zones are walked whatever the view); they go to a queue of their own, whose body
+        // carries the literal index decode.
         int rx0 = std::min(dx, tx0 * TX), rx1 = std::min(dx, tx1 * TX), ry0 = std::min(dy, ty0 * TY), ry1 = std::min(dy, ty1 * TY);
         rx0 = std::max(rx0, x0); rx1 = std::min(rx1, x1);              // the slab
         if (rx1 < rx0) rx1 = rx0;
@@ -1185,38 +1390,41 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         if (rows_main + rows_risky == 0) return RFX_OK;
         const int nch = (dz + 63) / 64;
         const size_t cap = mv_queue_capacity(x1 - x0, dy, dz), cap_risky = mv_risky_capacity(x1 - x0, dz);
-        uint2* queue = reinterpret_cast<uint2*>(reinterpret_cast<char*>(dimg) + mv_image_bytes(H, W));
-        uint2* queue_risky = queue + cap + MV_QUEUE_PAD;
+        MvItem* queue = reinterpret_cast<MvItem*>(reinterpret_cast<char*>(cpk_ws) + mv_cpk_bytes(H, W));
+        MvItem* queue_risky = queue + cap + MV_QUEUE_PAD;
         const unsigned q_cap = (unsigned)std::min<size_t>(cap, 0xffffffffu), q_cap_risky = (unsigned)std::min<size_t>(cap_risky, 0xffffffffu);
         const int blocks_main = (int)((rows_main + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS), blocks_risky = (int)((rows_risky + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS);
         hipLaunchKernelGGL(mv_rows_kernel, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
-                           q_cap, queue_risky, q_cap_risky, blocks_main);
+                           q_cap, queue_risky, q_cap_risky, blocks_main, skip);
         RFX_LAUNCH_CHECK();
         // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
-        // chip); small volumes need fewer
-        using Kern = void (*)(MvParams, const unsigned*, const uint2*, unsigned, const uint2*, unsigned, unsigned, const float2*, const float*,
-                              float*, float*, float*);
-        const Kern kern = P.reintegrate ? (Kern)mv_chunks_kernel<U, true> : (Kern)mv_chunks_kernel<U, false>;
-        static int resident[2] = {0, 0};       // blocks per CU x CUs, [reintegrate]; benign if raced (same value)
-        if (!resident[P.reintegrate]) {
+        // chip); small volumes need fewer.  Three instances: the fast body (every mapping frame), the generic one, and
+        // the generic one with the re-integration window test.
+        using Kern = void (*)(MvParams, const unsigned*, const MvItem*, unsigned, const MvItem*, unsigned, unsigned, int64_t, const float2*,
+                              const float2*, const float*, float*, float*, float*);
+        const int variant = P.reintegrate ? 2 : (obs_weight > 0.0f && trunc > 0.0f && (int64_t)H * W * 8 < (1 << 24) ? 0 : 1);
+        const Kern kern = variant == 2 ? (Kern)mv_chunks_kernel<U, false, true>
+                        : variant == 1 ? (Kern)mv_chunks_kernel<U, false, false> : (Kern)mv_chunks_kernel<U, true, false>;
+        static int resident[3] = {0, 0, 0};       // blocks per CU x CUs, per variant; benign if raced (same value)
+        if (!resident[variant]) {
             int per_cu = 0, dev = 0;
             hipDeviceProp_t prop;
             RFX_HIP_TRY(hipGetDevice(&dev));
             RFX_HIP_TRY(hipGetDeviceProperties(&prop, dev));
             RFX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
-            resident[P.reintegrate] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+            resident[variant] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
         }
         int blocks_risky_q = 0, blocks_main_q = 0;
         if (rows_risky > 0) {
             const int64_t max_items = std::min<int64_t>((int64_t)cap_risky, rows_risky * nch);
-            blocks_risky_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate] / 8, (max_items + 4 * U - 1) / (4 * U)));
+            blocks_risky_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[variant] / 8, (max_items + 4 * U - 1) / (4 * U)));
         }
         if (rows_main > 0) {
             const int64_t max_items = std::min<int64_t>((int64_t)cap, rows_main * nch);
-            blocks_main_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[P.reintegrate] - blocks_risky_q, (max_items + 4 * U - 1) / (4 * U)));
+            blocks_main_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[variant] - blocks_risky_q, (max_items + 4 * U - 1) / (4 * U)));
         }
         hipLaunchKernelGGL(kern, dim3(blocks_main_q + blocks_risky_q), dim3(256), 0, st, P, dmax_bits, queue, q_cap, queue_risky, q_cap_risky,
-                           (unsigned)blocks_main_q, dimg, color_packed, tsdf, weight, color);
+                           (unsigned)blocks_main_q, skip, dimg, fgimg, cpk, tsdf, weight, color);
         RFX_LAUNCH_CHECK();
         return RFX_OK;
     }
@@ -1236,7 +1444,7 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
     if (tiles == 0) return RFX_OK;
     const int blocks = (int)((tiles + 3) / 4);
     hipLaunchKernelGGL((mv_integrate_kernel<TX, TY, U>), dim3(blocks), dim3(256), 0, st, P, dimg, dmax_bits,
-                       color_packed, tsdf, weight, color);
+                       cpk, tsdf, weight, color);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1247,8 +1455,9 @@ int rfx_tsdf_integrate(float* tsdf, float* weight, float* color, int dx, int dy,
                        float trunc, float obs_weight, int weight_clamp, int reintegrate,
                        const float old_bnd[6], int index_decode,
                        void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    return integrate_slab(tsdf, weight, color, dx, dy, dz, 0, dx, origin, voxel, K, c2w, color_packed, depth, H, W, trunc, obs_weight,
-                          weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
+    if (!color_packed) return RFX_ERR_ARG;
+    return integrate_slab(tsdf, weight, color, dx, dy, dz, 0, dx, origin, voxel, K, c2w, color_packed, nullptr, depth, H, W, trunc,
+                          obs_weight, weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
 }
 
 int rfx_tsdf_integrate_slab(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
@@ -1257,8 +1466,20 @@ int rfx_tsdf_integrate_slab(float* tsdf, float* weight, float* color, int dx, in
                             float trunc, float obs_weight, int weight_clamp, int reintegrate,
                             const float old_bnd[6], int index_decode,
                             void* workspace, size_t workspace_bytes, rfx_stream stream) {
-    return integrate_slab(tsdf, weight, color, dx, dy, dz, x0, x1, origin, voxel, K, c2w, color_packed, depth, H, W, trunc, obs_weight,
-                          weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
+    if (!color_packed) return RFX_ERR_ARG;
+    return integrate_slab(tsdf, weight, color, dx, dy, dz, x0, x1, origin, voxel, K, c2w, color_packed, nullptr, depth, H, W, trunc,
+                          obs_weight, weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
+}
+
+int rfx_tsdf_integrate_rgb(float* tsdf, float* weight, float* color, int dx, int dy, int dz, int x0, int x1,
+                           const float origin[3], float voxel, const float K[9], const float c2w[16],
+                           const float* rgb255, const float* depth, int H, int W,
+                           float trunc, float obs_weight, int weight_clamp, int reintegrate,
+                           const float old_bnd[6], int index_decode,
+                           void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (!rgb255) return RFX_ERR_ARG;
+    return integrate_slab(tsdf, weight, color, dx, dy, dz, x0, x1, origin, voxel, K, c2w, nullptr, rgb255, depth, H, W, trunc,
+                          obs_weight, weight_clamp, reintegrate, old_bnd, index_decode, workspace, workspace_bytes, stream);
 }
 
 int rfx_pack_color(const float* rgb255, float* packed, int64_t n, rfx_stream stream) {

@@ -219,43 +219,6 @@ class sharded_volume(moving_volume):
         d = self.vol_dim
         return (int(d[0]) // self.world + 1) * int(d[1]) * int(d[2])
 
-    def _workspace(self, H: int, W: int):
-        from . import _lib
-        d = tuple(int(v) for v in self.vol_dim)
-        x0, x1 = self._slab()
-        key = (H, W, x1 - x0) + d[1:]
-        if self._ws_hw != key:
-            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(x1 - x0, d[1], d[2], H, W)
-            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
-            self._cpk = torch.empty(H * W, dtype=torch.float32, device=self.device)
-            self._ws_hw = key
-        return self._ws
-
-    def integrate(self, color_im, depth_im, cam_intr, cam_pose, old_bnd, obs_weight=1., reintegrate_flag=0.0, color_packed=None):
-        """V1 on this rank's slab (every rank is handed the same frame)."""
-        from . import _lib
-        from ._lib import _F3, _F6, _F9, _F16, check, farr, ptr, stream_ptr
-        lib = _lib.load()
-        H, W = depth_im.shape[-2:]
-        ws = self._workspace(H, W)
-        st = stream_ptr(self.device)
-        depth = self._dev(depth_im).reshape(-1)
-        if color_packed is None:
-            rgb = self._dev(color_im).reshape(-1, 3)
-            check(lib.rfx_pack_color(ptr(rgb), ptr(self._cpk), H * W, st), "rfx_pack_color")
-            color_packed = self._cpk
-        K = np.asarray(cam_intr.detach().cpu() if isinstance(cam_intr, torch.Tensor) else cam_intr, np.float32).reshape(-1)
-        c2w = np.asarray(cam_pose.detach().cpu() if isinstance(cam_pose, torch.Tensor) else cam_pose, np.float32).reshape(-1)
-        ob = np.zeros(6, np.float32) if old_bnd is None else np.asarray(old_bnd, np.float32).reshape(-1)
-        d = self.vol_dim
-        x0, x1 = self._slab()
-        check(lib.rfx_tsdf_integrate_slab(ptr(self.tsdf_vol_gpu), ptr(self.weight_vol_gpu), ptr(self.color_vol_gpu),
-                                          int(d[0]), int(d[1]), int(d[2]), x0, x1, farr(_F3, self.vol_origin), self.voxel_size,
-                                          farr(_F9, K), farr(_F16, c2w), ptr(color_packed), ptr(depth), H, W,
-                                          float(self.trunc_margin), float(obs_weight), int(self.weight_clamp == 1.0),
-                                          int(reintegrate_flag == 1.0), farr(_F6, ob), self.index_decode,
-                                          ptr(ws), ws.numel() * 4, st), "rfx_tsdf_integrate_slab")
-
     def update_tsdf_swap_rot_trans(self, vol_bnds, old_bnds):
         """V2 across slabs: fetch the old planes this slab reads from their owners, then gather locally."""
         import ctypes as C

@@ -77,7 +77,6 @@ class moving_volume:
         self.color_vol_gpu_back = torch.zeros(n, dtype=torch.float32, device=dev)
         self._ws = None
         self._ws_hw = None
-        self._cpk = None
 
     # ------------------------------------------------------------------ geometry helpers
     def _set_geometry(self, bnds: np.ndarray) -> None:
@@ -110,13 +109,18 @@ class moving_volume:
         """voxels per array to allocate (dist.sharded_volume: one x-slab)"""
         return int(np.prod(self.vol_dim))
 
+    def _slab(self) -> Tuple[int, int]:
+        """x-planes this object holds: all of them (dist.sharded_volume: one slab)"""
+        return 0, int(self.vol_dim[0])
+
     def _workspace(self, H: int, W: int) -> torch.Tensor:
         d = tuple(int(v) for v in self.vol_dim)
-        if self._ws_hw != (H, W) + d:
-            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(d[0], d[1], d[2], H, W)
+        x0, x1 = self._slab()
+        key = (H, W, x1 - x0) + d[1:]
+        if self._ws_hw != key:
+            nbytes = _lib.load().rfx_tsdf_integrate_workspace_bytes(x1 - x0, d[1], d[2], H, W)
             self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
-            self._cpk = torch.empty(H * W, dtype=torch.float32, device=self.device)
-            self._ws_hw = (H, W) + d
+            self._ws_hw = key
         return self._ws
 
     def _dev(self, a, dtype=torch.float32) -> torch.Tensor:
@@ -137,20 +141,23 @@ class moving_volume:
         ws = self._workspace(H, W)
         st = stream_ptr(self.device)
         depth = self._dev(depth_im).reshape(-1)
-        if color_packed is None:
-            rgb = self._dev(color_im).reshape(-1, 3)
-            check(lib.rfx_pack_color(ptr(rgb), ptr(self._cpk), H * W, st), "rfx_pack_color")
-            color_packed = self._cpk
         K = np.asarray(cam_intr.detach().cpu() if isinstance(cam_intr, torch.Tensor) else cam_intr, np.float32).reshape(-1)
         c2w = np.asarray(cam_pose.detach().cpu() if isinstance(cam_pose, torch.Tensor) else cam_pose, np.float32).reshape(-1)
         ob = np.zeros(6, np.float32) if old_bnd is None else np.asarray(old_bnd, np.float32).reshape(-1)
         d = self.vol_dim
-        check(lib.rfx_tsdf_integrate(ptr(self.tsdf_vol_gpu), ptr(self.weight_vol_gpu), ptr(self.color_vol_gpu),
-                                     int(d[0]), int(d[1]), int(d[2]), farr(_F3, self.vol_origin), self.voxel_size,
-                                     farr(_F9, K), farr(_F16, c2w), ptr(color_packed), ptr(depth), H, W,
-                                     float(self.trunc_margin), float(obs_weight), int(self.weight_clamp == 1.0),
-                                     int(reintegrate_flag == 1.0), farr(_F6, ob), self.index_decode,
-                                     ptr(ws), ws.numel() * 4, st), "rfx_tsdf_integrate")
+        x0, x1 = self._slab()
+        # the colour packing of the reference's host code (:725-728) happens inside the call (rfx_tsdf_integrate_rgb),
+        # unless the caller brings an already packed image
+        if color_packed is None:
+            img, fn, what = self._dev(color_im).reshape(-1, 3), lib.rfx_tsdf_integrate_rgb, "rfx_tsdf_integrate_rgb"
+        else:
+            img, fn, what = color_packed, lib.rfx_tsdf_integrate_slab, "rfx_tsdf_integrate_slab"
+        check(fn(ptr(self.tsdf_vol_gpu), ptr(self.weight_vol_gpu), ptr(self.color_vol_gpu),
+                 int(d[0]), int(d[1]), int(d[2]), x0, x1, farr(_F3, self.vol_origin), self.voxel_size,
+                 farr(_F9, K), farr(_F16, c2w), ptr(img), ptr(depth), H, W,
+                 float(self.trunc_margin), float(obs_weight), int(self.weight_clamp == 1.0),
+                 int(reintegrate_flag == 1.0), farr(_F6, ob), self.index_decode,
+                 ptr(ws), ws.numel() * 4, st), what)
 
     def clean_volume(self):
         """reference :656-677 (kernel :561-583)."""
