@@ -10,11 +10,13 @@ map_every = 5 frames) -- keyframe integration into the global volume plus iters 
 BA_iters (5) pose optimisation steps of the residual field (forward, backward, Adam), exactly
 the reference schedule.  All frames are rendered and resident in HBM before the timed region.
 Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @ 1 cm, ground-truth-initialised poses).
-At N>1 two things are measured, back to back.  `value` (weak scaling): every rank maps its own spatial partition of an
-N-times larger scene and exchanges the boundary planes of the global volume with its neighbours over RCCL.
-`one_scene` (strong scaling): the SAME single scene over the N GPUs -- the moving volume cut into x-slabs that all
-integrate the broadcast frame, the field replicated, each rank rendering a share of every ray batch, loss sums and
-gradients all-reduced (remixfusion_amd/dist.py, mp_slam/sharded.py); frames/s of that one camera stream.
+At N>1 the workload is ONE scene mapped by the N GPUs together (north_star: the scene volume partitioned spatially over the
+GPUs of one node) -- BASELINE config 4 (cafeteria: 1280x720, 700x700x300 voxels @ 2 cm, hash 2^21) at N = 2 and 4, config 5
+(apartment: 720x480, 1600x1600x600 voxels @ 1 cm, S = 117, a marching-cubes mesh per keyframe) at N = 8: the moving volume cut
+into x-slabs that all integrate the frame rank 0 broadcasts, the field replicated, each rank rendering a share of every ray
+batch, loss sums and gradients all-reduced over RCCL (remixfusion_amd/dist.py, mp_slam/sharded.py).  `value` = frames/s of
+that one camera stream (strong scaling: the scene does not grow with N).  `--rooms` adds, as a side field, the round-1
+figure of N independent rooms (one spatial partition of an N-times larger scene per GPU).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream) and `cpu_baseline` (the C / torch CPU oracle timed on this host's cores).
@@ -49,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="office0")
+    ap.add_argument("--config", default="office0", help="N = 1 workload (and the rooms of --rooms)")
     ap.add_argument("--first-iters", type=int, default=None, help="override mapping.first_iters (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-frames", type=int, default=3)
@@ -57,8 +59,9 @@ def parse():
     ap.add_argument("--pos-fp16", action="store_true",
                     help="opt in to OneBlob outputs rounded to fp16 on the fp16 matrix pipe (NOT the reference's precision, which "
                          "is fp32: model/encodings.py:73); reported in dtype/config")
-    ap.add_argument("--no-one-scene", action="store_true", help="N>1: skip the strong-scaling run of ONE sharded scene")
-    ap.add_argument("--one-scene-timeout", type=float, default=300.0, help="N>1: seconds the strong-scaling run may take")
+    ap.add_argument("--rooms", action="store_true", help="N>1: also time N independent rooms (one per GPU), reported as a side field")
+    ap.add_argument("--one-scene-timeout", type=float, default=900.0, help="N>1: seconds the sharded run may take before the watchdog ends it")
+    ap.add_argument("--sharded-config", default=None, help="N>1: synthetic config of the ONE scene (default: cafeteria, apartment at N >= 8)")
     ap.add_argument("--no-mv-stream", action="store_true", help="V1 on the mapper's stream instead of a stream of its own (A/B)")
     ap.add_argument("--stagewise-every", type=int, default=-1,
                     help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
@@ -167,20 +170,94 @@ def cpu_baseline(cfg, frame, model_points: int):
             "v1_seconds": round(t_v1, 3), "field_iter_seconds_scaled": round(t_iter, 2)}
 
 
-def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
+def field_rooflines(summ, cfg, merged_scatter=True):
+    """rooflines of the field kernels from HIP-event timings of their entry points (KernelTimer.summary())."""
+    out = {}
+
+    def mfma_roofline(name, flop_per_point, point_arg_index):
+        cnt, ms, evs = summ[name]
+        pts = float(np.mean([e[2][point_arg_index] for e in evs]))
+        ach = flop_per_point * pts / (ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "points_per_launch": int(pts),
+                "avg_ms": round(ms, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+
+    if "rfx_field_forward" in summ:
+        out["field_forward"] = mfma_roofline("rfx_field_forward", MLP_FLOP_PER_POINT, 2)
+    chain_name = next((k for k in ("rfx_field_backward_chain_weights", "rfx_field_backward_chain") if k in summ), None)
+    if chain_name:
+        # recompute-forward + dX chain (the map phase runs the _weights variant: of dX1 only d_emb); counted as one
+        # forward's FLOPs of algorithmic work; dW is the _weights stage
+        out["field_backward_chain"] = mfma_roofline(chain_name, MLP_FLOP_PER_POINT, 2)
+    if "rfx_field_backward_weights" in summ:
+        out["field_backward_weights"] = mfma_roofline("rfx_field_backward_weights", MLP_FLOP_PER_POINT, 0)
+    scat = "rfx_field_backward_scatter_merged" if "rfx_field_backward_scatter_merged" in summ else "rfx_field_backward_scatter"
+    if scat in summ:
+        # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered (SURVEY 8d);
+        # the merged call scatters the ray samples AND the TV lattice points in one sweep
+        cnt, ms, evs = summ[scat]
+        pts = float(np.mean([e[2][2] + (e[2][5] if scat.endswith("merged") else 0) for e in evs]))
+        nbytes = pts * (12 + 128 + 1024)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        f64 = cfg["grid"]["hash_size"] <= 17
+        out["field_backward_scatter"] = {
+            "kernel": f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})", "bound": "hbm", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "points_per_launch": int(pts), "avg_ms": round(ms, 4),
+            "note": "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
+                    "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
+                    "non-zero entry; bound by LDS atomics / index arithmetic, not HBM",
+            # algorithmic adds = points x 16 levels x 8 corners x 2 features, priced against the LDS atomic of the
+            # accumulator type this table size uses (tools/micro/lds_atomic.hip: a full-wave ds_add_f64 retires in 19
+            # clocks per CU, ds_add_f32 in 169; x 256 CUs x 2.4 GHz)
+            "lds_atomic": {"accumulator": "f64" if f64 else "f32", "algorithmic_lane_adds": int(pts * 256),
+                           "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
+                           "peak_per_s_measured": 2.07e12 if f64 else 2.03e11,
+                           "frac": round(pts * 256 / (ms * 1e-3) / (2.07e12 if f64 else 2.03e11), 3)}}
+    return out
+
+
+FIELD_ENTRY_POINTS = ("rfx_tsdf_integrate_rgb", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_chain_inputs",
+                      "rfx_field_backward_chain_weights", "rfx_field_backward_weights", "rfx_field_backward_scatter",
+                      "rfx_field_backward_scatter_merged", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
+                      "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward", "rfx_mapping_loss_forward",
+                      "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward")
+
+
+def wrap_entry_points(timer, lib):
+    for name in FIELD_ENTRY_POINTS:
+        timer.wrap(lib, name, "rfx_tsdf_integrate" if name == "rfx_tsdf_integrate_rgb" else None)
+    # the optimisation steps run the forward / chain pair that shares its hash lookups (include/rfx.h): same work items,
+    # reported under the un-suffixed names (points per launch = argument 2 either way)
+    timer.wrap(lib, "rfx_field_forward_stash", "rfx_field_forward")
+    for name in ("rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights"):
+        timer.wrap(lib, name + "_stashed", name)
+
+
+def sharded_workload(args, world):
+    return args.sharded_config or ("apartment" if world >= 8 else "cafeteria")
+
+
+def run_one_scene(args, dist, rank, world, device, timer):
     """frames/s of ONE camera stream mapped by `world` GPUs together (remixfusion_amd/dist.py): the moving volume in
     x-slabs, every rank integrating the frame rank 0 broadcast; keyframes integrated into every replica of the global
-    volume; each BA iteration's ray batch shared out, loss sums and gradients all-reduced.  Same barrier / max-over-ranks
-    timing as the main line."""
+    volume; each BA iteration's ray batch shared out, loss sums and gradients all-reduced.  Barrier +
+    torch.cuda.synchronize() on both sides of the timed region, elapsed = max over ranks."""
+    from remixfusion_amd.config import synthetic_config
     from remixfusion_amd.dist import ShardedPipeline, broadcast_
+    name = sharded_workload(args, world)
+    cfg = synthetic_config(name)
     if args.first_iters is not None:
         cfg["mapping"]["first_iters"] = args.first_iters
     cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
     if args.pos_fp16:
         cfg["pos"]["fp16_opt_in"] = True
+    cfg["data"]["output"] = os.path.join(ROOT, "gpurun_out", "bench_meshes")      # config 5 writes a mesh per keyframe
+    n_frames = 1 + args.warmup + args.steps
     pipe = ShardedPipeline(cfg, dist, rank, world, device=device, n_frames=n_frames + 8, seed=0)
     frames = pipe.prefetch(list(range(n_frames)))            # rank 0 renders, the others receive (resident before timing)
     pipe.start(frames[0])
+    direct = pipe.mapper._direct_iterations()
     for i in range(1, 1 + args.warmup):
         pipe.step(i, frames[i])
 
@@ -190,6 +267,8 @@ def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
         torch.cuda.synchronize()
 
     barrier()
+    timer.enabled = True
+    it0 = dict(direct.iterations)
     t0 = time.perf_counter()
     for i in range(1 + args.warmup, n_frames):
         # the camera is rank 0: in the timed loop the frame's depth and colour travel to the other ranks (16 H W bytes)
@@ -198,47 +277,121 @@ def run_one_scene(args, cfg, dist, rank, world, device, n_frames):
         pipe.step(i, frames[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    timer.enabled = False
     tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
+    iters = {k: direct.iterations[k] - it0[k] for k in it0}
     x0, x1 = pipe.mv._slab()
-    return {"value": round(args.steps / elapsed, 2), "unit": "frames/s", "scaling": "strong", "n_gpus": world,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "workload": "the N = 1 scene and camera stream, unchanged, on all GPUs together",
-            "partition": f"moving volume in {world} x-slabs of {x1 - x0} planes (every rank integrates the broadcast frame, no voxel "
-                         "exchange; P2P plane exchange when the volume moves); residual field + global volume replicated, ray "
-                         "batches shared out, all-reduce of 64 B of loss sums and of the gradients per iteration",
-            "collectives_per_frame": "broadcast 16*H*W B (depth + rgb); per BA iteration all-reduce 64 B + gradients "
-                                     f"({int(pipe.model.embed_res_fn.params.numel() * 4 / 1e6 * 10) / 10} MB hash table, 21 KB decoder)"}
+    cam, tr, m = cfg["cam"], cfg["training"], cfg["mapping"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    hash_mb = int(pipe.model.embed_res_fn.params.numel() * 4 / 1e6 * 10) / 10
+    meshes = "" if cfg["mesh"]["only_final"] else f", a marching-cubes mesh every {cfg['mesh']['vis']} frames (rank 0)"
+    info = {"workload": f"{name} (BASELINE config {'5' if name == 'apartment' else '4' if name == 'cafeteria' else '?'}), ONE scene on "
+                        f"{world} GPUs: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume {'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ "
+                        f"{cfg['volume']['voxel_size']} m in {world} x-slabs of {x1 - x0} planes, GBV 200^3 + hash 2^{cfg['grid']['hash_size']} "
+                        f"x16 levels replicated, {S} samples/ray, {m['iters']} map + {m['BA_iters']} pose iters every {m['map_every']} frames"
+                        + meshes,
+            "partition": "every rank integrates the frame rank 0 broadcasts into its x-slab (no voxel exchange; point-to-point plane "
+                         "exchange when the volume follows the camera); each rank renders rays r, r + N, ... of every batch; loss sums "
+                         "(64 B) and gradients all-reduced, identical Adam step on every replica",
+            "collectives_per_frame": f"broadcast 16*H*W B (depth + rgb); per BA iteration all-reduce 64 B + gradients ({hash_mb} MB hash "
+                                     "table, 21 KB decoder)",
+            "backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (rehearsal: device tensors staged through the host)"),
+            "unused_gradients": bool(args.unused_gradients), "pos_fp16_opt_in": bool(args.pos_fp16)}
+    return elapsed, iters, cfg, info
 
 
-def guarded_one_scene(args, cfg, dist, rank, world, device, n_frames, out):
-    """run_one_scene under a watchdog thread.  A stalled collective cannot be interrupted from Python, so on a timeout the
-    thread itself prints rank 0's line (`out`, with the reason under "one_scene") and ends the process with a NON-ZERO
-    status (3) on every rank: a hang must not read as success.  An exception on this rank is reported in the JSON line
-    (rank 0) or on stderr (other ranks) and the process also ends with status 3 once the line is out: the peers are
-    inside a collective this rank will never join, so they end through their own watchdogs.  Nothing is restarted."""
+def run_rooms(args, dist, rank, world, device):
+    """side figure (--rooms): every rank maps its own spatial partition of an N-times larger scene and exchanges the ghost
+    planes of the global volume with its neighbours (the round-1 multi-GPU form): total frames/s of the N rooms."""
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.dist import make_shard
+    from remixfusion_amd.pipeline import MappingPipeline
+    cfg = synthetic_config(args.config)
+    if args.first_iters is not None:
+        cfg["mapping"]["first_iters"] = args.first_iters
+    shard = make_shard(cfg, rank, world, dist)
+    n_frames = 1 + args.warmup + args.steps
+    pipe = MappingPipeline(shard.config, device=device, n_frames=n_frames + 8, seed=rank, shard=shard)
+    frames = pipe.prefetch(list(range(n_frames)))
+    pipe.start(frames[0])
+    for i in range(1, 1 + args.warmup):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1 + args.warmup, n_frames):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    tt = torch.tensor([time.perf_counter() - t0], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {"value": round(args.steps * world / float(tt.item()), 2), "unit": "frames/s (sum over N independent rooms)",
+            "workload": f"{args.config}: one room per GPU, ghost planes of the global volume exchanged per keyframe"}
+
+
+def main_sharded(args, dist, rank, world, device):
+    """N > 1: the one-scene run under a watchdog thread.  A stalled collective cannot be interrupted from Python, so on a
+    timeout the thread prints a line saying so (rank 0: the JSON line with "error") and ends the process with status 3 on
+    every rank: a hang never reads as success.  An exception on one rank is reported the same way; its peers are inside a
+    collective that rank will never join and end through their own watchdogs.  Nothing is restarted."""
     import threading
+    from remixfusion_amd import _lib
     done = threading.Event()
+    base = {"metric": "RGB-D frames/sec mapping (640x480, 1cm TSDF)", "value": None, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": {"workload": sharded_workload(args, world)}}
 
-    def watchdog():
-        if done.wait(args.one_scene_timeout):
-            return
-        reason = f"rank {rank}: one-scene run did not finish within {args.one_scene_timeout} s (stalled collective?)"
+    def fail(reason):
         print("[bench] " + reason, file=sys.stderr, flush=True)
-        if out is not None:
-            out["one_scene"] = {"error": reason}
+        if rank == 0:
+            out = dict(base)
+            out["error"] = reason
             print(json.dumps(out), flush=True)
         os._exit(3)
 
+    def watchdog():
+        if not done.wait(args.one_scene_timeout):
+            fail(f"rank {rank}: the sharded run did not finish within {args.one_scene_timeout} s (stalled collective?)")
+
     threading.Thread(target=watchdog, daemon=True).start()
     try:
-        res = run_one_scene(args, cfg, dist, rank, world, device, n_frames)
-    except Exception as e:          # noqa: BLE001 -- reported in the JSON line
-        res = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:400]}
-        print("[bench] one-scene run failed: " + res["error"], file=sys.stderr, flush=True)
+        lib = _lib.load()
+        timer = KernelTimer()
+        wrap_entry_points(timer, lib)
+        timer.every = 4
+        elapsed, iters, cfg, info = run_one_scene(args, dist, rank, world, device, timer)
+        rooms = run_rooms(args, dist, rank, world, device) if args.rooms else None
+    except Exception as e:          # noqa: BLE001 -- reported, then a non-zero exit
+        import traceback
+        traceback.print_exc()
+        fail(f"rank {rank}: {type(e).__name__}: {e}"[:400])
     done.set()
-    return res
+    if rank == 0:
+        summ = timer.summary()
+        per_kernel = {k: {"calls_timed": c, "avg_ms": round(ms, 4), "median_ms": round(timer.spread[k][0], 4), "max_ms": round(timer.spread[k][1], 4),
+                          "outliers_dropped": timer.spread[k][2]} for k, (c, ms, _) in summ.items()}
+        rl = field_rooflines(summ, cfg)
+        # dominant entry point of rank 0's share by summed device time (every 4th call was timed)
+        step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
+        dominant = max(step_kernels, key=lambda k: step_kernels[k][0] * step_kernels[k][1]) if step_kernels else None
+        key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
+               "rfx_field_backward_chain_weights": "field_backward_chain", "rfx_field_backward_chain_inputs": "field_backward_chain",
+               "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
+               "rfx_field_backward_scatter_merged": "field_backward_scatter"}.get(dominant)
+        roofline = rl.get(key) if key else None
+        if roofline is None and rl:
+            roofline = max(rl.values(), key=lambda r: r["avg_ms"])
+        out = dict(base)
+        out.update({"value": round(args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                    "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32",
+                    "config": info, "roofline": roofline, "rooflines": rl, "kernels": per_kernel, "dominant_call": dominant,
+                    "iterations_timed": iters, "cpu_baseline": None,
+                    "note": "rooflines are rank 0's share of each launch (1/N of the batch); cpu_baseline is reported at N = 1 only"})
+        if rooms is not None:
+            out["independent_rooms"] = rooms
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -262,23 +415,16 @@ def main():
             dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
+    if world > 1:
+        return main_sharded(args, dist, rank, world, device)
+
     from remixfusion_amd import _lib
     from remixfusion_amd.config import synthetic_config
-    from remixfusion_amd.dist import make_shard
     from remixfusion_amd.pipeline import MappingPipeline
 
     lib = _lib.load()
     timer = KernelTimer()
-    for name in ("rfx_tsdf_integrate", "rfx_field_forward", "rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights", "rfx_field_backward_weights",
-                 "rfx_field_backward_scatter", "rfx_field_backward_scatter_merged", "rfx_field_backward_dx", "rfx_render_rays", "rfx_gbv_integrate",
-                 "rfx_grid_encode_forward", "rfx_grid_encode_backward", "rfx_composite_forward",
-                 "rfx_mapping_loss_forward", "rfx_mapping_loss_backward", "rfx_tv_forward", "rfx_tv_backward"):
-        timer.wrap(lib, name)
-    # the optimisation steps run the forward / chain pair that shares its hash lookups (include/rfx.h): same work items,
-    # reported under the un-suffixed names (points per launch = argument 2 either way)
-    timer.wrap(lib, "rfx_field_forward_stash", "rfx_field_forward")
-    for name in ("rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights"):
-        timer.wrap(lib, name + "_stashed", name)
+    wrap_entry_points(timer, lib)
 
     cfg = synthetic_config(args.config)
     if args.first_iters is not None:
@@ -289,9 +435,7 @@ def main():
     if args.no_mv_stream:
         cfg.setdefault("pipeline", {})["mv_stream"] = False
     n_frames = 1 + args.warmup + args.steps
-    shard = make_shard(cfg, rank, world, dist) if world > 1 else None
-    if shard is not None:
-        cfg = shard.config
+    shard = None
     if not args.no_process_warmup:
         # Process-level warm-up, independent of --warmup: a throwaway pipeline of the same configuration runs two mapper
         # steps (one-call and stage-by-stage issue, both phases) and one fused render, so that code-object loads, the
@@ -395,19 +539,6 @@ def main():
         render = rays_d.shape[0] * args.render_frames / (time.perf_counter() - t1)
         timer.enabled = False
 
-    # ---- N > 1: ONE scene over the N GPUs (strong scaling): same stream, same schedule as the N = 1 workload.  It runs
-    # LAST and under a watchdog (guarded_one_scene): if its collectives ever stall, the weak-scaling line assembled below
-    # is still printed.  Ranks other than 0 go straight into it and wait there for rank 0.
-    one_scene = None
-    want_one_scene = dist is not None and not args.no_one_scene
-
-    if rank != 0:
-        if want_one_scene:
-            guarded_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames, None)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
     # ---- roofline of the dominant kernel (by summed device time over the timed region)
     summ = timer.summary()
     cam, tr = cfg["cam"], cfg["training"]
@@ -438,51 +569,7 @@ def main():
             launches[k] = iters["map"] + iters["pose"]
     dominant = max(step_kernels, key=lambda k: launches[k] * step_kernels[k][1]) if step_kernels else None
     roofline = None
-    extra_rooflines = {}
-
-    def mfma_roofline(name, flop_per_point, point_arg_index):
-        cnt, ms, evs = summ[name]
-        pts = float(np.mean([e[2][point_arg_index] for e in evs]))
-        ach = flop_per_point * pts / (ms * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "points_per_launch": int(pts),
-                "avg_ms": round(ms, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
-
-    if "rfx_field_forward" in summ:
-        extra_rooflines["field_forward"] = mfma_roofline("rfx_field_forward", MLP_FLOP_PER_POINT, 2)
-    chain_name = next((k for k in ("rfx_field_backward_chain_weights", "rfx_field_backward_chain") if k in summ), None)
-    if chain_name:
-        # recompute-forward + dX chain (the map phase runs the _weights variant: of dX1 only d_emb); counted as one
-        # forward's FLOPs of algorithmic work; dW is the _weights stage
-        extra_rooflines["field_backward_chain"] = mfma_roofline(chain_name, MLP_FLOP_PER_POINT, 2)
-    if "rfx_field_backward_weights" in summ:
-        extra_rooflines["field_backward_weights"] = mfma_roofline("rfx_field_backward_weights", MLP_FLOP_PER_POINT, 0)
-    scat = "rfx_field_backward_scatter_merged" if "rfx_field_backward_scatter_merged" in summ else "rfx_field_backward_scatter"
-    if scat in summ:
-        # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered;
-        # the merged call scatters the ray samples AND the TV lattice points in one sweep
-        cnt, ms, evs = summ[scat]
-        pts = float(np.mean([e[2][2] + (e[2][5] if scat.endswith("merged") else 0) for e in evs]))
-        nbytes = pts * (12 + 128 + 1024)
-        ach = nbytes / (ms * 1e-3) / 1e9
-        extra_rooflines["field_backward_scatter"] = {"kernel": f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})",
-                                                     "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                                     "points_per_launch": int(pts), "avg_ms": round(ms, 4),
-                                                     "note": "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
-                                                             "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
-                                                             "non-zero entry; bound by LDS atomics / index arithmetic, not HBM",
-                                                     # algorithmic adds = points x 16 levels x 8 corners x 2 features, priced against the
-                                                     # LDS atomic of the accumulator type this table size uses (tools/micro/lds_atomic.hip:
-                                                     # a full-wave ds_add_f64 retires in 19 clocks per CU, ds_add_f32 in 169; x 256 CUs x 2.4 GHz).
-                                                     # The register run accumulation merges adds of consecutive points in one cell before
-                                                     # they reach LDS, so the issued count is lower than the algorithmic one.
-                                                     "lds_atomic": (lambda f64: {"accumulator": "f64" if f64 else "f32",
-                                                                                 "algorithmic_lane_adds": int(pts * 256),
-                                                                                 "achieved_per_s": round(pts * 256 / (ms * 1e-3), 0),
-                                                                                 "peak_per_s_measured": 2.07e12 if f64 else 2.03e11,
-                                                                                 "frac": round(pts * 256 / (ms * 1e-3) / (2.07e12 if f64 else 2.03e11), 3)})(
-                                                         cfg["grid"]["hash_size"] <= 17)}
+    extra_rooflines = field_rooflines(summ, cfg)
     if "rfx_render_rays" in summ:
         cnt, ms, evs = summ["rfx_render_rays"]
         pts = float(evs[0][2][6]) * S
@@ -512,7 +599,7 @@ def main():
         if uc is not None:
             nbytes = 16 * uc[0] + 8 * uc[1] + 8 * cam["H"] * cam["W"]
             ach = nbytes / (ms * 1e-3) / 1e9
-            extra_rooflines["tsdf_integrate"] = {"kernel": "rfx_tsdf_integrate (mv_prepass + mv_rows + mv_chunks kernels)", "bound": "hbm",
+            extra_rooflines["tsdf_integrate"] = {"kernel": "rfx_tsdf_integrate_rgb (mv_frame + mv_rows + mv_chunks kernels)", "bound": "hbm",
                                                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                                  "updated_voxels": int(uc[0]), "colour_voxels": int(uc[1]),
@@ -524,21 +611,21 @@ def main():
                     "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
                     "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # HBM traffic per launch: NOT measured by this run (PMC counters need rocprofv3 passes of their own).  The figure is
-    # taken from the committed summary of those passes, profiles/r2_pmc_traffic.json (tools/summarize_pmc.py), and tagged
+    # taken from the committed summary of those passes, profiles/r3_pmc_traffic.json (tools/summarize_pmc.py), and tagged
     # with the commit the passes ran at; it stays null when that file does not cover the kernel.
     try:
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
         pmc, tag = pmc_all.get("kernels", {}), pmc_all.get("measured_at_commit", "unknown")
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
                         ("field_forward", ("rfx::field_forward_kernel<false, true>",)),
                         ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false, true>",)),
                         ("field_backward_weights", ("rfx::field_dw_recompute_kernel", "rfx::field_dw_reduce_kernel")),
                         ("render_rays", ("rfx::render_rays_kernel<false>",)),
-                        ("tsdf_integrate", ("rfx::mv_chunks_kernel", "rfx::mv_rows_kernel", "rfx::mv_prepass_kernel"))):
+                        ("tsdf_integrate", ("rfx::mv_chunks_kernel", "rfx::mv_rows_kernel", "rfx::mv_frame_kernel"))):
             keys = [k for k in pmc if any(kn in k for kn in kns)]
             if rk in extra_rooflines and keys:
                 extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes"] for k in keys))
-                extra_rooflines[rk]["traffic_source"] = (f"profiles/r2_pmc_traffic.json, rocprofv3 --pmc passes at commit {tag} (not this run): "
+                extra_rooflines[rk]["traffic_source"] = (f"profiles/r3_pmc_traffic.json, rocprofv3 --pmc passes at commit {tag} (not this run): "
                                                          "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B) + WRITE_SIZE; " + " + ".join(keys))
     except Exception:
         pass
@@ -572,17 +659,13 @@ def main():
                    "streams": "V1 on its own HIP stream, concurrent with the mapper" if getattr(pipe, "mv_stream", None) is not None else "one stream",
                    "note": "pose iterations step only the pose MLP (reference mapper.py:494-499); the map gradients its backward also "
                            "produces and zeroes are computed only with --unused-gradients (same parameters and poses either way)",
-                   "partition": "one spatial scene partition per GPU" if world > 1 else "single volume"},
+                   "partition": "single volume"},
         "render_rays_per_s": round(render, 1) if render else None,
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,
         "iterations_timed": iters,
         "cpu_baseline": base,
     }
-    if want_one_scene:
-        out["one_scene"] = guarded_one_scene(args, synthetic_config(args.config), dist, rank, world, device, n_frames, out)
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -124,6 +124,16 @@ int rfx_tsdf_trilerp(const float* tsdf, const float* weight, const float* color,
                      rfx_stream stream);
 
 /* V4: replaces `filter_tsdf` model/Volume.py:462-487 (host :857-881). */
+/* V3 on one x-slab [x0, x1) of the volume (one GPU of several; dx, dy, dz, origin describe the WHOLE volume, tsdf/color hold
+ * the slab's planes).  A point belongs to the slab that owns the plane of its lower corner (points outside the volume:
+ * to the slab with x0 = 0, which writes the reference's default record); that slab writes out5[p] and inside[p] = 1, the
+ * others leave out5[p] alone and write inside[p] = 0.  tsdf_halo / color_halo: plane x1 ([dy*dz] each, from the right
+ * neighbour -- the 1-plane halo of SURVEY 8e), NULL for the last slab.  Same arithmetic as rfx_tsdf_trilerp on the whole
+ * volume: the owning slab's record is bit-identical to it. */
+int rfx_tsdf_trilerp_slab(const float* tsdf, const float* color, int dx, int dy, int dz, int x0, int x1,
+                          const float* tsdf_halo, const float* color_halo, const float origin[3], float voxel,
+                          const float* pts, int64_t n, float* out5, uint8_t* inside, rfx_stream stream);
+
 int rfx_tsdf_filter(float* tsdf, float* weight, float* color, int64_t n, float weight_threshold,
                     rfx_stream stream);
 

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "rfx_tsdf_trilerp": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _P, _l, _P, _P]),
     "rfx_tsdf_integrate_rgb": (_i, [_P, _P, _P, _i, _i, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
                                      _i, _P, _sz, _P]),
+    "rfx_tsdf_trilerp_slab": (_i, [_P, _P, _i, _i, _i, _i, _i, _P, _P, _F3, _f, _P, _l, _P, _P, _P]),
     "rfx_tsdf_filter": (_i, [_P, _P, _P, _l, _f, _P]),
     "rfx_tsdf_truncated_pc": (_i, [_P, _P, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _i, _P]),
     "rfx_gbv_integrate": (_i, [_P, _P, _i, _F6, _F9, _P, _P, _P, _i, _i, _f, _f, _P]),

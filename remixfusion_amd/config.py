@@ -134,6 +134,9 @@ _OVERRIDES: Dict[str, Dict[str, Any]] = {
                                "n_range_d": 21, "c_trunc": 0.25, "trunc": 0.06, "rgb_missing": 0.0},
                   "volume": {"voxel_size": 0.01, "trunc": 0.06, "x_config": _axis(8), "y_config": _axis(8),
                              "z_config": _axis(3)},
+                  # BASELINE config 5: "online marching-cubes mesh extract per keyframe" = the in-loop export of the reference
+                  # (mp_slam/mapper.py:912-918) switched on at the keyframe rate
+                  "mesh": {"vis": 5, "only_final": 0},
                   "synthetic": {"room": [[-10, 10], [-5, 5], [0, 3]]}},
     # north-star target workload (SURVEY 8d "stress"): a (10 m)^3 scene at 1 cm on one GPU -- 1000^3 voxels, 12 GB + back
     # buffers; field and schedule as cfg 2

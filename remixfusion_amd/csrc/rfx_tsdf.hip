@@ -1065,10 +1065,15 @@ __global__ __launch_bounds__(256) void mv_shift_kernel(ShiftParams P, float* __r
 struct VolView { int dx, dy, dz; float origin[3]; float voxel; };
 
 // V3: one thread per query point; accumulators are double like the reference's `auto x = 0.0`.
-__global__ __launch_bounds__(256) void mv_trilerp_kernel(VolView V, const float* __restrict__ tsdf,
+// Slab form (one GPU of several holds the x-planes [x0, x1) of the volume): every coordinate is formed from the WHOLE
+// volume's origin, so a point gets the very cell and weights it gets on one GPU; the point belongs to the rank that owns
+// the plane of its lower corner, which reads the upper plane from its own slab or, at its last plane, from the one-plane
+// halo its right neighbour sent (tsdf_halo / color_halo = plane x1).  inside[p] = 1 where this rank produced the result.
+__global__ __launch_bounds__(256) void mv_trilerp_kernel(VolView V, int x0, int x1, const float* __restrict__ tsdf,
                                                          const float* __restrict__ color,
+                                                         const float* __restrict__ tsdf_halo, const float* __restrict__ color_halo,
                                                          const float* __restrict__ pts, int64_t n,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, unsigned char* __restrict__ inside) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
@@ -1079,23 +1084,31 @@ __global__ __launch_bounds__(256) void mv_trilerp_kernel(VolView V, const float*
     const float yo = madd((float)ly, V.voxel, V.origin[1]);
     const float zo = madd((float)lz, V.voxel, V.origin[2]);
     float* o = out + p * 5;
+    const bool whole = x0 == 0 && x1 == V.dx;
     if (lx < 0 || lx >= V.dx - 1 || ly < 0 || ly >= V.dy - 1 || lz < 0 || lz >= V.dz - 1) {
-        o[0] = 1.0f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f;
+        // outside the volume: the reference's default record.  In slab form the first rank reports it (one owner per point)
+        const bool mine = whole || x0 == 0;
+        if (inside) inside[p] = mine ? 1 : 0;
+        if (mine) { o[0] = 1.0f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
         return;
     }
+    if (lx < x0 || lx >= x1) { if (inside) inside[p] = 0; return; }
+    if (inside) inside[p] = 1;
     const float u = (x - xo) / V.voxel, v = (y - yo) / V.voxel, w = (z - zo) / V.voxel;
     double t = 0.0, cb = 0.0, cg = 0.0, cr = 0.0;
     float t_low = 0.f;
+    const int64_t plane = (int64_t)V.dy * V.dz;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int64_t id = (int64_t)(lz + k) + (int64_t)(ly + j) * V.dz + (int64_t)(lx + i) * V.dy * V.dz;
-                const float tv = tsdf[id];
+                const int64_t in_plane = (int64_t)(lz + k) + (int64_t)(ly + j) * V.dz;
+                const bool halo = lx + i >= x1;                       // only i = 1 at the slab's last plane
+                const float tv = halo ? tsdf_halo[in_plane] : tsdf[in_plane + (int64_t)(lx + i - x0) * plane];
                 if (!i && !j && !k) t_low = tv;
-                const float cc = color[id];
+                const float cc = halo ? color_halo[in_plane] : color[in_plane + (int64_t)(lx + i - x0) * plane];
                 const float b = floorf(cc / 65536.0f);
                 const float g = floorf((cc - b * 65536.0f) / 256.0f);
                 const float r = floorf(cc - b * 65536.0f - g * 256.0f);
@@ -1570,8 +1583,23 @@ int rfx_tsdf_trilerp(const float* tsdf, const float* weight, const float* color,
     if (n == 0) return RFX_OK;
     VolView V; V.dx = dx; V.dy = dy; V.dz = dz; V.voxel = voxel;
     for (int i = 0; i < 3; ++i) V.origin[i] = origin[i];
-    hipLaunchKernelGGL(mv_trilerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), V, tsdf,
-                       color, pts, n, out5);
+    hipLaunchKernelGGL(mv_trilerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), V, 0, dx, tsdf,
+                       color, (const float*)nullptr, (const float*)nullptr, pts, n, out5, (unsigned char*)nullptr);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_tsdf_trilerp_slab(const float* tsdf, const float* color, int dx, int dy, int dz, int x0, int x1,
+                          const float* tsdf_halo, const float* color_halo, const float origin[3], float voxel,
+                          const float* pts, int64_t n, float* out5, uint8_t* inside, rfx_stream stream) {
+    if (!tsdf || !color || !origin || !pts || !out5 || !inside || n < 0) return RFX_ERR_ARG;
+    if (dx <= 0 || dy <= 0 || dz <= 0 || !(voxel > 0.0f) || x0 < 0 || x1 > dx || x1 <= x0) return RFX_ERR_ARG;
+    if (x1 < dx && (!tsdf_halo || !color_halo)) return RFX_ERR_ARG;          // every slab but the last needs plane x1
+    if (n == 0) return RFX_OK;
+    VolView V; V.dx = dx; V.dy = dy; V.dz = dz; V.voxel = voxel;
+    for (int i = 0; i < 3; ++i) V.origin[i] = origin[i];
+    hipLaunchKernelGGL(mv_trilerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), V, x0, x1, tsdf,
+                       color, tsdf_halo, color_halo, pts, n, out5, inside);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -219,14 +219,83 @@ class sharded_volume(moving_volume):
         d = self.vol_dim
         return (int(d[0]) // self.world + 1) * int(d[1]) * int(d[2])
 
+    # -- reads of the volume that need a neighbour's plane (the 1-plane halo)
+    def _halo_plane(self):
+        """plane x1 of tsdf and colour from the right neighbour (None on the last rank); every rank sends its first plane left"""
+        plane = int(self.vol_dim[1]) * int(self.vol_dim[2])
+        halo = None
+        if self.dist is None or self.world == 1:
+            return halo
+        ops = []
+        host = _host_staged(self.dist, self.tsdf_vol_gpu)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        if self.rank > 0:
+            first = torch.stack([self.tsdf_vol_gpu[:plane], self.color_vol_gpu[:plane]])
+            ops.append(self.dist.P2POp(self.dist.isend, first.cpu() if host else first.contiguous(), self.rank - 1))
+        if self.rank < self.world - 1:
+            buf = torch.empty((2, plane), dtype=torch.float32, device="cpu" if host else self.device)
+            ops.append(self.dist.P2POp(self.dist.irecv, buf, self.rank + 1))
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+        if self.rank < self.world - 1:
+            halo = buf.to(self.device)
+        return halo
+
+    def tri_interpolate(self, query_pc):
+        """Trilinear tsdf/rgb at world points (reference model/Volume.py:760-794, kernel :337-458) on the sharded volume: a point
+        is evaluated by the rank that owns the plane of its lower corner, which reads the upper plane from its slab or from
+        the halo plane its right neighbour sends; the records are then summed over the ranks (exactly one rank contributes to
+        each), so every rank returns what the single-GPU volume returns, bit for bit."""
+        from . import _lib
+        from ._lib import _F3, check, farr, ptr, stream_ptr
+        self._wait_for_producer()
+        pts = self._dev(query_pc).reshape(-1, 3)
+        n = pts.shape[0]
+        halo = self._halo_plane()
+        out = torch.zeros((n, 5), dtype=torch.float32, device=self.device)
+        inside = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        d = self.vol_dim
+        x0, x1 = self._slab()
+        check(_lib.load().rfx_tsdf_trilerp_slab(ptr(self.tsdf_vol_gpu), ptr(self.color_vol_gpu), int(d[0]), int(d[1]), int(d[2]), x0, x1,
+                                                ptr(halo[0]) if halo is not None else None, ptr(halo[1]) if halo is not None else None,
+                                                farr(_F3, self.vol_origin), self.voxel_size, ptr(pts), n, ptr(out), inside.data_ptr(),
+                                                stream_ptr(self.device)), "rfx_tsdf_trilerp_slab")
+        out = out * inside.unsqueeze(1).to(out.dtype)          # rows of other ranks: exact zeros
+        all_reduce_sum_(self.dist, [out])
+        result = out.cpu().numpy()
+        notvalid = (result[:, 0] == 10.0) & (result[:, 1] == 0.0) & (result[:, 2] == 0.0) & (result[:, 3] == 0.0)
+        return result, ~notvalid
+
+    def get_truncated_pc(self, pc_num=5000000, trunc_tsdf=0.5):
+        """not available on a sharded volume: the reference's slot scatter (`voxel_idx % pc_num`, model/Volume.py:489-559) keeps
+        the LAST voxel per slot in global index order, which needs a merge over the ranks; no shipped configuration reaches it
+        (training.surface_weight = 0 everywhere)."""
+        from . import _lib
+        raise _lib.RfxError("get_truncated_pc is not implemented for sharded_volume (cold path: surface_weight = 0 in every config)")
+
+    def copy_volume(self):
+        """front -> back on this slab; remembers the layout of the copy (see update_tsdf_swap_rot_trans)"""
+        super().copy_volume()
+        self._back_dim = tuple(int(v) for v in self.vol_dim)
+
     def update_tsdf_swap_rot_trans(self, vol_bnds, old_bnds):
-        """V2 across slabs: fetch the old planes this slab reads from their owners, then gather locally."""
+        """V2 across slabs: fetch the old planes this slab reads from their owners, then gather locally.
+
+        The gather reads the BACK buffers.  version='more' re-grids without a copy_volume() of its own (a quirk kept from the
+        reference, model/Volume.py:1078): the back buffers then hold whatever the last copy left.  Slab r of that stale copy is
+        rank r's back slab as long as the slab cuts have not changed since, i.e. as long as the dimensions are the ones the
+        copy was made with; otherwise the planes a rank would send are not the ones the single-GPU gather reads: refuse."""
         import ctypes as C
         from . import _lib
         from ._lib import _F3, check, farr, ptr, stream_ptr
         lib = _lib.load()
         old_cuts = self._cuts()
         old_dim = np.ceil((old_bnds[:, 1] - old_bnds[:, 0]) / self.voxel_size).copy(order="C").astype(int)
+        back_dim = getattr(self, "_back_dim", None)
+        if back_dim is not None and tuple(int(v) for v in old_dim) != back_dim:
+            raise _lib.RfxError(f"sharded_volume: the back copy was made with dimensions {back_dim}, the re-gridding reads it as "
+                                f"{tuple(int(v) for v in old_dim)}: slab layouts differ (copy_volume() first)")
         old_origin = old_bnds[:, 0].copy(order="C").astype(np.float32)
         self._set_geometry(vol_bnds)
         d = [int(v) for v in self.vol_dim]

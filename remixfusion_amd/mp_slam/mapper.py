@@ -331,6 +331,22 @@ class Mapper:
         self.mapping_idx[0] = current_map_id
         if int(self.mapping_idx[0]) % ke == 0:
             self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
+        self._meshes_in_loop(current_map_id, batch)
+
+    def _meshes_in_loop(self, idx: int, batch):
+        """the mesh exports the reference makes inside its loop (:908-918): a mesh per `video.save_freq` frames when a video is
+        recorded, and one per `mesh.vis` frames unless mesh.only_final (BASELINE config 5: a marching-cubes mesh per
+        keyframe = mesh.vis: keyframe_every, only_final: 0).  On a sharded scene every rank holds the same field: rank 0 writes."""
+        cfg = self.config
+        sh = getattr(self, "scene_shard", None)
+        if sh is not None and sh.rank != 0:
+            return
+        if cfg["video"]["save"] and idx % cfg["video"]["save_freq"] == 0:
+            self.last_mesh = self.slam.save_mesh(idx, voxel_size=0.075)
+        if idx % cfg["mesh"]["vis"] == 0:
+            if not cfg["mesh"]["only_final"]:
+                self.last_mesh = self.slam.save_mesh(idx, voxel_size=0.1)
+            # (mesh.render_img / pose_eval_func at this point of the reference are evaluation I/O: out of scope, DESIGN.md)
 
     def run(self):
         """polling form of the loop (reference :874-906), for a tracker running in another thread."""

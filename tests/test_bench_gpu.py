@@ -1,0 +1,52 @@
+"""bench.py's N > 1 control flow on the real kernels: two ranks on this one GPU (gloo rendezvous on 127.0.0.1, device
+tensors staged through the host), launched the way the driver launches it.  One scene is the headline (`value`, strong
+scaling), the line is printed once by rank 0, and both ranks leave with status 0; a failing rank makes the run exit non-zero."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(extra, timeout=600):
+    env = dict(os.environ, RFX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_reports_one_scene_as_the_headline():
+    res = _torchrun(["--steps", "6", "--warmup", "5", "--first-iters", "5", "--sharded-config", "office0"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "frames/s"
+    assert d["steps"] == 6 and abs(d["ms_per_step"] * d["value"] - 1e3) < 1.0      # frames/s of ONE stream, not a sum over ranks
+    assert "ONE scene on 2 GPUs" in d["config"]["workload"] and "2 x-slabs" in d["config"]["workload"]
+    assert d["roofline"] is not None and d["cpu_baseline"] is None and "error" not in d
+    assert d["iterations_timed"]["map"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_failure_is_a_nonzero_exit():
+    res = _torchrun(["--steps", "2", "--warmup", "1", "--first-iters", "2", "--sharded-config", "no_such_config",
+                     "--one-scene-timeout", "60"], timeout=300)
+    assert res.returncode != 0
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "error" in json.loads(lines[0])

@@ -11,9 +11,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _small_cfg():
+def _small_cfg(version="center"):
     from remixfusion_amd.config import synthetic_config
     cfg = synthetic_config("office0")
+    cfg["volume"]["version"] = version
+    if version == "more":      # the layout the reference's 'more' logic is written for: one axis fixed to a range (no shipped config
+        cfg["volume"]["z_config"] = {"fix": 1, "len": 3, "range": [-3, 3]}     # selects 'more'; without a fixed axis it leaves z empty)
+        cfg["volume"]["third_len"] = cfg["volume"]["second_len"]              # same dimensions whichever axis leads (fixed allocation)
     cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
     cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
     cfg["mapping"].update({"first_iters": 6, "sample": 512})
@@ -94,16 +98,30 @@ def _run(pipe, frames, out):
     moved, _ = pipe.mv.check_move_volume_new(N_FRAMES, far, pipe.traj, version=pipe.config["volume"]["version"])
     out["moved"] = bool(moved)
     out["bnds"] = np.array(pipe.mv.vol_bnds)
+    if pipe.config["volume"]["version"] == "more":
+        # version 'more': the camera now looks along another world axis -> the box is re-laid along it, and (a quirk kept from
+        # the reference, model/Volume.py:1078) re-gridded from the BACK buffers without a fresh copy_volume()
+        from conftest import look_at
+        eye = far[:3, 3]
+        fwd0 = far[:3, 2]
+        turn = np.array([-fwd0[1], fwd0[0], 0.0])
+        turn /= np.linalg.norm(turn)
+        if turn[np.argmax(np.abs(turn))] < 0:      # (looking down a negative axis the reference's formula inverts the bounds)
+            turn = -turn
+        rot = look_at(tuple(eye), tuple(turn)).astype(np.float64)
+        moved2, _ = pipe.mv.check_move_volume_new(N_FRAMES + 1, rot, pipe.traj, version="more")
+        out["moved_more"] = bool(moved2)
+        out["bnds_more"] = np.array(pipe.mv.vol_bnds)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, version):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from remixfusion_amd.dist import ShardedPipeline
-    pipe = ShardedPipeline(_small_cfg(), dist, rank, world, n_frames=N_FRAMES + 4, seed=5)
+    pipe = ShardedPipeline(_small_cfg(version), dist, rank, world, n_frames=N_FRAMES + 4, seed=5)
     frames = pipe.prefetch(list(range(N_FRAMES)))
     out = {}
     _run(pipe, frames, out)
@@ -116,18 +134,22 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_sharded_scene_world2_equals_single_gpu(tmp_path):
+@pytest.mark.parametrize("version", ["center", "more"])
+def test_sharded_scene_world2_equals_single_gpu(tmp_path, version):
     import torch
     import torch.multiprocessing as mp
     from remixfusion_amd.pipeline import MappingPipeline
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), version), nprocs=world, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world))
     # ---- the single-GPU run
-    pipe = MappingPipeline(_small_cfg(), n_frames=N_FRAMES + 4, seed=5)
+    pipe = MappingPipeline(_small_cfg(version), n_frames=N_FRAMES + 4, seed=5)
     frames = pipe.prefetch(list(range(N_FRAMES)))
     ref = {}
     _run(pipe, frames, ref)
+    if version == "more":
+        assert ref["moved_more"] and r0["moved_more"] and r1["moved_more"]
+        assert np.array_equal(ref["bnds_more"], r0["bnds_more"]) and not np.array_equal(ref["bnds_more"], ref["bnds"])
     mv = [torch.from_numpy(a.copy()) for a in pipe.mv.get_volume_all()]
     assert ref["moved"] and r0["moved"] and r1["moved"] and np.array_equal(ref["bnds"], r0["bnds"])
     assert r0["slab"] == (0, 100) and r1["slab"] == (100, 200)
