@@ -1,10 +1,11 @@
-"""Readers for recorded RGB-D sequences (reference datasets/dataset.py:12-53, 55-87, 203-299,
-675-780, 1009-1205): Replica, ScanNet and TUM-RGBD layouts, returning the batch dict the Mapper / Tracker
-consume (`frame_id, c2w, rgb [H,W,3] 0..1, depth [H,W] metres*sc_factor, direction [H,W,3]`).
+"""Readers for recorded RGB-D sequences (reference datasets/dataset.py:12-53, 55-87, 203-299, 538-673,
+675-780, 1009-1205, 1207-1396): Replica, ScanNet, TUM-RGBD, BS3D and uHumans2 layouts -- the data of BASELINE configs
+2 to 5 -- returning the batch dict the Mapper / Tracker consume (`frame_id, c2w, rgb [H,W,3] 0..1, depth [H,W]
+metres*sc_factor, direction [H,W,3]`).
 
 Control-plane I/O, kept small: images are decoded with Pillow (cv2 / imageio are not in this image) and
 resampled with torch (`bilinear, align_corners=False` = cv2.INTER_LINEAR, `area` = INTER_AREA, `nearest` =
-INTER_NEAREST).  The other layouts of the reference (iPhone, Azure, Realsense, BS3D, uHumans2, ...) differ only
+INTER_NEAREST).  The other layouts of the reference (iPhone, Azure, Realsense, FastSyn, Largeindoor) differ only
 in file globbing and pose-file syntax and are not reproduced.
 """
 from __future__ import annotations
@@ -76,11 +77,12 @@ class BaseDataset(torch.utils.data.Dataset):
             self.config["cam"]["H"] -= 2 * e
             self.config["cam"]["W"] -= 2 * e
 
-    def _frame(self, color_path: str, depth_path: str, crop_size=None):
+    def _frame(self, color_path: str, depth_path: str, crop_size=None, depth_array=None):
         if self.distortion is not None and crop_size is None:
             raise NotImplementedError("lens undistortion is not implemented (the reference raises here too)")
         color = torch.from_numpy(_read_rgb(color_path).astype(np.float32) / 255.0)
-        depth = torch.from_numpy(_read_depth_png(depth_path) / self.png_depth_scale * self.sc_factor)
+        raw = _read_depth_png(depth_path) if depth_array is None else depth_array
+        depth = torch.from_numpy(raw / self.png_depth_scale * self.sc_factor)
         H, W = depth.shape
         if color.shape[:2] != (H, W):
             color = _resize(color, (H, W), "bilinear")
@@ -244,7 +246,91 @@ class TUMDataset(BaseDataset):
         return self._item(index, *self._frame(self.color_paths[index], self.depth_paths[index], crop_size=self.crop_size))
 
 
-_READERS = {"replica": ReplicaDataset, "scannet": ScannetDataset, "tum": TUMDataset}
+class BS3DDataset(BaseDataset):
+    """BS3D (BASELINE config 4): <dir>/color/N.jpg, depth/N.png in numeric order, <dir>/poses.txt with one
+    `stamp tx ty tz qx qy qz qw` row per frame; with cam.crop_size the images are resized to crop_size + 2 crop_edge and the
+    edge is cut off, the intrinsics following (reference :538-673)."""
+
+    def __init__(self, cfg, basedir, trainskip=1, downsample_factor=1, translation=0.0, sc_factor=1.0, crop=0):
+        super().__init__(cfg)
+        self.basedir, self.trainskip, self.downsample_factor = basedir, trainskip, downsample_factor
+        self.translation, self.sc_factor, self.crop = translation, sc_factor, crop
+        num = lambda p: int(os.path.basename(p)[:-4])                                        # noqa: E731
+        self.img_files = sorted(glob.glob(os.path.join(basedir, "color", "*.jpg")), key=num)
+        self.depth_paths = sorted(glob.glob(os.path.join(basedir, "depth", "*.png")), key=num)
+        self.frame_ids = range(0, len(self.img_files))
+        self.load_poses(os.path.join(basedir, "poses.txt"))
+        self.num_frames = len(self.frame_ids)
+        cam = cfg["cam"]
+        self.out_hw = None
+        if "crop_size" in cam:                                  # reference :569-584
+            e = cam["crop_edge"]
+            self.H_out, self.W_out = cam["crop_size"]
+            He, We = self.H_out + 2 * e, self.W_out + 2 * e
+            self.fx *= We / self.W
+            self.fy *= He / self.H
+            self.cx *= We / self.W
+            self.cy *= He / self.H
+            self.H, self.W = He - 2 * e, We - 2 * e
+            self.cx -= e
+            self.cy -= e
+            self.out_hw = (He, We)
+
+    def load_poses(self, path):
+        rows = np.loadtxt(path, dtype=np.float64, ndmin=2)[:, 1:]
+        self.poses = [torch.from_numpy(TUMDataset.pose_matrix_from_quaternion(r)).float() for r in rows]
+
+    def __getitem__(self, index):
+        if self.distortion is not None:
+            raise NotImplementedError("lens undistortion is not implemented (the reference raises here too)")
+        color = torch.from_numpy(_read_rgb(self.img_files[index]).astype(np.float32) / 255.0)
+        depth = torch.from_numpy(_read_depth_png(self.depth_paths[index]) / self.png_depth_scale * self.sc_factor)
+        H, W = depth.shape
+        if self.out_hw is not None:
+            color = _resize(color, self.out_hw, "bilinear")
+            depth = _resize(depth, self.out_hw, "nearest")
+        elif color.shape[:2] != (H, W):
+            color = _resize(color, (H, W), "bilinear")
+        if self.downsample_factor > 1:                          # (the reference re-divides the focal length on every read)
+            H, W = H // self.downsample_factor, W // self.downsample_factor
+            self.fx, self.fy = self.fx // self.downsample_factor, self.fy // self.downsample_factor
+            color = _resize(color, (H, W), "area")
+            depth = _resize(depth, (H, W), "nearest")
+        e = self.config["cam"].get("crop_edge", 0)
+        if e > 0:
+            color, depth = color[e:-e, e:-e], depth[e:-e, e:-e]
+        if self.rays_d is None:
+            self.rays_d = get_camera_rays(self.H, self.W, self.fx, self.fy, self.cx, self.cy)
+        return self._item(index, color.contiguous().float(), depth.contiguous().float())
+
+
+class uhumansDataset(TUMDataset):
+    """uHumans2 (BASELINE config 5): color.txt / depth.txt / pose.txt list files whose rows pair up by index (no time-stamp
+    association, no header row); depth as 16-bit PNG in millimetres or as .npy in metres (reference :1207-1396)."""
+
+    def loadtum(self, datapath, frame_rate=-1):
+        image_data = self.parse_list(os.path.join(datapath, "color.txt"))
+        depth_data = self.parse_list(os.path.join(datapath, "depth.txt"))
+        pose_vecs = self.parse_list(os.path.join(datapath, "pose.txt"))[:, 1:].astype(np.float64)
+        images = [os.path.join(datapath, image_data[i, 1]) for i in range(image_data.shape[0])]
+        depths = [os.path.join(datapath, depth_data[i, 1]) for i in range(image_data.shape[0])]
+        poses = [torch.from_numpy(self.pose_matrix_from_quaternion(pose_vecs[i])).float() for i in range(image_data.shape[0])]
+        return images, depths, poses
+
+    def __getitem__(self, index):
+        depth_path = self.depth_paths[index]
+        self.png_depth_scale = 1.0 if depth_path.endswith(".npy") else 1000.0          # reference :1327-1332
+        if self.downsample_factor > 1:
+            self.fx, self.fy = self.fx // self.downsample_factor, self.fy // self.downsample_factor
+        if depth_path.endswith(".npy"):
+            color, depth = self._frame(self.color_paths[index], depth_path, crop_size=self.crop_size,
+                                       depth_array=np.load(depth_path).astype(np.float32))
+        else:
+            color, depth = self._frame(self.color_paths[index], depth_path, crop_size=self.crop_size)
+        return self._item(index, color, depth)
+
+
+_READERS = {"replica": ReplicaDataset, "scannet": ScannetDataset, "tum": TUMDataset, "BS3D": BS3DDataset, "uhumans": uhumansDataset}
 
 
 def get_recorded_dataset(config: Dict):

@@ -89,6 +89,55 @@ def test_tum_layout_association(tmp_path):
     assert torch.equal(b["c2w"][:3, :3], torch.eye(3))
 
 
+def test_bs3d_layout_crop_size_and_quaternion_poses(tmp_path):
+    """BASELINE config 4's data layout (reference datasets/dataset.py:538-673)."""
+    from scipy.spatial.transform import Rotation
+    ids = [0, 1, 2, 10]
+    depths = _write_frames(tmp_path / "color", tmp_path / "depth", [(f"{i}.jpg", f"{i}.png") for i in ids], H=24, W=32)
+    quats = Rotation.from_euler("xyz", [[0.1 * i, -0.2, 0.05 * i] for i in range(4)]).as_quat()
+    with open(tmp_path / "poses.txt", "w") as f:
+        for i, q in enumerate(quats):
+            f.write(f"{100.0 + i:.3f} {i}.5 -1.0 2.0 " + " ".join(f"{v:.9f}" for v in q) + "\n")
+    cfg = _cfg("BS3D", tmp_path, H=24, W=32, crop_size=[8, 12], crop_edge=2, fx=20.0, fy=20.0, cx=15.5, cy=11.5)
+    ds = get_dataset(cfg)
+    assert len(ds) == 4 and (ds.H, ds.W) == (8, 12)
+    # intrinsics: scaled by (crop + 2 edge) / original, then the principal point moves in by the edge (:573-584)
+    assert ds.fx == pytest.approx(20.0 * 16 / 32) and ds.fy == pytest.approx(20.0 * 12 / 24)
+    assert ds.cx == pytest.approx(15.5 * 16 / 32 - 2) and ds.cy == pytest.approx(11.5 * 12 / 24 - 2)
+    b = ds[3]                                               # "10.jpg" is the LAST frame (numeric order)
+    assert b["frame_id"] == 3 and b["rgb"].shape == (8, 12, 3) and b["depth"].shape == (8, 12) and b["direction"].shape == (8, 12, 3)
+    # depth: nearest-neighbour resize of the 24x32 image to 12x16 (every second pixel), then the 2-pixel edge cut off
+    exp = torch.from_numpy(depths[3].astype(np.float32) / 1000.0)[0::2, 0::2][2:-2, 2:-2]
+    assert torch.equal(b["depth"], exp)
+    R = Rotation.from_quat(quats[3]).as_matrix()
+    assert torch.allclose(b["c2w"][:3, :3], torch.from_numpy(R).float(), atol=1e-6)
+    assert torch.allclose(b["c2w"][:3, 3], torch.tensor([3.5, -1.0, 2.0]))
+    assert ds.num_rays_to_save == int(8 * 12 * cfg["mapping"]["n_pixels"])
+
+
+def test_uhumans_layout_lists_paired_by_index_png_and_npy_depth(tmp_path):
+    """BASELINE config 5's data layout (reference datasets/dataset.py:1207-1396)."""
+    n = 3
+    depths = _write_frames(tmp_path / "color", tmp_path / "depth", [(f"c{i}.png", f"d{i}.png") for i in range(n)], ext="png")
+    np.save(tmp_path / "depth" / "d2.npy", depths[2].astype(np.float32) / 1000.0)     # metres
+    with open(tmp_path / "color.txt", "w") as f:
+        f.writelines(f"{i}.0 color/c{i}.png\n" for i in range(n))
+    with open(tmp_path / "depth.txt", "w") as f:
+        f.writelines(f"{i + 0.5} depth/d{i}.{'npy' if i == 2 else 'png'}\n" for i in range(n))     # stamps differ: rows pair by index
+    with open(tmp_path / "pose.txt", "w") as f:
+        f.writelines(f"{i}.0 {i}.0 0 0 0 0 0 1\n" for i in range(n))                    # no header row
+    cfg = _cfg("uhumans", tmp_path, png_depth_scale=5000.0)                            # overridden: PNG depth is millimetres
+    ds = get_dataset(cfg)
+    assert len(ds) == n and [float(p[0, 3]) for p in ds.poses] == [0.0, 1.0, 2.0]
+    b1, b2 = ds[1], ds[2]
+    assert torch.allclose(b1["depth"], torch.from_numpy(depths[1].astype(np.float32) / 1000.0))
+    assert torch.allclose(b2["depth"], torch.from_numpy(depths[2].astype(np.float32) / 1000.0))      # the .npy frame, in metres
+    assert b1["rgb"].shape == (12, 16, 3) and b1["direction"].shape == (12, 16, 3)
+    cfg = _cfg("uhumans", tmp_path, crop_size=[6, 8], crop_edge=1)
+    ds = get_dataset(cfg)
+    assert (ds.H, ds.W) == (4, 6) and ds[0]["rgb"].shape == (4, 6, 3) and cfg["cam"]["W"] == 6 and ds.cx == pytest.approx(7.5 * 0.5 - 1)
+
+
 def test_unknown_layout_raises():
     cfg = _cfg("azure", "/nonexistent")
     with pytest.raises(NotImplementedError):
