@@ -69,20 +69,7 @@ __global__ __launch_bounds__(256) void sample_z_kernel(SamplerK s, const float* 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = s.n_range_d + s.n_samples_d;
     float* zs = zsh[wv];
-    // XCD-contiguous ray order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; speed only,
-    // never correctness) and each XCD has its own L2.  Neighbouring rays of an image gather the same cells of the 128 MB
-    // global volume and of the fine hash levels: with rays dealt out block by block every XCD's L2 fetched every line
-    // (1.8 GB of fabric reads per 640x480 frame against a 128 MB table).  Here XCD slot x = b % 8 walks its own contiguous
-    // eighth of the ray list, so a line is fetched by one L2 and re-used by the rays next to it and the rows below.
-#ifndef RENDER_XCD_ORDER
-#define RENDER_XCD_ORDER 1
-#endif
-    const bool by_xcd = RENDER_XCD_ORDER && gridDim.x >= 64;          // small ray lists: plain order
-    const int64_t n_slots = by_xcd ? 8 : 1;
-    const int64_t slot = by_xcd ? (blockIdx.x & 7) : 0, blk = by_xcd ? (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t blocks_per_slot = by_xcd ? ((int64_t)gridDim.x + 7 - slot) / 8 : gridDim.x;
-    const int64_t r0 = n_rays * slot / n_slots, r1 = n_rays * (slot + 1) / n_slots;
-    for (int64_t ray = r0 + blk * 4 + wv; ray < r1; ray += blocks_per_slot * 4) {
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + wv; ray < n_rays; ray += (int64_t)gridDim.x * 4) {
         sample_ray(s, target_d[ray], zs, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to it
         __builtin_amdgcn_wave_barrier();
@@ -97,12 +84,15 @@ __global__ __launch_bounds__(256) void sample_z_kernel(SamplerK s, const float* 
 
 // x01 = ((o + d*z) - bb_min) / (bb_max - bb_min); the reference evaluates the normalisation in
 // float64 when mapping.bound holds a non-integer (torch type promotion, scene_rep.py:388).
-struct BoxK { double lo[3], hi[3]; int f64; };
+struct BoxK { double lo[3], hi[3], inv[3]; float lo32[3], ext32[3]; int f64; };      // lo32 / ext32: the fp32 form's operands (host)
 
+// float64 form (a bound with a non-integer entry, scene_rep.py:388): the quotient (p - lo) / (hi - lo) is formed as a product
+// with the extent's reciprocal (host, float64): one rounding of 1.1e-16 relative more before the result is rounded to fp32,
+// which changes that fp32 number for about one value in 5e8 (by one ulp) -- and costs two float64 operations instead of the
+// ~35 instructions of a float64 division, three times per sample.
 __device__ __forceinline__ float normalise(const BoxK& b, int d, float p) {
-    if (b.f64) return (float)(((double)p - b.lo[d]) / (b.hi[d] - b.lo[d]));
-    const float lo = (float)b.lo[d], hi = (float)b.hi[d];
-    return (p - lo) / (hi - lo);
+    if (b.f64) return (float)(((double)p - b.lo[d]) * b.inv[d]);
+    return (p - b.lo32[d]) / b.ext32[d];
 }
 
 __global__ __launch_bounds__(256) void ray_points_kernel(const float* __restrict__ o, const float* __restrict__ d,
@@ -243,7 +233,10 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float4* _
 
 // ------------------------------------------------------------------ fused eval renderer
 // one wave per ray; lanes = samples; S1 + points + Q1 (encode + MFMA MLP) + R1, all in registers.
-template <bool POS16>
+// NCHUNK = ceil(S / 64) lane passes per ray (1 for the 59-sample configurations, 2 for the 117-sample ones): with one pass
+// nothing is carried between passes and the kernel fits its 256 registers without scratch (the generic two-pass form wrote
+// 366 MiB of spills per 640x480 frame).
+template <bool POS16, int NCHUNK>
 __global__ __launch_bounds__(256, RENDER_WAVES) void render_rays_kernel(FieldK f, SamplerK s, BoxK box,
                                                                     const float* __restrict__ rays_o,
                                                                     const float* __restrict__ rays_d,
@@ -257,20 +250,32 @@ __global__ __launch_bounds__(256, RENDER_WAVES) void render_rays_kernel(FieldK f
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = s.n_range_d + s.n_samples_d;
     float* zs = zsh[wv];
-    for (int64_t ray = (int64_t)blockIdx.x * 4 + wv; ray < n_rays; ray += (int64_t)gridDim.x * 4) {
+    // XCD-contiguous ray order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; speed only,
+    // never correctness) and each XCD has its own L2.  Neighbouring rays of an image gather the same cells of the 128 MB
+    // global volume and of the fine hash levels: with rays dealt out block by block every XCD's L2 fetched every line
+    // (1.8 GB of fabric reads per 640x480 frame against a 128 MB table).  Here XCD slot x = b % 8 walks its own contiguous
+    // eighth of the ray list, so a line is fetched by one L2 and re-used by the rays next to it and the rows below.
+#ifndef RENDER_XCD_ORDER
+#define RENDER_XCD_ORDER 1
+#endif
+    const bool by_xcd = RENDER_XCD_ORDER && gridDim.x >= 64;          // small ray lists: plain order
+    const int64_t n_slots = by_xcd ? 8 : 1;
+    const int64_t slot = by_xcd ? (blockIdx.x & 7) : 0, blk = by_xcd ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t blocks_per_slot = by_xcd ? ((int64_t)gridDim.x + 7 - slot) / 8 : gridDim.x;
+    const int64_t r0 = n_rays * slot / n_slots, r1 = n_rays * (slot + 1) / n_slots;
+    for (int64_t ray = r0 + blk * 4 + wv; ray < r1; ray += blocks_per_slot * 4) {
         sample_ray(s, target_d[ray], zs, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
         const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
-        float sdf[2], z[2];
-        float4 rv[2];
-        bool valid[2];
+        float sdf[2] = {0.f, 0.f}, z[2] = {0.f, 0.f};
+        float4 rv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        bool valid[2] = {false, false};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NCHUNK; ++c) {
             const int j = lane + 64 * c;
             valid[c] = j < S;
-            z[c] = 0.f; sdf[c] = 0.f; rv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (64 * c >= S) continue;           // wave-uniform: second chunk only for S > 64
             const int jj = valid[c] ? j : S - 1;
             float zz = zs[jj];
@@ -810,7 +815,8 @@ static int make_sampler(const rfx_sampler_desc* d, SamplerK* k) {
 
 static BoxK make_box(const double bbox[6], int f64) {
     BoxK b;
-    for (int i = 0; i < 3; ++i) { b.lo[i] = bbox[2 * i]; b.hi[i] = bbox[2 * i + 1]; }
+    for (int i = 0; i < 3; ++i) { b.lo[i] = bbox[2 * i]; b.hi[i] = bbox[2 * i + 1]; b.inv[i] = 1.0 / (bbox[2 * i + 1] - bbox[2 * i]);
+                                  b.lo32[i] = (float)bbox[2 * i]; b.ext32[i] = (float)bbox[2 * i + 1] - (float)bbox[2 * i]; }
     b.f64 = f64 ? 1 : 0;
     return b;
 }
@@ -887,12 +893,11 @@ int rfx_render_rays(const rfx_field_desc* f, const rfx_sampler_desc* s, const fl
     if (rc) return rc;
     if (!rays_o || !rays_d || !target_d || !bbox || !rgb || !depth || n_rays < 0) return RFX_ERR_ARG;
     if (n_rays == 0) return RFX_OK;
-    if (fk.pos_fp16)
-        hipLaunchKernelGGL(render_rays_kernel<true>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
-                           make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
-    else
-        hipLaunchKernelGGL(render_rays_kernel<false>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
-                           make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
+    const bool one_pass = sk.n_range_d + sk.n_samples_d <= 64;
+    auto kern = fk.pos_fp16 ? (one_pass ? render_rays_kernel<true, 1> : render_rays_kernel<true, 2>)
+                            : (one_pass ? render_rays_kernel<false, 1> : render_rays_kernel<false, 2>);
+    hipLaunchKernelGGL(kern, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), fk, sk,
+                       make_box(bbox, bbox_f64), rays_o, rays_d, target_d, u01, n_rays, sc_factor, rgb, depth);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
