@@ -620,13 +620,29 @@ def main():
                         ("field_forward", ("rfx::field_forward_kernel<false, true>",)),
                         ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false, true>",)),
                         ("field_backward_weights", ("rfx::field_dw_recompute_kernel", "rfx::field_dw_reduce_kernel")),
-                        ("render_rays", ("rfx::render_rays_kernel<false>",)),
+                        ("render_rays", ("rfx::render_rays_kernel<false, 1>",)),
                         ("tsdf_integrate", ("rfx::mv_chunks_kernel", "rfx::mv_rows_kernel", "rfx::mv_frame_kernel"))):
             keys = [k for k in pmc if any(kn in k for kn in kns)]
             if rk in extra_rooflines and keys:
                 extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes"] for k in keys))
                 extra_rooflines[rk]["traffic_source"] = (f"profiles/r3_pmc_traffic.json, rocprofv3 --pmc passes at commit {tag} (not this run): "
                                                          "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B) + WRITE_SIZE; " + " + ".join(keys))
+    except Exception:
+        pass
+    # V1: traffic of the SAME frame the algorithmic bytes above were counted on (frame 1 + warmup + steps - 1), when the
+    # committed passes cover it (profiles/r3_pmc_v1_frame25.json: the driver's settings)
+    try:
+        v1p = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_v1_frame25.json")))
+        if "tsdf_integrate" in extra_rooflines and v1p["frame"] == n_frames - 1 and v1p["config"] == args.config:
+            extra_rooflines["tsdf_integrate"]["traffic"] = int(sum(k["hbm_bytes"] for k in v1p["kernels"].values()))
+            extra_rooflines["tsdf_integrate"]["traffic_raw_counters"] = int(sum(k["hbm_bytes_raw"] for k in v1p["kernels"].values()))
+            extra_rooflines["tsdf_integrate"]["traffic_source"] = (
+                f"profiles/r3_pmc_v1_frame25.json: rocprofv3 --pmc passes of tools/pmc_v1.py at commit {v1p['measured_at_commit']} on frame "
+                f"{v1p['frame']} (this frame; not this run): 2 x FETCH_SIZE + WRITE_SIZE, the factor 2 calibrated on a coalesced "
+                "dword-per-lane read of known size in the same passes; traffic_raw_counters = FETCH_SIZE + WRITE_SIZE")
+        elif "tsdf_integrate" in extra_rooflines:
+            extra_rooflines["tsdf_integrate"]["traffic"] = None         # passes of other frames are not comparable
+            extra_rooflines["tsdf_integrate"].pop("traffic_source", None)
     except Exception:
         pass
     key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",

@@ -1,12 +1,14 @@
-"""Summarise rocprofv3 --pmc passes into profiles/r2_pmc_traffic.json and a per-kernel SQ counter table.
+"""Summarise rocprofv3 --pmc passes into profiles/<PREFIX>_pmc_traffic.json and a per-kernel SQ counter table.
 
-usage: python tools/summarize_pmc.py OUT_DIR COMMIT FETCH_CSV WRITE_CSV [SQ_CSV ...]
+usage: [PMC_PREFIX=r3] python tools/summarize_pmc.py OUT_DIR COMMIT FETCH_CSV WRITE_CSV [SQ_CSV ...]
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950
 tallies the 128-byte requests of wide coalesced reads at 64 B: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; the raw
 sum is recorded next to it (gathers of 8/16-byte elements are closer to the raw figure)."""
 import collections, csv, json, os, sys
 out_dir, commit, fetch_csv, write_csv = sys.argv[1:5]
+prefix = os.environ.get("PMC_PREFIX", "r3")
+command = os.environ.get("PMC_COMMAND", "python3 bench.py --steps 40 --warmup 11 --no-cpu-baseline")
 sq_csvs = sys.argv[5:]
 
 
@@ -31,9 +33,9 @@ for k, v in kern.items():
     f, w = v.get("FETCH_SIZE_KiB_avg", 0.0), v.get("WRITE_SIZE_KiB_avg", 0.0)
     v["hbm_bytes_raw"] = (f + w) * 1024
     v["hbm_bytes"] = (2 * f + w) * 1024
-json.dump({"measured_at_commit": commit, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 40 --warmup 11 --no-cpu-baseline (one pass per counter)",
+json.dump({"measured_at_commit": commit, "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- {command} (one pass per counter)",
            "unit_note": "KiB counters; hbm_bytes = (2*FETCH + WRITE)*1024 (gfx950 FETCH correction), hbm_bytes_raw = (FETCH + WRITE)*1024; per launch averages",
-           "kernels": kern}, open(os.path.join(out_dir, "r2_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+           "kernels": kern}, open(os.path.join(out_dir, prefix + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 lines = [f"# HBM traffic per launch (rocprofv3 --pmc, commit {commit}); MiB", "", "| kernel | launches | FETCH raw | FETCH x2 | WRITE |", "|---|---|---|---|---|"]
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
     lines.append(f"| `{k}` | {v['dispatches']} | {v.get('FETCH_SIZE_KiB_avg', 0) / 1024:.2f} | {2 * v.get('FETCH_SIZE_KiB_avg', 0) / 1024:.2f} | {v.get('WRITE_SIZE_KiB_avg', 0) / 1024:.2f} |")
@@ -48,5 +50,5 @@ if sq_csvs:
     lines += ["| kernel | " + " | ".join(names) + " |", "|---|" + "---|" * len(names)]
     for k, d in sorted(acc.items()):
         lines.append(f"| `{k}` | " + " | ".join(f"{sum(d[c]) / len(d[c]):.3g}" if d.get(c) else "" for c in names) + " |")
-open(os.path.join(out_dir, "r2_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(out_dir, prefix + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:60]))
