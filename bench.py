@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--first-iters", type=int, default=None, help="override mapping.first_iters (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-frames", type=int, default=3)
+    ap.add_argument("--frame-times", action="store_true", help="print host and GPU time per timed frame to stderr")
     ap.add_argument("--no-process-warmup", action="store_true", help="skip the throwaway pipeline that loads kernels / primes the allocator")
     ap.add_argument("--pos-fp16", action="store_true",
                     help="opt in to OneBlob outputs rounded to fp16 on the fp16 matrix pipe (NOT the reference's precision, which "
@@ -491,11 +492,36 @@ def main():
     timer.enabled = True
     it0 = dict(direct.iterations) if direct is not None else None
     t0 = time.perf_counter()
+    frame_marks = []
+    if args.frame_times:
+        import gc
+        gc_log, gc_t = [], [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                gc_t[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], (time.perf_counter() - gc_t[0]) * 1e3, (time.perf_counter() - t0) * 1e3))
+        gc.callbacks.append(_gc_cb)
     for i in range(1 + args.warmup, n_frames):
         pipe.step(i, frames[i])
+        if args.frame_times:                             # dev aid: where inside the timed region the time goes
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            frame_marks.append((i, time.perf_counter() - t0, ev))
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if args.frame_times and rank == 0:
+        gc.callbacks.remove(_gc_cb)
+        for g, dur, at in gc_log:
+            print(f"gc generation {g}: {dur:.3f} ms at +{at:.3f} ms", file=sys.stderr)
+        prev_h, prev_e = 0.0, None
+        for i, h, ev in frame_marks:
+            g = frame_marks[0][2].elapsed_time(ev)
+            print(f"frame {i:4d} host +{(h - prev_h) * 1e3:7.3f} ms  gpu mark {g:9.3f} ms (+{0.0 if prev_e is None else g - prev_e:7.3f})",
+                  file=sys.stderr)
+            prev_h, prev_e = h, g
     iters = {k: direct.iterations[k] - it0[k] for k in it0} if direct is not None else {"map": 0, "pose": 0}
     if dist is not None:
         tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)

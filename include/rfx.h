@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 4
+#define RFX_ABI_VERSION 5
 
 typedef void* rfx_stream;
 
@@ -363,6 +363,12 @@ int rfx_tv_lattice(const float* u6, int P, float voxel, float margin, const doub
 /* k distinct pseudo-random indices out of range(population), on the device: replaces python's
  * random.sample in the ray samplers (model/keyframe.py:33,89; mp_slam/mapper.py:396).  out dev int64[k].
  * Deterministic in (seed, population). */
+/* out[e] = the e-th uniform of stream `stream_id` under `seed`: word 0 of Philox4x32-10(counter (e, stream_id), key seed)
+ * as a float in [0, 1) with 24 random bits (torch.rand's resolution).  Replaces the torch.rand((n, S)) / torch.rand(6) draws
+ * of scene_rep.py:437 and mp_slam/slam.py:198-203 where a caller lets rfx_ba_forward_backward draw for itself
+ * (rfx_ba_desc.seed_u): this entry point reproduces those draws in a buffer. */
+int rfx_uniform_draws(uint64_t seed, int stream_id, int64_t n, float* out, rfx_stream stream);
+
 int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream);
 
 /* M1 ray batch of one optimisation iteration: replaces the host glue of mp_slam/mapper.py:394-409
@@ -487,6 +493,8 @@ typedef struct rfx_ba_desc {
     int32_t       K;
     const float*  u_z;                  /* dev [n,S] uniforms of the sampler jitter, or NULL                 */
     const float*  u6;                   /* dev [6] uniforms of the TV lattice                                */
+    uint64_t      seed_u;               /* != 0: the call draws both sets of uniforms itself (u_z, u6 not read): element e */
+                                        /* of rfx_uniform_draws(seed_u, 0, n*S) jitters sample e, (seed_u, 1, 6) is u6      */
     int64_t       hash_entries;         /* entries (of n_feat floats) of the hash table = size of d_hash     */
     float*        d_hash;               /* out dev: hash-table gradient (zeroed here); d_hash and d_w both NULL: */
     float*        d_w;                  /* out dev [5312]: dW1 | dW2 | dW3 | dW4 (zeroed here)  | no map gradients */

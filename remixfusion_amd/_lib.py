@@ -54,7 +54,7 @@ class BaDesc(C.Structure):
                 ("num_kf", C.c_int64), ("kf_frame_ids", C.c_void_p), ("keyframe_every", C.c_int32), ("cur_rays", C.c_void_p),
                 ("cur_population", C.c_int64), ("n_kf_samples", C.c_int64), ("n_cur", C.c_int64), ("seed_kf", C.c_uint64),
                 ("seed_cur", C.c_uint64), ("poses16", C.c_void_p), ("K", C.c_int32), ("u_z", C.c_void_p), ("u6", C.c_void_p),
-                ("hash_entries", C.c_int64), ("d_hash", C.c_void_p), ("d_w", C.c_void_p), ("d_poses16", C.c_void_p),
+                ("seed_u", C.c_uint64), ("hash_entries", C.c_int64), ("d_hash", C.c_void_p), ("d_w", C.c_void_p), ("d_poses16", C.c_void_p),
                 ("losses8", C.c_void_p), ("tv_sum", C.c_void_p)]
 
 
@@ -127,6 +127,7 @@ PROTOTYPES = {
     "rfx_tv_forward": (_i, [_P, _i, _i, _P, _P]),
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
     "rfx_random_subset": (_i, [C.c_uint64, _l, _l, _P, _P]),
+    "rfx_uniform_draws": (_i, [C.c_uint64, _i, _l, _P, _P]),
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),
     "rfx_track_normal": (_i, [_P, _P, _i, _i, _P]),
     "rfx_track_evaluate": (_i, [_P, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
@@ -170,7 +171,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 4:
+    if lib.rfx_abi_version() != 5:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

@@ -101,7 +101,7 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const int64_t n = b->n_kf_samples + b->n_cur;
     const int S = b->sampler.n_range_d + b->sampler.n_samples_d, P = b->tv_P;
     const int L = b->field.hash.n_levels, F = b->field.hash.n_feat;
-    if (n <= 0 || S <= 0 || P <= 0 || !b->u6 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0) return RFX_ERR_ARG;
+    if (n <= 0 || S <= 0 || P <= 0 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0) return RFX_ERR_ARG;
     // map gradients are optional as a pair: without them (pose phase, where no optimizer consumes them) only the
     // ray/pose gradients are produced, so there must be somewhere to put those
     const bool map_grads = b->d_hash != nullptr;
@@ -111,12 +111,14 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const BaWs w = carve_ba(workspace, n, S, P, L * F, L);
     hipStream_t st = as_stream(stream);
     const int64_t nS = n * S, nt = (int64_t)P * P * P;
-    // ---- decoder weights -> MFMA operand image (the optimizers update the weights in place between calls)
-    if (b->field.staged) RFX_TRY(rfx_field_stage_weights(&b->field, const_cast<float*>(b->field.staged), stream));
-    // ---- ray batch
-    RFX_TRY(ray_batch_setup(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
-                            b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->bbox,
-                            b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, stream));     // rays, S1, points
+    // ---- ray batch (rays, S1, points); beside it in the same launch: decoder weights -> MFMA operand image (the optimizers
+    //      update the weights in place between calls) and the TV lattice with its table lookups, which depend on nothing computed here
+    const bool tv_on = map_grads || b->tv_sum;
+    if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
+    RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
+                        b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
+                        b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, P, b->tv_voxel,
+                        b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr, stream));
     // ---- forward
     // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
     RFX_TRY(rfx_field_forward_stash(&b->field, w.x01, nS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
@@ -126,11 +128,7 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     RFX_TRY(composite_loss_forward(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc,
                                    b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, &n_partials, stream));       // R1 + L1 sums
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
-    if (map_grads || b->tv_sum) {
-        RFX_TRY(rfx_tv_lattice(b->u6, P, b->tv_voxel, b->tv_margin, b->bbox, b->bbox_f64, b->tv_normalise, w.pts, stream));
-        RFX_TRY(rfx_grid_encode_forward(&b->field.hash, b->field.hash_table, w.pts, nt, w.feat, stream));
-        if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));
-    }
+    if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));      // (its features: the prologue's)
     // ---- backward
     RFX_TRY(loss_backward_from_partials(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
                                         b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw,

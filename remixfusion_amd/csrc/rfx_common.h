@@ -34,11 +34,12 @@ __device__ __forceinline__ float madd(float a, float b, float c) { return fmaf(a
 __device__ __forceinline__ int f2i_rn(float v) { return (int)rintf(v); }
 
 // fused forms of public entry points, used by rfx_ba_forward_backward (defined in rfx_render.hip)
-int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
-                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
-                    uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01,
-                    const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
-                    float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, rfx_stream stream);
+int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01, uint64_t seed_u,
+                const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
+                float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
+                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, rfx_stream stream);
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,

@@ -399,6 +399,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
             const unsigned r = idx8[k] - base;
 #if defined(SCATTER_DBG) && SCATTER_DBG == 2
             if (r < cnt) { acc[2 * lds_slot(r, pm)] = a0[k]; acc[2 * lds_slot(r, pm) + 1] = a1[k]; }
+#elif defined(SCATTER_DBG) && SCATTER_DBG == 4
+            if (r == 0x7fffffffu) { acc[2 * lds_slot(r, pm)] = a0[k]; acc[2 * lds_slot(r, pm) + 1] = a1[k]; }
 #else
             if (r < cnt) {
                 atomicAdd(&acc[2 * lds_slot(r, pm)], (ACC)a0[k]);
@@ -444,7 +446,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const unsigned r = idx8[k] - base;
+#if defined(SCATTER_DBG) && SCATTER_DBG == 4
+                    if (r == 0x7fffffffu) {
+#else
                     if (r < cnt) {
+#endif
                         const float w = corner_weight(c, k);
                         atomicAdd(&acc[2 * lds_slot(r, pm)], (ACC)(w * gv.x));
                         atomicAdd(&acc[2 * lds_slot(r, pm) + 1], (ACC)(w * gv.y));

@@ -600,6 +600,34 @@ __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------ counter-based uniforms
+// The reference draws its jitter (torch.rand((n, S)), scene_rep.py:437) and the TV lattice offset (torch.rand(6),
+// slam.py:198-203) from torch's generator: two launches per iteration that produce nothing but random numbers.  A BA
+// iteration can draw them itself instead (rfx_ba_desc.seed_u): element e of stream `stream` is word 0 of
+// Philox4x32-10(counter = (e, stream), key = seed), mapped to [0, 1) with 24 bits like torch's float uniform.
+// rfx_uniform_draws fills a buffer with the same numbers (the stage-by-stage issue and the tests use it).
+__device__ __forceinline__ uint32_t philox_word0(uint64_t seed, uint32_t stream, uint64_t e) {
+    uint32_t c0 = (uint32_t)e, c1 = (uint32_t)(e >> 32), c2 = stream, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__device__ __forceinline__ float draw_uniform(uint64_t seed, uint32_t stream, uint64_t e) {
+    return (float)(philox_word0(seed, stream, e) >> 8) * 5.9604644775390625e-08f;      // 2^-24
+}
+constexpr uint32_t DRAW_STREAM_JITTER = 0u, DRAW_STREAM_LATTICE = 1u;
+
+__global__ __launch_bounds__(256) void uniform_draws_kernel(uint64_t seed, uint32_t stream, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = draw_uniform(seed, stream, (uint64_t)i);
+}
+
 // TV lattice points (mp_slam/slam.py:198-207): P^3 points at spacing `voxel`, anchored at
 // bound_lo + offset with offset = u[0:3] * offset_max + margin, plus a sub-voxel jitter u[3:6], then
 // normalised by the bound.  torch's type promotion is reproduced: a float64 bound -> everything in
@@ -610,10 +638,7 @@ struct LatticeK {
     float voxel, margin;
 };
 
-__global__ __launch_bounds__(256) void tv_lattice_kernel(LatticeK L, const float* __restrict__ u6, float* __restrict__ pts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)L.P * L.P * L.P;
-    if (i >= n) return;
+__device__ __forceinline__ void tv_lattice_point(const LatticeK& L, const float u6[6], int64_t i, float xyz[3]) {
     const int c[3] = {(int)(i / ((int64_t)L.P * L.P)), (int)((i / L.P) % L.P), (int)(i % L.P)};
     const double grid = (double)(L.P) * (double)L.voxel;          // (sample_points - 1) * voxel_size
 #pragma unroll
@@ -630,8 +655,18 @@ __global__ __launch_bounds__(256) void tv_lattice_kernel(LatticeK L, const float
             const float p = ((float)c[d] * L.voxel + (float)L.lo[d]) + off;
             out = L.normalise ? (p - (float)L.lo[d]) / ext : p;
         }
-        pts[i * 3 + d] = out;
+        xyz[d] = out;
     }
+}
+
+__global__ __launch_bounds__(256) void tv_lattice_kernel(LatticeK L, const float* __restrict__ u6, float* __restrict__ pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)L.P * L.P * L.P;
+    if (i >= n) return;
+    const float u[6] = {u6[0], u6[1], u6[2], u6[3], u6[4], u6[5]};
+    float x[3];
+    tv_lattice_point(L, u, i, x);
+    pts[i * 3] = x[0]; pts[i * 3 + 1] = x[1]; pts[i * 3 + 2] = x[2];
 }
 
 // ------------------------------------------------------------------ distinct random indices
@@ -717,18 +752,20 @@ __global__ __launch_bounds__(256) void gather_rays_kernel(GatherK g, float* __re
 
 // gather_rays_kernel + sample_z_kernel + ray_points_kernel in one launch, wave = ray (the three stages of a BA
 // iteration's ray batch are each a few microseconds of launch-bound work).  Same expressions, so the outputs are
-// bit-identical to the three separate launches.
-__global__ __launch_bounds__(256) void ray_setup_kernel(GatherK g, SamplerK s, BoxK box, const float* __restrict__ u01,
-                                                        float* __restrict__ rays_o, float* __restrict__ rays_d,
-                                                        float* __restrict__ tgt_rgb, float* __restrict__ tgt_d,
-                                                        float* __restrict__ d_cam, int* __restrict__ pose_idx,
-                                                        float* __restrict__ z_vals, float* __restrict__ x01) {
-    __shared__ float zsh[4][MAX_S];
+// bit-identical to the three separate launches.  block / n_blocks: the block's place among the blocks that run this
+// body (the prologue kernel below gives the rest of its grid to other work).  seed_u != 0 (and no u01): the jitter
+// uniforms are drawn here (draw_uniform, stream DRAW_STREAM_JITTER, element ray * S + sample).
+struct RayOut {
+    float *rays_o, *rays_d, *tgt_rgb, *tgt_d, *d_cam; int* pose_idx; float *z_vals, *x01;
+};
+
+__device__ __forceinline__ void ray_setup_body(const GatherK& g, const SamplerK& s, const BoxK& box, const float* __restrict__ u01,
+                                               uint64_t seed_u, const RayOut& out, int block, int n_blocks, float (*zsh)[MAX_S]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = s.n_range_d + s.n_samples_d;
     float* zs = zsh[wv];
     const int64_t n = g.n_kf + g.n_cur;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += (int64_t)gridDim.x * 4) {
+    for (int64_t i = (int64_t)block * 4 + wv; i < n; i += (int64_t)n_blocks * 4) {
         const float* ray;
         int k;
         if (i < g.n_kf) {
@@ -753,22 +790,60 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(GatherK g, SamplerK s, B
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                rays_d[i * 3 + r] = d[r]; rays_o[i * 3 + r] = o[r]; tgt_rgb[i * 3 + r] = ray[3 + r]; d_cam[i * 3 + r] = dc[r];
+                out.rays_d[i * 3 + r] = d[r]; out.rays_o[i * 3 + r] = o[r]; out.tgt_rgb[i * 3 + r] = ray[3 + r]; out.d_cam[i * 3 + r] = dc[r];
             }
-            tgt_d[i] = td;
-            pose_idx[i] = k;
+            out.tgt_d[i] = td;
+            out.pose_idx[i] = k;
         }
         sample_ray(s, td, zs, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to it
         __builtin_amdgcn_wave_barrier();
         for (int j = lane; j < S; j += 64) {
             float z = zs[j];
-            if (s.perturb > 0.0f && u01) z = jitter(zs, j, S, u01[i * S + j]);
-            z_vals[i * S + j] = z;
+            if (s.perturb > 0.0f) {
+                if (u01) z = jitter(zs, j, S, u01[i * S + j]);
+                else if (seed_u) z = jitter(zs, j, S, draw_uniform(seed_u, DRAW_STREAM_JITTER, (uint64_t)(i * S + j)));
+            }
+            out.z_vals[i * S + j] = z;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x01[(i * S + j) * 3 + c] = normalise(box, c, o[c] + d[c] * z);
+            for (int c = 0; c < 3; ++c) out.x01[(i * S + j) * 3 + c] = normalise(box, c, o[c] + d[c] * z);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Everything at the head of a BA iteration that depends on nothing computed in it, in ONE launch (a dependent kernel
+// boundary costs 3-5 us on this part, more than most of these stages' work): blocks [0, nb_rays) build the ray batch
+// (ray_setup_body), the next nb_stage blocks refresh the decoder's MFMA operand image from the weights the optimizer just
+// stepped (stage_weights_kernel's work), the rest lay out the TV lattice and look its features up, thread = (lattice
+// point, level) like grid_encode_forward_lp_kernel (tv_lattice_kernel's + that kernel's work; lp_shift = 4, F = 2).
+struct TvEncK {
+    LatticeK L; rfx_grid_desc g; const float* table; const float* u6; float* pts; float* feat;
+};
+
+__global__ __launch_bounds__(256) void ba_prologue_kernel(GatherK g, SamplerK s, BoxK box, const float* __restrict__ u01,
+                                                          uint64_t seed_u, RayOut out, int nb_rays, FieldK f,
+                                                          float* __restrict__ staged, int nb_stage, TvEncK tv) {
+    __shared__ float zsh[4][MAX_S];
+    const int b = blockIdx.x;
+    if (b < nb_rays) {
+        ray_setup_body(g, s, box, u01, seed_u, out, b, nb_rays, zsh);
+    } else if (b < nb_rays + nb_stage) {
+        const int i = (b - nb_rays) * 256 + threadIdx.x;
+        if (i < ALL_SLOTS * 64) staged[i] = staged_weight(f, i >> 6, i & 63);
+    } else {
+        float* us = zsh[0];
+        if (threadIdx.x < 6) us[threadIdx.x] = tv.u6 ? tv.u6[threadIdx.x] : draw_uniform(seed_u, DRAW_STREAM_LATTICE, (uint64_t)threadIdx.x);
+        __syncthreads();
+        const int64_t gid = (int64_t)(b - nb_rays - nb_stage) * 256 + threadIdx.x;
+        const int64_t p = gid >> 4;
+        const int l = (int)(gid & 15);
+        if (p >= (int64_t)tv.L.P * tv.L.P * tv.L.P || l >= tv.g.n_levels) return;
+        const float u[6] = {us[0], us[1], us[2], us[3], us[4], us[5]};
+        float x[3];
+        tv_lattice_point(tv.L, u, p, x);
+        if (l == 0) { tv.pts[p * 3] = x[0]; tv.pts[p * 3 + 1] = x[1]; tv.pts[p * 3 + 2] = x[2]; }
+        reinterpret_cast<float2*>(tv.feat + p * (int64_t)(tv.g.n_levels * 2))[l] = lookup2(tv.table, get_level(tv.g, l), x);
     }
 }
 
@@ -1014,6 +1089,15 @@ int rfx_tv_lattice(const float* u6, int P, float voxel, float margin, const doub
     return RFX_OK;
 }
 
+int rfx_uniform_draws(uint64_t seed, int stream_id, int64_t n, float* out, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
+    if (!out || n < 0 || stream_id < 0) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(uniform_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
+                       (uint32_t)stream_id, n, out);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream) {
     if (k == 0) return RFX_OK;
     if (!out || population <= 0 || k < 0 || k > population) return RFX_ERR_ARG;
@@ -1078,12 +1162,16 @@ int rfx_pose_grad(const float* g_o, const float* g_d, const float* d_cam, const 
 // ---- fused forms used by rfx_ba_forward_backward (internal: declared in rfx_common.h) --------------------------------
 namespace rfx {
 
-// rfx_gather_rays + rfx_sample_z + rfx_ray_points
-int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
-                    const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
-                    uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01,
-                    const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
-                    float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, rfx_stream stream) {
+// rfx_gather_rays + rfx_sample_z + rfx_ray_points, and beside them in the same launch (ba_prologue_kernel)
+// rfx_field_stage_weights (field with a `staged` image: refreshed) and rfx_tv_lattice + rfx_grid_encode_forward of the
+// lattice (tv_pts / tv_feat given).  seed_u != 0: the jitter and lattice uniforms are drawn in the kernel, u01 / u6 are
+// not read.
+int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
+                const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
+                uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01, uint64_t seed_u,
+                const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
+                float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
+                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, rfx_stream stream) {
     const int64_t n = n_kf_samples + n_cur;
     if (n == 0) return RFX_OK;
     if (!rays_o || !rays_d || !target_rgb || !target_d || !d_cam || !pose_idx || !z_vals || !x01 || !bbox) return RFX_ERR_ARG;
@@ -1094,8 +1182,30 @@ int ray_batch_setup(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, c
     SamplerK k;
     rc = make_sampler(sampler, &k);
     if (rc) return rc;
-    hipLaunchKernelGGL(ray_setup_kernel, dim3(ray_grid(n)), dim3(256), 0, as_stream(stream), g, k, make_box(bbox, bbox_f64), u01,
-                       rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01);
+    FieldK fk = {};
+    int nb_stage = 0;
+    float* staged = nullptr;
+    if (field && field->staged) {
+        rc = make_fieldk(field, &fk);
+        if (rc) return rc;
+        staged = const_cast<float*>(field->staged);
+        fk.staged = nullptr;
+        nb_stage = (ALL_SLOTS * 64 + 255) / 256;
+    }
+    TvEncK tv = {};
+    int nb_tv = 0;
+    if (tv_pts) {
+        if (!field || !tv_feat || tv_P <= 0 || !(tv_voxel > 0.f) || (!u6 && !seed_u)) return RFX_ERR_ARG;
+        if (field->hash.n_feat != 2 || field->hash.n_levels < 1 || field->hash.n_levels > 16) return RFX_ERR_UNSUPPORTED;
+        for (int d = 0; d < 3; ++d) { tv.L.lo[d] = bbox[2 * d]; tv.L.hi[d] = bbox[2 * d + 1]; }
+        tv.L.f64 = bbox_f64 ? 1 : 0; tv.L.normalise = tv_normalise ? 1 : 0; tv.L.P = tv_P; tv.L.voxel = tv_voxel; tv.L.margin = tv_margin;
+        tv.g = field->hash; tv.table = field->hash_table; tv.u6 = seed_u ? nullptr : u6; tv.pts = tv_pts; tv.feat = tv_feat;
+        nb_tv = (int)(((int64_t)tv_P * tv_P * tv_P * 16 + 255) / 256);
+    }
+    const RayOut out = {rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01};
+    const int nb_rays = ray_grid(n);
+    hipLaunchKernelGGL(ba_prologue_kernel, dim3(nb_rays + nb_stage + nb_tv), dim3(256), 0, as_stream(stream), g, k,
+                       make_box(bbox, bbox_f64), seed_u ? nullptr : u01, seed_u, out, nb_rays, fk, staged, nb_stage, tv);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -134,6 +134,11 @@ class DirectIterations:
         self.unused_gradients = bool(mapper.config["mapping"].get("unused_gradients", False))
         # the TV value itself (SLAM.smoothness's return) only matters through its gradient: evaluated on request
         self.report_tv = bool(mapper.config["mapping"].get("report_tv", False))
+        # The sampler jitter (torch.rand((n, S))) and the TV lattice offset (torch.rand(6)) are drawn inside the iteration's
+        # first kernel from a seed taken from python's generator (rfx_ba_desc.seed_u), like the ray draws; torch_draws = True
+        # takes them from torch's generator in the autograd formulation's order instead (two more launches per iteration).
+        self.torch_draws = bool(mapper.config["mapping"].get("torch_draws", False))
+        self.last_seed_u = 0            # seed of the latest iteration's own draws (tests reproduce them: oracle/draws_oracle.py)
         self._count = 0
         self.iterations = {"map": 0, "pose": 0}          # issued so far (bench.py: launches per entry point)
 
@@ -214,10 +219,16 @@ class DirectIterations:
         d.n_cur = n - d.n_kf_samples
         d.seed_kf, d.seed_cur = random.getrandbits(64), random.getrandbits(64)     # same draw order as the autograd path
         d.poses16, d.K = poses_ptr, K
-        if self._perturb:
-            B.u_view(n).uniform_()                       # the draw torch.rand((n, S)) makes
-            d.u_z = p.u
-        t.u6.uniform_()                                   # the draw torch.rand(6) makes
+        if self.torch_draws:
+            d.u_z = None
+            if self._perturb:
+                B.u_view(n).uniform_()                   # the draw torch.rand((n, S)) makes
+                d.u_z = p.u
+            t.u6.uniform_()                               # the draw torch.rand(6) makes
+            d.u6, d.seed_u = p.u6, 0
+        else:
+            d.u_z = d.u6 = None
+            d.seed_u = self.last_seed_u = random.getrandbits(64) | 1
         d.d_poses16 = d_poses_ptr
         if map_grads:
             d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, (p.tv_acc if self.report_tv else None)
@@ -250,8 +261,12 @@ class DirectIterations:
         dev = t.o.device
         # ---- forward (== _MappingFn.forward)
         u_ptr = None
+        seed_u = self.last_seed_u = 0 if self.torch_draws else random.getrandbits(64) | 1      # same place in python's stream as in _run
         if tr["perturb"] > 0.0:
-            t.u.uniform_()                               # the draw torch.rand((n, S)) makes
+            if self.torch_draws:
+                t.u.uniform_()                           # the draw torch.rand((n, S)) makes
+            else:
+                check(lib.rfx_uniform_draws(seed_u, 0, n * S, p.u, st), "rfx_uniform_draws")
             u_ptr = p.u
         sd = model._sampler_desc()
         check(lib.rfx_sample_z(C.byref(sd), p.td, u_ptr, n, p.z, st), "rfx_sample_z")
@@ -271,7 +286,10 @@ class DirectIterations:
         # ---- TV term forward (== SLAM.smoothness / _SmoothFn.forward)
         enc = model.embed_res_fn
         table_ptr = enc.params.data_ptr()
-        t.u6.uniform_()                                   # the draw torch.rand(6) makes
+        if self.torch_draws:
+            t.u6.uniform_()                               # the draw torch.rand(6) makes
+        else:
+            check(lib.rfx_uniform_draws(seed_u, 1, 6, p.u6, st), "rfx_uniform_draws")
         n_tv = P * P * P
         if map_grads:
             check(lib.rfx_tv_lattice(p.u6, P, float(tr["smooth_vox"]), float(tr["smooth_margin"]), model._bbox6, model._bbox_f64,

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import random
+
 import torch
 
 from .. import _lib
@@ -61,9 +63,15 @@ class ShardedIterations(DirectIterations):
                                                  self._weights, cap_K)
         G.bind(n, K)
         self._rays(G, current_rays, poses_ptr, K, st)           # same seeds on every rank: the same n rays
-        if tr["perturb"] > 0.0:
-            G.t.u.uniform_()                                      # the draw torch.rand((n, S)) makes, on every rank
-        G.t.u6.uniform_()                                         # the draw torch.rand(6) makes
+        if self.torch_draws:
+            if tr["perturb"] > 0.0:
+                G.t.u.uniform_()                                  # the draw torch.rand((n, S)) makes, on every rank
+            G.t.u6.uniform_()                                     # the draw torch.rand(6) makes
+        else:                                                     # the draws DirectIterations._run lets the library make
+            seed_u = random.getrandbits(64) | 1
+            if tr["perturb"] > 0.0:
+                check(lib.rfx_uniform_draws(seed_u, 0, n * S, G.p.u, st), "rfx_uniform_draws")
+            check(lib.rfx_uniform_draws(seed_u, 1, 6, G.p.u6, st), "rfx_uniform_draws")
         # ---- this rank's share: rays rank, rank + world, ...
         sel = torch.arange(self.rank, n, self.world, device=dev)
         n_loc = int(sel.numel())

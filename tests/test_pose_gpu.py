@@ -225,6 +225,7 @@ def test_direct_iterations_equal_autograd_iterations():
     mp, model, slam = pipe.mapper, pipe.model, pipe.slam
     assert mp._direct_iterations() is not None            # the pipeline above ran on the direct path
     direct = DirectIterations(mp)
+    direct.torch_draws = True                             # both formulations take their uniforms from torch's generator
     b = frames[10]
     cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
     K = len(mp.keyframe) + 1
@@ -425,3 +426,16 @@ def test_error_statuses_of_the_round_one_entry_points():
     d.d_w = None                                # neither: only allowed with somewhere to put the pose gradients
     assert lib.rfx_ba_forward_backward(C.byref(d), base, need, st) == ERR_ARG
     torch.cuda.synchronize()
+
+
+def test_uniform_draws_match_oracle_bit_exact():
+    """rfx_uniform_draws (the uniforms a BA iteration draws for itself, include/rfx.h) against oracle/draws_oracle.py."""
+    import numpy as np
+    from oracle import draws_oracle as DO
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    for seed, stream, n in ((1, 0, 6), (0x9E3779B97F4A7C15, 0, 135936), (0xFFFFFFFFFFFFFFFF, 1, 6), (0x0123456789ABCDEF, 1, 70001)):
+        out = torch.empty(n, device="cuda")
+        L.check(lib.rfx_uniform_draws(seed, stream, n, L.ptr(out), L.stream_ptr(out.device)), "rfx_uniform_draws")
+        assert np.array_equal(out.cpu().numpy(), DO.uniform_draws(seed, stream, n)), (seed, stream, n)
+    assert lib.rfx_uniform_draws(1, 0, 4, None, None) != 0          # no output buffer

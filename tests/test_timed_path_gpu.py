@@ -18,6 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from oracle import draws_oracle as DO  # noqa: E402
 from oracle import field_oracle as FO  # noqa: E402
 from test_field_gpu import _close, _f64_params, _grad_close, _level_groups, _oracle_params  # noqa: E402
 
@@ -119,9 +120,15 @@ def test_one_call_ba_iteration_matches_oracle_at_bench_size(name, frames):
     _close(f["o"], pa[pidx, :3, 3], 0, 1e-7, "rays_o")
     _close(f["d"], torch.sum(f["d_cam"][:, None, :] * pa[pidx, :3, :3], -1), 1e-6, 1e-6, "rays_d")
     cam = cfg["cam"]
+    # the uniforms the call drew for itself (rfx_ba_desc.seed_u): restated by oracle/draws_oracle.py
+    assert not direct.torch_draws and direct.last_seed_u
+    u_z = torch.from_numpy(DO.uniform_draws(direct.last_seed_u, 0, n * S)).view(n, S)
     z_ref = FO.sample_z_vals(f["td"][:, None], cam["near"], cam["far"], tr["range_d"], tr["n_range_d"], tr["n_samples_d"],
-                             tr["perturb"], B.t.u[:n * S].view(n, S).cpu())
+                             tr["perturb"], u_z)
     _close(f["z"], z_ref, 1e-6, 2e-6, "z_vals")
+    u6 = torch.from_numpy(DO.uniform_draws(direct.last_seed_u, 1, 6))
+    lat = slam.smoothness_points_torch(u6.to(dev), tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"]).cpu()   # slam.py:198-207
+    _close(f["pts"], lat.reshape(-1, 3).float(), 0, 2e-7, "TV lattice")
     for t in (fp.hash_table, fp.W1, fp.W2, fp.W3, fp.W4):
         t.requires_grad_(True)
     rend, ls, total = _oracle_iteration(fp, cfg, bbox, f["o"], f["d"], f["z"], f["tgt"], f["td"], False, f["pts"])

@@ -10,12 +10,17 @@ wp = MappingPipeline(wcfg, n_frames=20, seed=1000)
 wf = wp.prefetch(list(range(12))); wp.start(wf[0])
 for i in range(1, 12): wp.step(i, wf[i])
 torch.cuda.synchronize(); del wp, wf; gc.collect()
-pipe = MappingPipeline(cfg, n_frames=40)
-frames = pipe.prefetch(list(range(30)))
+pipe = MappingPipeline(cfg, n_frames=140)
+probe = [int(a) for a in sys.argv[1:]] or [6, 11]
+frames = pipe.prefetch(list(range(max(probe) + 6)))
 pipe.start(frames[0], first_iters=20)
 for i in range(1, 6): pipe.step(i, frames[i])
 torch.cuda.synchronize()
-for i in (6, 11):
+done = 6
+for i in probe:
+    for j in range(done, i):
+        pipe.step(j, frames[j])
+    done = i + 5
     for j in range(i, i + 5):
         pr = cProfile.Profile()
         torch.cuda.synchronize(); t0 = time.time()
@@ -26,4 +31,4 @@ for i in (6, 11):
         torch.cuda.synchronize(); tot = time.time() - t0
         if j == i:
             print(f"frame {j}: host {host * 1e3:.2f} ms, total {tot * 1e3:.2f} ms")
-            s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats(18); print(s.getvalue()[:3500])
+            s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14); print(s.getvalue()[:3000])
