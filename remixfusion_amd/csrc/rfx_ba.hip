@@ -112,13 +112,14 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     hipStream_t st = as_stream(stream);
     const int64_t nS = n * S, nt = (int64_t)P * P * P;
     // ---- ray batch (rays, S1, points); beside it in the same launch: decoder weights -> MFMA operand image (the optimizers
-    //      update the weights in place between calls) and the TV lattice with its table lookups, which depend on nothing computed here
+    //      update the weights in place between calls) the TV lattice with its table lookups and the zero-fill of the hash gradient, which depend on nothing computed here
     const bool tv_on = map_grads || b->tv_sum;
     if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
     RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                         b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
                         b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, P, b->tv_voxel,
-                        b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr, stream));
+                        b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
+                        map_grads ? b->d_hash : nullptr, map_grads ? (int64_t)b->hash_entries * F : 0, stream));
     // ---- forward
     // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
     RFX_TRY(rfx_field_forward_stash(&b->field, w.x01, nS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
@@ -126,7 +127,8 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
     int n_partials = 0;
     RFX_TRY(composite_loss_forward(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc,
-                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, &n_partials, stream));       // R1 + L1 sums
+                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, &n_partials, map_grads ? w.feat : nullptr, P,
+                                   L * F, b->tv_scale, map_grads ? w.dfeat : nullptr, stream));   // R1 + L1 sums | TV1 backward
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));      // (its features: the prologue's)
     // ---- backward
@@ -137,11 +139,13 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
     else RFX_TRY(rfx_field_backward_chain_inputs_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    if (map_grads) {
-        RFX_HIP_TRY(hipMemsetAsync(b->d_hash, 0, (size_t)b->hash_entries * F * sizeof(float), st));
-        float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
-        RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    float* dw1 = b->d_w; float* dw2 = dw1 ? dw1 + 32 * 81 : nullptr; float* dw3 = dw1 ? dw2 + 16 * 32 : nullptr;
+    float* dw4 = dw1 ? dw3 + 32 * 66 : nullptr;
+    if (map_grads && !b->d_poses16) {     // map phase: weight gradients and table scatter back to back (they share a launch)
+        return field_backward_weights_scatter(&b->field, w.x01, nS, w.d_raw, dw1, dw2, dw3, dw4, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws,
+                                              w.bwd_bytes, w.scat_ws, w.scat_bytes, stream);
     }
+    if (map_grads) RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
     if (b->d_poses16) {
         RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));
         RFX_TRY(rfx_field_backward_dx(&b->field, w.x01, nS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
@@ -151,7 +155,6 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
         RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
     }
     if (map_grads) {
-        RFX_TRY(rfx_tv_backward(w.feat, P, L * F, b->tv_scale, nullptr, w.dfeat, stream));
         RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
                                                   w.scat_bytes, stream));
     }

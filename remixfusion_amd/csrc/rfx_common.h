@@ -39,12 +39,18 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01, uint64_t seed_u,
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
-                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, rfx_stream stream);
+                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
+                rfx_stream stream);
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip
+int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
+                                   float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
+                                   float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
+                                   rfx_stream stream);                                              // rfx_field.hip
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
                            int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, int* n_partials, rfx_stream stream);
+                           float* rgb_map, float* depth_map, double* sums, int* n_partials, const float* tv_feat, int tv_P, int tv_C,
+                           float tv_scale, float* tv_dfeat, rfx_stream stream);     // + rfx_tv_backward beside it (tv_dfeat given)
 int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
                                 const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
                                 float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,

@@ -311,8 +311,40 @@ struct ScatterSrc {
     const int* n_sel;         // device-side row count, <= n (null: n)
 };
 
+// Second stage of the decoder's weight gradients (field_dw_reduce_kernel below: 16 slices of the partial list, each added in
+// order, then the slices in order) for a 256-thread block: 16 outputs x 16 slices, the same sums in the same order.  It rides
+// in the staging launch of the table scatter, which follows the weight-gradient kernel in a BA iteration and has nothing
+// to do with it: one kernel boundary less.
+constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
+struct DwJob { const float* partial; int n_partials; float *dw1, *dw2, *dw3, *dw4; };
+constexpr int DW_JOB_BLOCKS = (DW_TOTAL + 15) / 16;
+
+__device__ __forceinline__ void dw_reduce_overwrite_16(const DwJob& j, int block, float (*red)[16]) {
+    const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int i = block * 16 + col;
+    float s = 0.f;
+    if (i < DW_TOTAL) {
+#pragma unroll 8
+        for (int k = slice; k < j.n_partials; k += 16) s += j.partial[(size_t)k * DW_TOTAL + i];
+    }
+    red[slice][col] = s;
+    __syncthreads();
+    if (slice != 0 || i >= DW_TOTAL) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][col];
+    const int o1 = N_H * N_IN1, o2 = o1 + N_OUT2 * N_H, o3 = o2 + N_H * N_IN3;
+    float* d = i < o1 ? (j.dw1 ? j.dw1 + i : nullptr) : i < o2 ? (j.dw2 ? j.dw2 + (i - o1) : nullptr)
+             : i < o3 ? (j.dw3 ? j.dw3 + (i - o2) : nullptr) : (j.dw4 ? j.dw4 + (i - o3) : nullptr);
+    if (d) *d = s;
+}
+
 __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, ScatterSrc b, ScatterPlan plan, int n_levels,
-                                                            float* __restrict__ scratch) {
+                                                            float* __restrict__ scratch, int nb_stage, DwJob dw) {
+    if ((int)blockIdx.x >= nb_stage) {
+        __shared__ float red[16][16];
+        dw_reduce_overwrite_16(dw, (int)blockIdx.x - nb_stage, red);
+        return;
+    }
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t slots = plan.slots;
     if (s >= slots) return;
@@ -717,8 +749,9 @@ static int launch_binned_level(const rfx_grid_desc& g, int l, const ScatterSrc& 
 static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
                                const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0, const int* perm = nullptr,
-                               const int* n_sel = nullptr) {
+                               const int* n_sel = nullptr, const DwJob* dw = nullptr, bool* dw_taken = nullptr) {
     ScatterPlan plan;
+    if (dw_taken) *dw_taken = false;
     const int64_t n_all = n + n_b;
     const bool staged_ok = scratch && n_all >= SCATTER_MIN_POINTS;
     // levels cut into many segments are binned (one at a time, below); the others share one LDS sweep
@@ -755,9 +788,11 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
         plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
         plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
         if ((size_t)plan.slots * (2 * g.n_levels + 3) > scratch_floats) return RFX_ERR_WORKSPACE;
-        hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)((plan.slots + 255) / 256)), dim3(256), 0, st, a, b, plan, g.n_levels,
-                           scratch);
+        const int nb_stage = (int)((plan.slots + 255) / 256);
+        hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)(nb_stage + (dw ? DW_JOB_BLOCKS : 0))), dim3(256), 0, st, a, b, plan,
+                           g.n_levels, scratch, nb_stage, dw ? *dw : DwJob{});
         RFX_LAUNCH_CHECK();
+        if (dw && dw_taken) *dw_taken = true;
         const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
         static bool attr_set[64] = {};       // the attribute is per device
         int dev = 0;
@@ -822,7 +857,6 @@ __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __res
 // the weight-gradient kernel's LDS image of a batch is piece-major as well, so its fills are contiguous reads.
 constexpr int LD_DX1 = 96;
 constexpr int PC_EMB = 8, PC_X1 = 13, PC_G = 5, PC_DY2 = 4;      // float4 pieces per point
-constexpr int DW_TOTAL = N_H * N_IN1 + N_OUT2 * N_H + N_H * N_IN3 + N_OUT4 * N_H;   // 5312
 constexpr int DW_BLOCKS = 256;       // the weight-gradient kernel is persistent: at most one block per CU
 
 // B-operand (k-step) images of W1..W4 for the weight-gradient kernel's recompute of H1 / H3, 84 slots of 64 lanes
@@ -1643,7 +1677,9 @@ int rfx_field_backward_chain_weights_stashed(const rfx_field_desc* f, const floa
 }
 
 static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
-                                   void* workspace, size_t workspace_bytes, rfx_stream stream, bool overwrite) {
+                                   void* workspace, size_t workspace_bytes, rfx_stream stream, bool overwrite,
+                                   DwJob* defer = nullptr) {
+    if (defer) *defer = DwJob{};
     if (!dw1 && !dw2 && !dw3 && !dw4) return RFX_OK;
     hipStream_t st = as_stream(stream);
     if (n == 0) {           // nothing to add; the overwriting form still has to leave zeros
@@ -1670,6 +1706,10 @@ static int launch_backward_weights(int64_t n, const float* draw4, float* dw1, fl
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(DW_BLOCKS, ((n + 31) / 32 + 3) / 4));
     hipLaunchKernelGGL(field_dw_recompute_kernel, dim3(blocks), dim3(512), DWR_LDS, st, ws, n, sel_on(n) ? ws.sel_hdr : nullptr, ws.partial);
     RFX_LAUNCH_CHECK();
+    if (defer && overwrite) {             // the caller issues the second stage (beside the scatter's staging pass)
+        *defer = DwJob{ws.partial, blocks, dw1, dw2, dw3, dw4};
+        return RFX_OK;
+    }
     if (overwrite)
         hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, st, ws.partial, blocks, dw1, dw2, dw3, dw4);
     else
@@ -1758,6 +1798,43 @@ int rfx_field_backward(const rfx_field_desc* f, const float* x01, int64_t n, con
 }  // extern "C"
 
 namespace rfx {
+// field_backward_weights_overwrite followed by rfx_field_backward_scatter_merged, with the weight gradients' second stage
+// moved into the scatter's staging launch when there is one (same sums in the same order: bit-identical results)
+int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
+                                   float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
+                                   float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
+                                   rfx_stream stream) {
+    if (!d_hash || (n == 0 && extra_n == 0)) {
+        int rc = launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true);
+        if (rc) return rc;
+        return rfx_field_backward_scatter_merged(f, x01, n, extra_x01, extra_dfeat, extra_n, d_hash, workspace, workspace_bytes, scatter_ws,
+                                                 scatter_bytes, stream);
+    }
+    FieldK k;
+    int rc = make_fieldk(f, &k);
+    if (rc) return rc;
+    if (n < 0 || extra_n < 0 || (n > 0 && !x01) || (extra_n > 0 && (!extra_x01 || !extra_dfeat))) return RFX_ERR_ARG;
+    if (n > 0 && (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n))) return RFX_ERR_WORKSPACE;
+    if (scatter_ws && (scatter_bytes < rfx_grid_encode_backward_workspace_bytes(n + extra_n, k.hash.n_levels) || ((uintptr_t)scatter_ws & 7)))
+        return RFX_ERR_WORKSPACE;
+    DwJob job;
+    rc = launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true, &job);
+    if (rc) return rc;
+    BwdWs ws{};
+    if (n > 0) ws = carve(workspace, n);
+    bool taken = false;
+    rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
+                             extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n, sel_on(n) ? ws.perm : nullptr,
+                             sel_on(n) ? ws.sel_hdr : nullptr, job.partial ? &job : nullptr, &taken);
+    if (rc) return rc;
+    if (job.partial && !taken) {          // no staging launch on this path: the stand-alone second stage
+        hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, as_stream(stream), job.partial,
+                           job.n_partials, job.dw1, job.dw2, job.dw3, job.dw4);
+    }
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 // rfx_field_backward_weights that OVERWRITES dw1..dw4 (no zero-fill needed before it); used by rfx_ba_forward_backward
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream) {

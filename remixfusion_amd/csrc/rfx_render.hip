@@ -384,15 +384,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_forward_kernel(Loss
 
 // composite_forward_kernel + mapping_loss_forward_kernel in one launch (same ray-to-wave dealing and the same
 // expressions as the loss kernel, fed from registers instead of the maps just written: bit-identical partial sums)
-__global__ __launch_bounds__(LOSS_THREADS) void composite_loss_forward_kernel(LossK L, const float4* __restrict__ raw,
-                                                                              const float* __restrict__ zv,
-                                                                              const float* __restrict__ tgt_rgb,
-                                                                              const float* __restrict__ tgt_d, int64_t n_rays, int S,
-                                                                              float trunc, float sc, float* __restrict__ rgb_map,
-                                                                              float* __restrict__ depth_map, double* __restrict__ sums) {
+// block / n_blocks: the block's place among the blocks that run this body
+__device__ __forceinline__ void composite_loss_forward_body(const LossK& L, const float4* __restrict__ raw,
+                                                            const float* __restrict__ zv, const float* __restrict__ tgt_rgb,
+                                                            const float* __restrict__ tgt_d, int64_t n_rays, int S, float trunc,
+                                                            float sc, float* __restrict__ rgb_map, float* __restrict__ depth_map,
+                                                            double* __restrict__ sums, int block, int n_blocks, double* red) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
-    for (int64_t ray = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * wpb) {
+    for (int64_t ray = (int64_t)block * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)n_blocks * wpb) {
         float s[2], z[2];
         float4 rv[2];
         bool vs[2];
@@ -439,15 +439,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void composite_loss_forward_kernel(Lo
             }
         }
     }
-    __shared__ double red[LOSS_THREADS / 64];
     a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
     a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
     a_nsdf = block_sum_d(a_nsdf, red);
     if (threadIdx.x == 0) {
-        double* o = sums + (size_t)blockIdx.x * 8;
+        double* o = sums + (size_t)block * 8;
         o[0] = a_rgb; o[1] = a_dep; o[2] = a_val; o[3] = a_fs; o[4] = a_sdf; o[5] = a_nfs; o[6] = a_nsdf; o[7] = 0.0;
     }
 }
+
 
 // lc[0..3] = losses (rgb, depth, sdf, fs), lc[4..7] = coef: d loss_i / d (its squared-error sum), from the per-block
 // partial sums; for a 256-thread block, lc in LDS, valid for all threads on return.
@@ -580,11 +580,11 @@ __global__ __launch_bounds__(256) void tv_forward_kernel(const float* __restrict
 }
 
 // dfeat = (*gscale) * scale * d(sum)/d feat
-__global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restrict__ feat, int P, int Cn, float scale,
-                                                          const float* __restrict__ gscale, float* __restrict__ dfeat) {
+__device__ __forceinline__ void tv_backward_body(const float* __restrict__ feat, int P, int Cn, float scale,
+                                                 const float* __restrict__ gscale, float* __restrict__ dfeat, int block, int n_blocks) {
     const int64_t total = (int64_t)P * P * P * Cn;
     const float k = 2.0f * scale * (gscale ? gscale[0] : 1.0f);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < total; i += (int64_t)n_blocks * blockDim.x) {
         const int64_t cell = i / Cn;
         const int z = (int)(cell % P), y = (int)((cell / P) % P), x = (int)(cell / ((int64_t)P * P));
         const float v = feat[i];
@@ -597,6 +597,31 @@ __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restric
         if (z + 1 < P) g -= feat[i + sz] - v;
         if (z > 0) g += v - feat[i - sz];
         dfeat[i] = k * g;
+    }
+}
+
+__global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restrict__ feat, int P, int Cn, float scale,
+                                                          const float* __restrict__ gscale, float* __restrict__ dfeat) {
+    tv_backward_body(feat, P, Cn, scale, gscale, dfeat, blockIdx.x, gridDim.x);
+}
+
+// composite_forward + the loss sums of a BA iteration's rays (blocks [0, nb_loss)) and, beside them, the gradient of the
+// TV term w.r.t. the lattice features the prologue looked up (the remaining blocks): the two are independent, and both only
+// feed the backward that follows.
+struct TvBackK { const float* feat; int P, Cn; float scale; float* dfeat; };
+
+__global__ __launch_bounds__(LOSS_THREADS) void composite_loss_tv_kernel(LossK L, const float4* __restrict__ raw,
+                                                                         const float* __restrict__ zv,
+                                                                         const float* __restrict__ tgt_rgb,
+                                                                         const float* __restrict__ tgt_d, int64_t n_rays, int S,
+                                                                         float trunc, float sc, float* __restrict__ rgb_map,
+                                                                         float* __restrict__ depth_map, double* __restrict__ sums,
+                                                                         int nb_loss, TvBackK tv) {
+    __shared__ double red[LOSS_THREADS / 64];
+    if ((int)blockIdx.x < nb_loss) {
+        composite_loss_forward_body(L, raw, zv, tgt_rgb, tgt_d, n_rays, S, trunc, sc, rgb_map, depth_map, sums, blockIdx.x, nb_loss, red);
+    } else {
+        tv_backward_body(tv.feat, tv.P, tv.Cn, tv.scale, nullptr, tv.dfeat, (int)blockIdx.x - nb_loss, (int)gridDim.x - nb_loss);
     }
 }
 
@@ -816,14 +841,17 @@ __device__ __forceinline__ void ray_setup_body(const GatherK& g, const SamplerK&
 // boundary costs 3-5 us on this part, more than most of these stages' work): blocks [0, nb_rays) build the ray batch
 // (ray_setup_body), the next nb_stage blocks refresh the decoder's MFMA operand image from the weights the optimizer just
 // stepped (stage_weights_kernel's work), the rest lay out the TV lattice and look its features up, thread = (lattice
-// point, level) like grid_encode_forward_lp_kernel (tv_lattice_kernel's + that kernel's work; lp_shift = 4, F = 2).
+// point, level) like grid_encode_forward_lp_kernel (tv_lattice_kernel's + that kernel's work; lp_shift = 4, F = 2), and the
+// last blocks zero-fill a buffer (the hash gradient, which the end of the iteration accumulates into).
+constexpr int PROLOGUE_ZERO = 8192;
 struct TvEncK {
     LatticeK L; rfx_grid_desc g; const float* table; const float* u6; float* pts; float* feat;
 };
 
 __global__ __launch_bounds__(256) void ba_prologue_kernel(GatherK g, SamplerK s, BoxK box, const float* __restrict__ u01,
                                                           uint64_t seed_u, RayOut out, int nb_rays, FieldK f,
-                                                          float* __restrict__ staged, int nb_stage, TvEncK tv) {
+                                                          float* __restrict__ staged, int nb_stage, TvEncK tv, int nb_tv,
+                                                          float* __restrict__ zero, int64_t zero_floats) {
     __shared__ float zsh[4][MAX_S];
     const int b = blockIdx.x;
     if (b < nb_rays) {
@@ -831,6 +859,16 @@ __global__ __launch_bounds__(256) void ba_prologue_kernel(GatherK g, SamplerK s,
     } else if (b < nb_rays + nb_stage) {
         const int i = (b - nb_rays) * 256 + threadIdx.x;
         if (i < ALL_SLOTS * 64) staged[i] = staged_weight(f, i >> 6, i & 63);
+    } else if (b >= nb_rays + nb_stage + nb_tv) {
+        // zero-fill (the hash-gradient buffer the iteration's last kernel accumulates into): PROLOGUE_ZERO floats per block
+        const int64_t base = (int64_t)(b - nb_rays - nb_stage - nb_tv) * PROLOGUE_ZERO;
+        const int64_t end = min(zero_floats, base + PROLOGUE_ZERO);
+        if ((((uintptr_t)zero) & 15) == 0) {
+            for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += 256 * 4) *reinterpret_cast<float4*>(zero + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t i = base + ((end - base) & ~(int64_t)3) + threadIdx.x; i < end; i += 256) zero[i] = 0.f;
+        } else {
+            for (int64_t i = base + threadIdx.x; i < end; i += 256) zero[i] = 0.f;
+        }
     } else {
         float* us = zsh[0];
         if (threadIdx.x < 6) us[threadIdx.x] = tv.u6 ? tv.u6[threadIdx.x] : draw_uniform(seed_u, DRAW_STREAM_LATTICE, (uint64_t)threadIdx.x);
@@ -1171,7 +1209,8 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 uint64_t seed_cur, const float* poses16, int K, const rfx_sampler_desc* sampler, const float* u01, uint64_t seed_u,
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
-                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, rfx_stream stream) {
+                float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
+                rfx_stream stream) {
     const int64_t n = n_kf_samples + n_cur;
     if (n == 0) return RFX_OK;
     if (!rays_o || !rays_d || !target_rgb || !target_d || !d_cam || !pose_idx || !z_vals || !x01 || !bbox) return RFX_ERR_ARG;
@@ -1204,8 +1243,12 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
     }
     const RayOut out = {rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01};
     const int nb_rays = ray_grid(n);
-    hipLaunchKernelGGL(ba_prologue_kernel, dim3(nb_rays + nb_stage + nb_tv), dim3(256), 0, as_stream(stream), g, k,
-                       make_box(bbox, bbox_f64), seed_u ? nullptr : u01, seed_u, out, nb_rays, fk, staged, nb_stage, tv);
+    if (zero_floats < 0 || (zero_floats > 0 && !zero)) return RFX_ERR_ARG;
+    const int64_t nb_zero = zero ? (zero_floats + PROLOGUE_ZERO - 1) / PROLOGUE_ZERO : 0;
+    if (nb_rays + nb_stage + nb_tv + nb_zero > 0x7fffffff) return RFX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ba_prologue_kernel, dim3((unsigned)(nb_rays + nb_stage + nb_tv + nb_zero)), dim3(256), 0, as_stream(stream), g, k,
+                       make_box(bbox, bbox_f64), seed_u ? nullptr : u01, seed_u, out, nb_rays, fk, staged, nb_stage, tv, nb_tv, zero,
+                       zero_floats);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1214,17 +1257,22 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
 // (*n_partials of them) for loss_backward_from_partials, which finishes them
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
                            int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, int* n_partials, rfx_stream stream) {
+                           float* rgb_map, float* depth_map, double* sums, int* n_partials, const float* tv_feat, int tv_P, int tv_C,
+                           float tv_scale, float* tv_dfeat, rfx_stream stream) {
     *n_partials = 0;
     if (n_rays == 0) return RFX_OK;
     if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums) return RFX_ERR_ARG;
     if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
+    if (tv_dfeat && (!tv_feat || tv_P <= 0 || tv_C <= 0)) return RFX_ERR_ARG;
     hipStream_t st = as_stream(stream);
     LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
     const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_BLOCKS);
-    hipLaunchKernelGGL(composite_loss_forward_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, st, L, reinterpret_cast<const float4*>(raw4),
-                       z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map, sums);
+    TvBackK tv = {tv_feat, tv_P, tv_C, tv_scale, tv_dfeat};
+    int nb_tv = 0;          // rfx_tv_backward's grid
+    if (tv_dfeat) nb_tv = (int)std::min<int64_t>(((int64_t)tv_P * tv_P * tv_P * tv_C + 255) / 256, 2048);
+    hipLaunchKernelGGL(composite_loss_tv_kernel, dim3(blocks + nb_tv), dim3(LOSS_THREADS), 0, st, L, reinterpret_cast<const float4*>(raw4),
+                       z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map, sums, blocks, tv);
     RFX_LAUNCH_CHECK();
     *n_partials = blocks;
     return RFX_OK;
