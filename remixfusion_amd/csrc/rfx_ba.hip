@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __res
 
 struct BaWs {
     float *o, *d, *tgt, *d_cam, *td, *z, *x01, *raw, *rgb_map, *depth_map, *lc, *pts, *feat, *d_raw, *dx, *go, *gd, *dfeat, *ones;
-    int* pidx;
+    int *pidx, *ray_cnt;
     double* sums;
     void *bwd_ws, *scat_ws;
     size_t bwd_bytes, scat_bytes, total;
@@ -53,7 +53,7 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     auto take = [&](size_t bytes) { char* r = b0 ? b0 + off : nullptr; off += al(bytes); return r; };
     const size_t nS = (size_t)n * S, nt = (size_t)P * P * P;
     w.o = (float*)take(n * 12); w.d = (float*)take(n * 12); w.tgt = (float*)take(n * 12); w.d_cam = (float*)take(n * 12);
-    w.td = (float*)take(n * 4); w.pidx = (int*)take(n * 4);
+    w.td = (float*)take(n * 4); w.pidx = (int*)take(n * 4); w.ray_cnt = (int*)take(n * 4);
     w.z = (float*)take(nS * 4); w.x01 = (float*)take(nS * 12); w.raw = (float*)take(nS * 16);
     w.rgb_map = (float*)take(n * 12); w.depth_map = (float*)take(n * 4);
     w.sums = (double*)take(RFX_LOSS_WS_DOUBLES * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
@@ -133,12 +133,11 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));      // (its features: the prologue's)
     // ---- backward
     RFX_TRY(loss_backward_from_partials(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
-                                        b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw,
-                                        stream));                                                                   // L1 finish + backward
+                                        b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw, w.ray_cnt,
+                                        stream));                          // L1 finish + backward (+ rows with a gradient, per ray)
     // the chain variant that produces exactly what the following stages read
-    if (map_grads && b->d_poses16) RFX_TRY(rfx_field_backward_chain_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    else if (map_grads) RFX_TRY(rfx_field_backward_chain_weights_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
-    else RFX_TRY(rfx_field_backward_chain_inputs_stashed(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes, stream));
+    RFX_TRY(field_backward_chain_stashed_counted(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes,
+                                                 map_grads && b->d_poses16 ? 0 : map_grads ? 2 : 1, w.ray_cnt, S, stream));
     float* dw1 = b->d_w; float* dw2 = dw1 ? dw1 + 32 * 81 : nullptr; float* dw3 = dw1 ? dw2 + 16 * 32 : nullptr;
     float* dw4 = dw1 ? dw3 + 32 * 66 : nullptr;
     if (map_grads && !b->d_poses16) {     // map phase: weight gradients and table scatter back to back (they share a launch)

@@ -47,6 +47,8 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
                                    float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
                                    rfx_stream stream);                                              // rfx_field.hip
+int field_backward_chain_stashed_counted(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
+                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, rfx_stream stream);   // rfx_field.hip
 int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
                            int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
                            float* rgb_map, float* depth_map, double* sums, int* n_partials, const float* tv_feat, int tv_P, int tv_C,
@@ -54,6 +56,7 @@ int composite_loss_forward(const float* raw4, const float* z_vals, const float* 
 int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
                                 const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
                                 float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
-                                const float* gout4, float* lc8, float* d_raw4, rfx_stream stream);
+                                const float* gout4, float* lc8, float* d_raw4, int32_t* ray_counts, rfx_stream stream);
+                                // ray_counts (optional): [n_rays] samples of each ray whose d_raw4 row is not all zero
 
 }  // namespace rfx

@@ -955,27 +955,32 @@ __global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict_
 }
 
 // stable partition: block b's non-zero points go to rows [sum of earlier blocks' counts, ...), its zero points to the rows
-// after all non-zero ones, both in point order (so the result does not depend on scheduling)
+// after all non-zero ones, both in point order (so the result does not depend on scheduling -- nor on how the points are
+// cut into blocks).  A block takes `ppb` consecutive points (768 < ppb <= SEL_PPB) = `upb` consecutive count units:
+// counts[] holds the non-zero points per unit, either sel_count_kernel's (unit = block, ppb = SEL_PPB) or the loss
+// backward's per ray (unit = ray of S points, upb rays per block: no counting launch).
 __global__ __launch_bounds__(256) void sel_scatter_kernel(const float* __restrict__ draw4, int64_t n, const int* __restrict__ counts,
-                                                          int n_blocks, int* __restrict__ perm, int* __restrict__ hdr) {
+                                                          int n_counts, int upb, int ppb, int* __restrict__ perm, int* __restrict__ hdr) {
     __shared__ int red[2][4];
     __shared__ int wave_cnt[SEL_PPB / 256][4];
     int before = 0, total = 0;
-    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+    const int first_unit = (int)blockIdx.x * upb;
+    for (int i = threadIdx.x; i < n_counts; i += 256) {
         const int c = counts[i];
         total += c;
-        if (i < (int)blockIdx.x) before += c;
+        if (i < first_unit) before += c;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { red[0][wv] = before; red[1][wv] = total; }
-    const int64_t p0 = (int64_t)blockIdx.x * SEL_PPB;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p_end = min(n, p0 + ppb);
     bool f[SEL_PPB / 256];
     unsigned long long m[SEL_PPB / 256];
 #pragma unroll
     for (int r = 0; r < SEL_PPB / 256; ++r) {
-        f[r] = sel_flag(draw4, p0 + r * 256 + threadIdx.x, n);
+        f[r] = sel_flag(draw4, p0 + r * 256 + threadIdx.x, p_end);
         m[r] = __ballot(f[r]);
         if (lane == 0) wave_cnt[r][wv] = __popcll(m[r]);
     }
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(256) void sel_scatter_kernel(const float* __restric
     total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = total;
     int nz_run = before;                                         // non-zero rows placed so far (this block's share included)
-    int64_t seen = p0;                                           // points placed so far
+    int64_t seen = p0;                                           // points placed so far (only the block's last lanes can lie past p_end)
 #pragma unroll
     for (int r = 0; r < SEL_PPB / 256; ++r) {
 #pragma unroll
@@ -992,7 +997,7 @@ __global__ __launch_bounds__(256) void sel_scatter_kernel(const float* __restric
             if (w == wv) {
                 const int64_t p = p0 + r * 256 + threadIdx.x;
                 const int rank = __popcll(m[r] & ((1ull << lane) - 1ull));
-                if (p < n) perm[f[r] ? nz_run + rank : total + (int)(seen - nz_run) + (lane - rank)] = (int)p;
+                if (p < p_end) perm[f[r] ? nz_run + rank : total + (int)(seen - nz_run) + (lane - rank)] = (int)p;
             }
             nz_run += wave_cnt[r][w];
             seen += 64;
@@ -1606,7 +1611,8 @@ int rfx_field_forward_stash(const rfx_field_desc* f, const float* x01, int64_t n
 }
 
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
-                                 size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull, bool stashed = false) {
+                                 size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull, bool stashed = false,
+                                 const int* ray_counts = nullptr, int ray_S = 0) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
@@ -1635,9 +1641,18 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
     const int variant = rows ? (dxfull ? 0 : 2) : 1;
     Sel sel{nullptr, nullptr};
     if (sel_on(n)) {            // points with a non-zero loss gradient first; the later stages read the same perm / count
-        const int nb = (int)((n + SEL_PPB - 1) / SEL_PPB);
-        hipLaunchKernelGGL(sel_count_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts);
-        hipLaunchKernelGGL(sel_scatter_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts, nb, ws.perm, ws.sel_hdr);
+        if (ray_counts && ray_S > 0 && ray_S < 256 && n % ray_S == 0) {
+            // the non-zero rows were counted per ray by the kernel that wrote draw4 (the loss backward): blocks of whole rays
+            const int upb = SEL_PPB / ray_S, ppb = upb * ray_S;
+            const int n_rays = (int)(n / ray_S);
+            hipLaunchKernelGGL(sel_scatter_kernel, dim3((n_rays + upb - 1) / upb), dim3(256), 0, as_stream(stream), draw4, n, ray_counts, n_rays,
+                               upb, ppb, ws.perm, ws.sel_hdr);
+        } else {
+            const int nb = (int)((n + SEL_PPB - 1) / SEL_PPB);
+            hipLaunchKernelGGL(sel_count_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts);
+            hipLaunchKernelGGL(sel_scatter_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts, nb, 1, SEL_PPB, ws.perm,
+                               ws.sel_hdr);
+        }
         RFX_LAUNCH_CHECK();
         sel = Sel{ws.perm, ws.sel_hdr};
     }
@@ -1833,6 +1848,14 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
     }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+// the three stashed chain stages for a caller that already knows how many rows of every ray have a gradient
+// (ray_counts[n / S], from the kernel that wrote draw4): variant 0 = _chain_stashed, 1 = _chain_inputs_stashed,
+// 2 = _chain_weights_stashed.  Same result: the selection is a stable partition, whoever counts.
+int field_backward_chain_stashed_counted(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
+                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, rfx_stream stream) {
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, variant != 1, variant != 2, true, ray_counts, S);
 }
 
 // rfx_field_backward_weights that OVERWRITES dw1..dw4 (no zero-fill needed before it); used by rfx_ba_forward_backward

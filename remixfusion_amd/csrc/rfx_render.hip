@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, con
                                                                     const float* __restrict__ g_rgb_map,
                                                                     const float* __restrict__ g_depth_map, float4* __restrict__ d_raw,
                                                                     const double* __restrict__ partial, int n_partials,
-                                                                    float* __restrict__ lc_out) {
+                                                                    float* __restrict__ lc_out, int* __restrict__ ray_counts) {
     const int lane = threadIdx.x & 63;
     __shared__ float lc[8];
     if (PARTIALS) {
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, con
             dot += rw.w[c] * gj[c];
         }
         dot = wave_sum(dot);
+        int nz = 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (!ok[c]) continue;
@@ -556,7 +557,13 @@ __global__ __launch_bounds__(256) void mapping_loss_backward_kernel(LossK L, con
                 ds += k_fs * 2.0f * (s[c] * front - front) * front;
                 ds += k_sdf * 2.0f * ((z[c] + s[c] * L.trunc_loss) * smk - d * smk) * (L.trunc_loss * smk);
             }
-            d_raw[ray * S + lane + 64 * c] = make_float4(rw.w[c] * g[0], rw.w[c] * g[1], rw.w[c] * g[2], ds);
+            const float4 o = make_float4(rw.w[c] * g[0], rw.w[c] * g[1], rw.w[c] * g[2], ds);
+            d_raw[ray * S + lane + 64 * c] = o;
+            nz += (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) ? 1 : 0;
+        }
+        if (ray_counts) {                      // rows of this ray with a gradient (the selection of the field backward counts them)
+            nz = (int)wave_sum((float)nz);
+            if (lane == 0) ray_counts[ray] = nz;
         }
     }
 }
@@ -853,6 +860,8 @@ __global__ __launch_bounds__(256) void ba_prologue_kernel(GatherK g, SamplerK s,
                                                           float* __restrict__ staged, int nb_stage, TvEncK tv, int nb_tv,
                                                           float* __restrict__ zero, int64_t zero_floats) {
     __shared__ float zsh[4][MAX_S];
+    // dispatch order = block index: the ray batch first (a chain of dependent latencies per ray: the launch's critical
+    // path; with the lattice's lookups ahead of it the launch took 25 us instead of 20)
     const int b = blockIdx.x;
     if (b < nb_rays) {
         ray_setup_body(g, s, box, u01, seed_u, out, b, nb_rays, zsh);
@@ -1091,7 +1100,7 @@ int rfx_mapping_loss_backward(const float* raw4, const float* z_vals, const floa
     hipLaunchKernelGGL(mapping_loss_backward_kernel<false>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
                        reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
                        sc_factor, coef4, gout4, g_rgb_map, g_depth_map, reinterpret_cast<float4*>(d_raw4), (const double*)nullptr, 0,
-                       (float*)nullptr);
+                       (float*)nullptr, (int*)nullptr);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -1282,7 +1291,7 @@ int composite_loss_forward(const float* raw4, const float* z_vals, const float* 
 int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
                                 const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
                                 float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
-                                const float* gout4, float* lc8, float* d_raw4, rfx_stream stream) {
+                                const float* gout4, float* lc8, float* d_raw4, int32_t* ray_counts, rfx_stream stream) {
     if (n_rays == 0) return RFX_OK;
     if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !gout4 || !lc8 || !d_raw4) return RFX_ERR_ARG;
     if (n_rays < 0 || S <= 0 || !(trunc > 0.f) || n_partials <= 0) return RFX_ERR_ARG;
@@ -1291,7 +1300,7 @@ int loss_backward_from_partials(const float* raw4, const float* z_vals, const fl
     hipLaunchKernelGGL(mapping_loss_backward_kernel<true>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
                        reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
                        sc_factor, (const float*)nullptr, gout4, (const float*)nullptr, (const float*)nullptr,
-                       reinterpret_cast<float4*>(d_raw4), sums, n_partials, lc8);
+                       reinterpret_cast<float4*>(d_raw4), sums, n_partials, lc8, ray_counts);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
