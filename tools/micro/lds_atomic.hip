@@ -40,6 +40,35 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, unsigned keep_m
     for (int i = threadIdx.x; i < 32768; i += 1024) s += acc[i];
     if (s == -1.f) out[0] = s;
 }
+// eight LDS operations per loop trip (the single-operation loops above bottom out at ~8.7 clk of loop overhead per operation):
+// OP 0 = ds_add_f64, 1 = ds_write_b64, 2 = ds_write_b128, 3 = ds_add_u64, each to a random address, `keep_mask` thins the lanes
+template <int OP>
+__global__ __launch_bounds__(1024) void k8(float* out, int iters, unsigned keep_mask) {
+    extern __shared__ unsigned char raw8[];
+    double* acc = reinterpret_cast<double*>(raw8);
+    for (int i = threadIdx.x; i < 16384; i += 1024) acc[i] = 0;
+    __syncthreads();
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < iters; ++i) {
+        h = h * 1664525u + 1013904223u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned hh = h ^ (0x9e3779b9u * (u + 1));
+            const unsigned a = (hh >> 15) & 16383u;
+            if (((hh >> 7) & keep_mask) == 0) {
+                if (OP == 0) atomicAdd(&acc[a], (double)(hh & 255));
+                else if (OP == 1) acc[a] = (double)(hh & 255);
+                else if (OP == 2) *reinterpret_cast<double2*>(&acc[a & ~1u]) = make_double2((double)(hh & 255), 1.0);
+                else atomicAdd(reinterpret_cast<unsigned long long*>(&acc[a]), (unsigned long long)(hh & 255));
+            }
+        }
+    }
+    __syncthreads();
+    double s = 0;
+    for (int i = threadIdx.x; i < 16384; i += 1024) s += acc[i];
+    if (s == 12345.0) out[0] = 1.f;
+}
+
 int main() {
     float* out; hipMalloc(&out, 4);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -68,6 +97,21 @@ int main() {
                    ms * 1e-3 * 2.1e9 / (16.0 * iters), 1024.0 * iters / (km + 1) / (ms * 1e-3 * 2.1e9));
         }
     };
+    auto bench8 = [&](auto kern, const char* name) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        for (unsigned km : {0u, 1u, 3u, 7u, 15u}) {
+            kern<<<blocks, 1024, 131072>>>(out, iters / 8, km);
+            hipEventRecord(e0);
+            kern<<<blocks, 1024, 131072>>>(out, iters / 8, km);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("x8 %s active 1/%u: %.3f ms -> %.1f clk per wave-instruction per CU\n", name, km + 1, ms, ms * 1e-3 * 2.1e9 / (16.0 * iters));
+        }
+    };
+    bench8(k8<0>, "ds_add_f64");
+    bench8(k8<3>, "ds_add_u64");
+    bench8(k8<1>, "ds_write_b64");
+    bench8(k8<2>, "ds_write_b128");
     bench_int(ki<float>, "f32 (typed kernel)");
     bench_int(ki<unsigned>, "u32");
     bench_int(ki<unsigned long long>, "u64");
