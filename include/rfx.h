@@ -505,6 +505,14 @@ typedef struct rfx_ba_desc {
     float*        losses8;              /* out dev [8] or NULL: the four losses, then their coefficients     */
     double*       tv_sum;               /* out dev [1] or NULL: un-normalised TV sum (only its gradient enters the
                                          * update, so the value is evaluated just when asked for)            */
+    /* optional (ABI 5), with d_poses16: carry on into the pose MLP's backward -- rfx_rba_backward(rba, rba_acts, K,
+     * d_poses16, rba_scale, rba_grads, rba_ws) -- inside the call: the ray-gradient reduction, rfx_pose_grad and the MLP
+     * backward then share one launch (same results to rounding: the sums are grouped differently).  All NULL: not done. */
+    const struct rfx_rba_params* rba;
+    const float*  rba_acts;             /* dev: what rfx_rba_forward left for these K cameras                */
+    float         rba_scale;
+    const struct rfx_rba_grads* rba_grads;
+    float*        rba_ws;               /* dev, rfx_rba_grads_floats(K)                                      */
 } rfx_ba_desc;
 size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign binding verify its mirror of the struct */
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);

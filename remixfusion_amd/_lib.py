@@ -55,7 +55,8 @@ class BaDesc(C.Structure):
                 ("cur_population", C.c_int64), ("n_kf_samples", C.c_int64), ("n_cur", C.c_int64), ("seed_kf", C.c_uint64),
                 ("seed_cur", C.c_uint64), ("poses16", C.c_void_p), ("K", C.c_int32), ("u_z", C.c_void_p), ("u6", C.c_void_p),
                 ("seed_u", C.c_uint64), ("hash_entries", C.c_int64), ("d_hash", C.c_void_p), ("d_w", C.c_void_p), ("d_poses16", C.c_void_p),
-                ("losses8", C.c_void_p), ("tv_sum", C.c_void_p)]
+                ("losses8", C.c_void_p), ("tv_sum", C.c_void_p), ("rba", C.c_void_p), ("rba_acts", C.c_void_p),
+                ("rba_scale", C.c_float), ("rba_grads", C.c_void_p), ("rba_ws", C.c_void_p)]
 
 
 class RbaParams(C.Structure):

@@ -148,10 +148,19 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     if (b->d_poses16) {
         RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));
         RFX_TRY(rfx_field_backward_dx(&b->field, w.x01, nS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
-        const float ex = (float)(b->bbox[1] - b->bbox[0]), ey = (float)(b->bbox[3] - b->bbox[2]), ez = (float)(b->bbox[5] - b->bbox[4]);
-        hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.dx, w.z, n, S, ex, ey, ez, w.go, w.gd);
-        RFX_LAUNCH_CHECK();
-        RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
+        int chained = 0;      // d rays -> d poses -> pose-MLP backward in one launch, when the caller hands the MLP over
+        if (b->rba) {
+            if (!b->rba_acts || !b->rba_grads || !b->rba_ws) return RFX_ERR_ARG;
+            RFX_TRY(pose_chain_backward(w.dx, w.z, w.d_cam, w.pidx, n, S, b->bbox, b->K, b->d_poses16, b->rba, b->rba_acts, b->rba_scale,
+                                        b->rba_grads, b->rba_ws, stream, &chained));
+        }
+        if (!chained) {
+            const float ex = (float)(b->bbox[1] - b->bbox[0]), ey = (float)(b->bbox[3] - b->bbox[2]), ez = (float)(b->bbox[5] - b->bbox[4]);
+            hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.dx, w.z, n, S, ex, ey, ez, w.go, w.gd);
+            RFX_LAUNCH_CHECK();
+            RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
+            if (b->rba) RFX_TRY(rfx_rba_backward(b->rba, b->rba_acts, b->K, b->d_poses16, b->rba_scale, b->rba_grads, b->rba_ws, stream));
+        }
     }
     if (map_grads) {
         RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,

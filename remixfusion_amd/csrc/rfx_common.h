@@ -43,6 +43,9 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 rfx_stream stream);
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip
+int pose_chain_backward(const float* dx01, const float* z_vals, const float* d_cam, const int32_t* pose_idx, int64_t n, int S,
+                        const double bbox[6], int K, float* dposes16, const rfx_rba_params* prm, const float* acts, float scale,
+                        const rfx_rba_grads* gr, float* workspace, rfx_stream stream, int* done);      // rfx_pose.hip
 int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
                                    float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,

@@ -279,6 +279,158 @@ __global__ __launch_bounds__(256) void rba_wgrad_kernel(const float* __restrict_
     out[e] = acc;
 }
 
+// ---- the tail of a pose iteration in ONE launch: d rays -> d poses -> pose-MLP backward ------------------------------------
+// What ray_grad_reduce_kernel (rfx_ba.hip), pose_grad_kernel (rfx_render.hip) and rba_backward_kernel above do one after the
+// other: all three are block = camera (or trivially regrouped that way), each is a few microseconds of latency, and a
+// dependent kernel boundary costs ~4.7 us here.  Block = camera k, 1 024 threads:
+//   1. the rays riding on pose k, in ray order (ballot + prefix over the block, 1 024 rays per round);
+//   2. sixteen lanes per ray: d rays_o = sum_s dx / extent, d rays_d = sum_s z dx / extent (scene_rep.py:388,443), folded straight into
+//      dposes[k] (rotation rows += g_d (x) d_cam, translation += g_o); the groups' sums combined in a fixed order: deterministic;
+//   3. the MLP backward with four threads per hidden unit (each a quarter of the 256-term column dot products).
+// Sums are grouped differently from the three separate kernels: equal to rounding, not bit-identical.
+constexpr int PCB_THREADS = 1024, PCB_MAX_RAYS = 8192;
+struct PoseChainK {
+    const float *dx, *z, *d_cam; const int* pose_idx; int64_t n; int S; float ex, ey, ez;
+};
+
+__global__ __launch_bounds__(PCB_THREADS) void pose_chain_backward_kernel(PoseChainK p, RbaW W, const float* __restrict__ acts,
+                                                                         float scale, float eps, float* __restrict__ grads,
+                                                                         float* __restrict__ dposes) {
+    __shared__ int list[PCB_MAX_RAYS];
+    __shared__ int wcnt[PCB_THREADS / 64];
+    __shared__ float accs[PCB_THREADS / 16][12];
+    __shared__ float sa[RBA_H], sb[RBA_H], part[4][RBA_H], sd[8], D[12];
+    const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // 1. this camera's rays
+    int total = 0;
+    for (int64_t r0 = 0; r0 < p.n; r0 += PCB_THREADS) {
+        const int64_t i = r0 + t;
+        const bool hit = i < p.n && p.pose_idx[i] == k;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, round_total = 0;
+#pragma unroll
+        for (int w = 0; w < PCB_THREADS / 64; ++w) { const int c = wcnt[w]; round_total += c; if (w < wv) before += c; }
+        if (hit) list[total + before + __popcll(bal & ((1ull << lane) - 1ull))] = (int)i;
+        total += round_total;
+        __syncthreads();
+    }
+    // 2. ray gradients -> dposes[k]: sixteen lanes per ray (four rays per wave, 64 per block in flight: a ray is a chain of
+    //    dependent latencies, and a camera has only a few hundred of them)
+    float a[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) a[q] = 0.f;
+    const int grp = t >> 4, sub = t & 15;
+    for (int e = grp; e < total; e += PCB_THREADS / 16) {
+        const int64_t ray = list[e];
+        float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = sub; j < p.S; j += 16) {
+            const float* g = p.dx + (ray * p.S + j) * 3;
+            const float zz = p.z[ray * p.S + j];
+            const float px = g[0] / p.ex, py = g[1] / p.ey, pz = g[2] / p.ez;
+            s6[0] += px; s6[1] += py; s6[2] += pz;
+            s6[3] += px * zz; s6[4] += py * zz; s6[5] += pz * zz;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s6[q] += __shfl_xor(s6[q], o);
+        }
+        const float dc[3] = {p.d_cam[ray * 3], p.d_cam[ray * 3 + 1], p.d_cam[ray * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a[4 * r] += s6[3 + r] * dc[0]; a[4 * r + 1] += s6[3 + r] * dc[1]; a[4 * r + 2] += s6[3 + r] * dc[2];
+            a[4 * r + 3] += s6[r];
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) accs[grp][q] = a[q];
+    }
+    __syncthreads();
+    if (t < 16) {
+        float v = 0.f;
+        if (t < 12) {
+            for (int w = 0; w < PCB_THREADS / 16; ++w) v += accs[w][t];
+            D[t] = v;
+        }
+        dposes[(size_t)k * 16 + t] = v;
+    }
+    __syncthreads();
+    // 3. pose-MLP backward (rba_backward_kernel's arithmetic)
+    const float* __restrict__ row = acts + (size_t)k * RBA_ACT_LD;
+    float* __restrict__ g = grads + (size_t)k * RBA_GRAD_LD;
+    const int j = t & (RBA_H - 1), q4 = t >> 8;
+    if (t == 0) {
+        const float* tail = row + 8 + 3 * RBA_H;
+        const float aa[3] = {tail[0], tail[1], tail[2]};
+        const float G[9] = {D[0], D[1], D[2], D[4], D[5], D[6], D[8], D[9], D[10]};
+        float daa[3];
+        rodrigues_backward(aa, eps, G, daa);
+        const float f = scale * tail[3];
+        sd[0] = daa[0] * f; sd[1] = daa[1] * f; sd[2] = daa[2] * f;
+        sd[3] = D[3] * f; sd[4] = D[7] * f; sd[5] = D[11] * f;
+        for (int o = 0; o < RBA_OUT; ++o) g[3 * RBA_H + o] = sd[o];
+    }
+    __syncthreads();
+    if (q4 == 0) {
+        float v = 0.f;
+        for (int o = 0; o < RBA_OUT; ++o) v = fmaf(W.w3[o * RBA_H + j], sd[o], v);
+        v *= elu_grad_from_out(row[8 + 2 * RBA_H + j]);
+        sa[j] = v; g[2 * RBA_H + j] = v;                 // dP3
+    }
+    __syncthreads();
+    {
+        float v = 0.f;
+#pragma unroll 8
+        for (int i = q4 * (RBA_H / 4); i < (q4 + 1) * (RBA_H / 4); ++i) v = fmaf(W.w2[(size_t)i * RBA_H + j], sa[i], v);
+        part[q4][j] = v;
+    }
+    __syncthreads();
+    if (q4 == 0) {
+        float v = ((part[0][j] + part[1][j]) + part[2][j]) + part[3][j];
+        v *= elu_grad_from_out(row[8 + RBA_H + j]);
+        sb[j] = v; g[RBA_H + j] = v;                     // dP2
+    }
+    __syncthreads();
+    {
+        float v = 0.f;
+#pragma unroll 8
+        for (int i = q4 * (RBA_H / 4); i < (q4 + 1) * (RBA_H / 4); ++i) v = fmaf(W.w1[(size_t)i * RBA_H + j], sb[i], v);
+        part[q4][j] = v;
+    }
+    __syncthreads();
+    if (q4 == 0) {
+        float v = ((part[0][j] + part[1][j]) + part[2][j]) + part[3][j];
+        v *= elu_grad_from_out(row[8 + j]);
+        g[j] = v;                                        // dP1
+    }
+}
+
+// rfx_pose_grad (fed the ray gradients of dx01) + rfx_rba_backward in two launches instead of four; false: not applicable
+// (too many rays for the block's list), the caller issues the separate stages
+int pose_chain_backward(const float* dx01, const float* z_vals, const float* d_cam, const int32_t* pose_idx, int64_t n, int S,
+                        const double bbox[6], int K, float* dposes16, const rfx_rba_params* prm, const float* acts, float scale,
+                        const rfx_rba_grads* gr, float* workspace, rfx_stream stream, int* done) {
+    *done = 0;
+    if (n <= 0 || n > PCB_MAX_RAYS || S <= 0 || K <= 0) return RFX_OK;
+    if (!prm || prm->hidden != RBA_H || !prm->w0 || !prm->b0 || !prm->w1 || !prm->b1 || !prm->w2 || !prm->b2 || !prm->w3 || !prm->b3)
+        return RFX_ERR_ARG;
+    if (!dx01 || !z_vals || !d_cam || !pose_idx || !bbox || !dposes16 || !acts || !gr || !workspace) return RFX_ERR_ARG;
+    PoseChainK pk{dx01, z_vals, d_cam, pose_idx, n, S, (float)(bbox[1] - bbox[0]), (float)(bbox[3] - bbox[2]), (float)(bbox[5] - bbox[4])};
+    RbaW W{prm->w0, prm->b0, prm->w1, prm->b1, prm->w2, prm->b2, prm->w3, prm->b3};
+    hipLaunchKernelGGL(pose_chain_backward_kernel, dim3((unsigned)K), dim3(PCB_THREADS), 0, as_stream(stream), pk, W, acts, scale, 1e-6f,
+                       workspace, dposes16);
+    RFX_LAUNCH_CHECK();
+    RbaG G{gr->w0, gr->b0, gr->w1, gr->b1, gr->w2, gr->b2, gr->w3, gr->b3};
+    const int total = RBA_H * RBA_IN + RBA_H + 2 * (RBA_H * RBA_H + RBA_H) + RBA_OUT * RBA_H + RBA_OUT;
+    hipLaunchKernelGGL(rba_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), acts, workspace, K, G);
+    RFX_LAUNCH_CHECK();
+    *done = 1;
+    return RFX_OK;
+}
+
 }  // namespace rfx
 
 using namespace rfx;

@@ -208,8 +208,9 @@ class DirectIterations:
         self._perturb = tr["perturb"] > 0.0
         return d
 
-    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True):
-        """fill in what changes per iteration and launch it (forward + backward)."""
+    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True, rba=None):
+        """fill in what changes per iteration and launch it (forward + backward).  rba = (params, acts, scale, grads, workspace):
+        the call carries on into the pose MLP's backward (rfx_ba_desc.rba)."""
         t, p = B.t, B.p
         n = B.n
         d = self._descriptor(B, clamp, t.u.device)
@@ -230,6 +231,10 @@ class DirectIterations:
             d.u_z = d.u6 = None
             d.seed_u = self.last_seed_u = random.getrandbits(64) | 1
         d.d_poses16 = d_poses_ptr
+        if rba is not None:
+            d.rba, d.rba_acts, d.rba_scale, d.rba_grads, d.rba_ws = C.addressof(rba[0]), rba[1], rba[2], C.addressof(rba[3]), rba[4]
+        else:
+            d.rba = d.rba_acts = d.rba_grads = d.rba_ws = None
         if map_grads:
             d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, (p.tv_acc if self.report_tv else None)
         else:                           # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
@@ -408,12 +413,12 @@ class DirectIterations:
         if self._stagewise_now():
             B, go, gd = self._run_stagewise(current_rays, p.poses, K, True, True, dev, st, map_grads)
             check(lib.rfx_pose_grad(go.data_ptr(), gd.data_ptr(), B.p.d_cam, B.p.pidx, B.t.o.shape[0], K, p.dposes, st), "rfx_pose_grad")
-        else:
+            check(lib.rfx_rba_backward(C.byref(prm), p.acts, K, p.dposes, float(rba.scale), C.byref(gdesc), p.wsr, st), "rfx_rba_backward")
+        else:                                        # ... and on into the pose MLP's backward, inside the same call
             B = R
-            self._run(B, current_rays, p.poses, K, True, p.dposes, st, map_grads)
+            self._run(B, current_rays, p.poses, K, True, p.dposes, st, map_grads, rba=(prm, p.acts, float(rba.scale), gdesc, p.wsr))
         if map_grads:
             self._set_map_grads(B)                   # produced by the reference's backward too; no optimizer consumes them
-        check(lib.rfx_rba_backward(C.byref(prm), p.acts, K, p.dposes, float(rba.scale), C.byref(gdesc), p.wsr, st), "rfx_rba_backward")
         for w, g in zip(params, grads):
             w.grad = g
         return B.t.lc
