@@ -99,10 +99,13 @@ def _worker_collectives(rank, world, port, out_dir):
     b = torch.arange(6, dtype=torch.float32).view(2, 3).t()          # non-contiguous view
     b = b * (rank + 1)
     d = torch.full((8,), 0.5 * (rank + 1), dtype=torch.float64)
-    all_reduce_sum_(dist, [a, None, b, d])
+    big = torch.arange(70000, dtype=torch.float32) * (rank + 1)       # above the bucket limit: reduced where it lies
+    big_ptr = big.data_ptr()
+    all_reduce_sum_(dist, [a, None, big, b, d])
+    assert big.data_ptr() == big_ptr
     f = torch.full((4,), float(rank * 10 + 3))
     broadcast_(dist, f, 0)
-    torch.save({"a": a, "b": b, "d": d, "f": f}, os.path.join(out_dir, f"c{rank}.pt"))
+    torch.save({"a": a, "b": b, "d": d, "f": f, "big": big}, os.path.join(out_dir, f"c{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,3 +119,4 @@ def test_collective_helpers_world2(tmp_path):
         assert torch.equal(c["b"], torch.arange(6, dtype=torch.float32).view(2, 3).t() * 3)
         assert torch.equal(c["d"], torch.full((8,), 1.5, dtype=torch.float64))
         assert torch.equal(c["f"], torch.full((4,), 3.0))
+        assert torch.equal(c["big"], torch.arange(70000, dtype=torch.float32) * 3)
