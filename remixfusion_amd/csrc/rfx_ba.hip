@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __res
 struct BaWs {
     float *o, *d, *tgt, *d_cam, *td, *z, *x01, *raw, *rgb_map, *depth_map, *lc, *pts, *feat, *d_raw, *dx, *go, *gd, *dfeat, *ones;
     int *pidx, *ray_cnt;
-    double* sums;
+    double *sums, *cnt, *lsum;
     void *bwd_ws, *scat_ws;
     size_t bwd_bytes, scat_bytes, total;
 };
@@ -56,7 +56,7 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     w.td = (float*)take(n * 4); w.pidx = (int*)take(n * 4); w.ray_cnt = (int*)take(n * 4);
     w.z = (float*)take(nS * 4); w.x01 = (float*)take(nS * 12); w.raw = (float*)take(nS * 16);
     w.rgb_map = (float*)take(n * 12); w.depth_map = (float*)take(n * 4);
-    w.sums = (double*)take(RFX_LOSS_WS_DOUBLES * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
+    w.sums = (double*)take(RFX_LOSS_WS_DOUBLES * 8); w.cnt = (double*)take(2048 * 4 * 8); w.lsum = (double*)take(1024 * 8 * 8); w.lc = (float*)take(8 * 4); w.ones = (float*)take(4);
     w.pts = (float*)take(nt * 12); w.feat = (float*)take(nt * n_feat * 4); w.dfeat = (float*)take(nt * n_feat * 4);
     w.d_raw = (float*)take(nS * 16); w.dx = (float*)take(nS * 12); w.go = (float*)take(n * 12); w.gd = (float*)take(n * 12);
     w.bwd_bytes = rfx_field_backward_workspace_bytes((int64_t)nS);
@@ -115,29 +115,33 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     //      update the weights in place between calls) the TV lattice with its table lookups and the zero-fill of the hash gradient, which depend on nothing computed here
     const bool tv_on = map_grads || b->tv_sum;
     if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
+    const float trunc_loss = b->trunc * b->sc_factor;
+    int n_cnt = 0;
     RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                         b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
                         b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, P, b->tv_voxel,
                         b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
-                        map_grads ? b->d_hash : nullptr, map_grads ? (int64_t)b->hash_entries * F : 0, stream));
+                        map_grads ? b->d_hash : nullptr, map_grads ? (int64_t)b->hash_entries * F : 0, trunc_loss, b->depth_trunc,
+                        w.cnt, &n_cnt, stream));            // ... and counts what the loss coefficients are made of
     // ---- forward
     // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
     RFX_TRY(rfx_field_forward_stash(&b->field, w.x01, nS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
-    const float trunc_loss = b->trunc * b->sc_factor;
-    float* lc = b->losses8 ? b->losses8 : w.lc;       // the four losses, then their coefficients (read by the backward)
+    float* lc = b->losses8 ? b->losses8 : w.lc;       // out: the four losses, then their coefficients
+    // ---- R1 + L1 forward and L1 backward in one launch (the coefficients come from the prologue's counts), TV1 backward beside
+    //      them; leaves the loss partial sums, the rows with a gradient per ray and d_raw
     int n_partials = 0;
-    RFX_TRY(composite_loss_forward(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc,
-                                   b->rgb_missing_on, w.rgb_map, w.depth_map, w.sums, &n_partials, map_grads ? w.feat : nullptr, P,
-                                   L * F, b->tv_scale, map_grads ? w.dfeat : nullptr, stream));   // R1 + L1 sums | TV1 backward
+    RFX_TRY(composite_loss_grad(w.raw, w.z, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss, b->depth_trunc, b->rgb_missing_on,
+                                w.rgb_map, w.depth_map, w.lsum, &n_partials, w.cnt, n_cnt, b->loss_w_dev, w.d_raw, w.ray_cnt,
+                                map_grads ? w.feat : nullptr, P, L * F, b->tv_scale, map_grads ? w.dfeat : nullptr, stream));
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));      // (its features: the prologue's)
-    // ---- backward
-    RFX_TRY(loss_backward_from_partials(w.raw, w.z, w.rgb_map, w.depth_map, w.tgt, w.td, n, S, b->trunc, b->sc_factor, trunc_loss,
-                                        b->depth_trunc, b->rgb_missing_on, w.sums, n_partials, b->loss_w_dev, lc, w.d_raw, w.ray_cnt,
-                                        stream));                          // L1 finish + backward (+ rows with a gradient, per ray)
-    // the chain variant that produces exactly what the following stages read
+    // ---- backward: the chain variant that produces exactly what the following stages read; its selection launch also
+    //      finishes the losses
+    int finalized = 0;
     RFX_TRY(field_backward_chain_stashed_counted(&b->field, w.x01, nS, w.d_raw, w.bwd_ws, w.bwd_bytes,
-                                                 map_grads && b->d_poses16 ? 0 : map_grads ? 2 : 1, w.ray_cnt, S, stream));
+                                                 map_grads && b->d_poses16 ? 0 : map_grads ? 2 : 1, w.ray_cnt, S, w.lsum, n_partials, lc,
+                                                 &finalized, stream));
+    if (!finalized) RFX_TRY(loss_finalize_launch(w.lsum, n_partials, n, S, lc, stream));
     float* dw1 = b->d_w; float* dw2 = dw1 ? dw1 + 32 * 81 : nullptr; float* dw3 = dw1 ? dw2 + 16 * 32 : nullptr;
     float* dw4 = dw1 ? dw3 + 32 * 66 : nullptr;
     if (map_grads && !b->d_poses16) {     // map phase: weight gradients and table scatter back to back (they share a launch)

@@ -33,6 +33,37 @@ __device__ __forceinline__ float madd(float a, float b, float c) { return fmaf(a
 // CUDA __float2int_rn: round-half-even.
 __device__ __forceinline__ int f2i_rn(float v) { return (int)rintf(v); }
 
+// lc[0..3] = losses (rgb, depth, sdf, fs), lc[4..7] = coef: d loss_i / d (its squared-error sum), from the per-block
+// partial sums; for a 256-thread block, lc in LDS, valid for all threads on return.
+__device__ __forceinline__ void loss_finalize(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S, float* lc) {
+    __shared__ double part[32][8], sums[8];
+    {   // thread = (value v, slice q): partials q, q + 32, ... in order, then the 32 slices in order
+        const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
+        double a = 0.0;
+        for (int k = q; k < n_partials; k += 32) a += partial[k * 8 + v];
+        part[q][v] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double a = 0.0;
+        for (int q = 0; q < 32; ++q) a += part[q][threadIdx.x];
+        sums[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ns = (double)n_rays * (double)S;
+        const double tot = sums[5] + sums[6];
+        const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
+        const float c_rgb = (float)(1.0 / (3.0 * (double)n_rays)), c_dep = (float)(1.0 / sums[2]);
+        const float c_sdf = (float)(1.0 / ns) * sdf_w, c_fs = (float)(1.0 / ns) * fs_w;
+        lc[0] = (float)sums[0] * c_rgb; lc[1] = (float)sums[1] * c_dep;
+        lc[2] = (float)sums[4] * c_sdf; lc[3] = (float)sums[3] * c_fs;
+        lc[4] = c_rgb; lc[5] = c_dep; lc[6] = c_sdf; lc[7] = c_fs;
+    }
+    __syncthreads();
+}
+
+
 // fused forms of public entry points, used by rfx_ba_forward_backward (defined in rfx_render.hip)
 int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const int64_t* kf_frame_ids, int keyframe_every,
                 const float* cur_rays, int64_t cur_population, int64_t n_kf_samples, int64_t n_cur, uint64_t seed_kf,
@@ -40,7 +71,13 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
-                rfx_stream stream);
+                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream);
+int composite_loss_grad(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays, int S,
+                        float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, float* rgb_map,
+                        float* depth_map, double* sums, int* n_partials, const double* count_partials, int n_count_partials,
+                        const float* gout4, float* d_raw4, int32_t* ray_counts, const float* tv_feat, int tv_P, int tv_C, float tv_scale,
+                        float* tv_dfeat, rfx_stream stream);
+int loss_finalize_launch(const double* sums, int n_partials, int64_t n_rays, int S, float* lc8, rfx_stream stream);
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip
 int pose_chain_backward(const float* dx01, const float* z_vals, const float* d_cam, const int32_t* pose_idx, int64_t n, int S,
@@ -51,15 +88,7 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
                                    rfx_stream stream);                                              // rfx_field.hip
 int field_backward_chain_stashed_counted(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
-                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, rfx_stream stream);   // rfx_field.hip
-int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
-                           int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, int* n_partials, const float* tv_feat, int tv_P, int tv_C,
-                           float tv_scale, float* tv_dfeat, rfx_stream stream);     // + rfx_tv_backward beside it (tv_dfeat given)
-int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
-                                const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
-                                float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
-                                const float* gout4, float* lc8, float* d_raw4, int32_t* ray_counts, rfx_stream stream);
-                                // ray_counts (optional): [n_rays] samples of each ray whose d_raw4 row is not all zero
+                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, const double* loss_partials,
+                                         int n_loss_partials, float* lc8, int* finalized, rfx_stream stream);   // rfx_field.hip
 
 }  // namespace rfx

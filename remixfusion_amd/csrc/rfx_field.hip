@@ -959,8 +959,20 @@ __global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict_
 // cut into blocks).  A block takes `ppb` consecutive points (768 < ppb <= SEL_PPB) = `upb` consecutive count units:
 // counts[] holds the non-zero points per unit, either sel_count_kernel's (unit = block, ppb = SEL_PPB) or the loss
 // backward's per ray (unit = ray of S points, upb rays per block: no counting launch).
+// fin (optional): one more block, which has nothing to do with the selection: it adds up a ray batch's loss partial sums and
+// writes the four losses and their coefficients (loss_finalize, rfx_common.h) -- a one-block job that would otherwise be a
+// launch of its own between the loss kernel and this one.
+struct LossFinJob { const double* partial; int n_partials; int64_t n_rays; int S; float* lc8; };
+
 __global__ __launch_bounds__(256) void sel_scatter_kernel(const float* __restrict__ draw4, int64_t n, const int* __restrict__ counts,
-                                                          int n_counts, int upb, int ppb, int* __restrict__ perm, int* __restrict__ hdr) {
+                                                          int n_counts, int upb, int ppb, int* __restrict__ perm, int* __restrict__ hdr,
+                                                          int nb_sel, LossFinJob fin) {
+    if ((int)blockIdx.x >= nb_sel) {
+        __shared__ float lc[8];
+        loss_finalize(fin.partial, fin.n_partials, fin.n_rays, fin.S, lc);
+        if (threadIdx.x < 8) fin.lc8[threadIdx.x] = lc[threadIdx.x];
+        return;
+    }
     __shared__ int red[2][4];
     __shared__ int wave_cnt[SEL_PPB / 256][4];
     int before = 0, total = 0;
@@ -1612,7 +1624,8 @@ int rfx_field_forward_stash(const rfx_field_desc* f, const float* x01, int64_t n
 
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
                                  size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull, bool stashed = false,
-                                 const int* ray_counts = nullptr, int ray_S = 0) {
+                                 const int* ray_counts = nullptr, int ray_S = 0, const LossFinJob* fin = nullptr, int* finalized = nullptr) {
+    if (finalized) *finalized = 0;
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
@@ -1645,13 +1658,15 @@ static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int6
             // the non-zero rows were counted per ray by the kernel that wrote draw4 (the loss backward): blocks of whole rays
             const int upb = SEL_PPB / ray_S, ppb = upb * ray_S;
             const int n_rays = (int)(n / ray_S);
-            hipLaunchKernelGGL(sel_scatter_kernel, dim3((n_rays + upb - 1) / upb), dim3(256), 0, as_stream(stream), draw4, n, ray_counts, n_rays,
-                               upb, ppb, ws.perm, ws.sel_hdr);
+            const int nb_sel = (n_rays + upb - 1) / upb;
+            hipLaunchKernelGGL(sel_scatter_kernel, dim3(nb_sel + (fin ? 1 : 0)), dim3(256), 0, as_stream(stream), draw4, n, ray_counts, n_rays,
+                               upb, ppb, ws.perm, ws.sel_hdr, nb_sel, fin ? *fin : LossFinJob{});
+            if (fin && finalized) *finalized = 1;
         } else {
             const int nb = (int)((n + SEL_PPB - 1) / SEL_PPB);
             hipLaunchKernelGGL(sel_count_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts);
             hipLaunchKernelGGL(sel_scatter_kernel, dim3(nb), dim3(256), 0, as_stream(stream), draw4, n, ws.sel_counts, nb, 1, SEL_PPB, ws.perm,
-                               ws.sel_hdr);
+                               ws.sel_hdr, nb, LossFinJob{});
         }
         RFX_LAUNCH_CHECK();
         sel = Sel{ws.perm, ws.sel_hdr};
@@ -1853,9 +1868,14 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
 // the three stashed chain stages for a caller that already knows how many rows of every ray have a gradient
 // (ray_counts[n / S], from the kernel that wrote draw4): variant 0 = _chain_stashed, 1 = _chain_inputs_stashed,
 // 2 = _chain_weights_stashed.  Same result: the selection is a stable partition, whoever counts.
+// loss_partials (optional): a ray batch's loss partial sums still waiting for their finalize (composite_loss_grad): taken along by
+// the selection's launch when there is one (*finalized = 1), else left to the caller.
 int field_backward_chain_stashed_counted(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
-                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, rfx_stream stream) {
-    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, variant != 1, variant != 2, true, ray_counts, S);
+                                         size_t workspace_bytes, int variant, const int* ray_counts, int S, const double* loss_partials,
+                                         int n_loss_partials, float* lc8, int* finalized, rfx_stream stream) {
+    LossFinJob fin{loss_partials, n_loss_partials, S > 0 ? n / S : 0, S, lc8};
+    return launch_backward_chain(f, x01, n, draw4, workspace, workspace_bytes, stream, variant != 1, variant != 2, true, ray_counts, S,
+                                 loss_partials && lc8 && n_loss_partials > 0 ? &fin : nullptr, finalized);
 }
 
 // rfx_field_backward_weights that OVERWRITES dw1..dw4 (no zero-fill needed before it); used by rfx_ba_forward_backward

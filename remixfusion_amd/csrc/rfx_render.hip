@@ -382,103 +382,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_forward_kernel(Loss
     }
 }
 
-// composite_forward_kernel + mapping_loss_forward_kernel in one launch (same ray-to-wave dealing and the same
-// expressions as the loss kernel, fed from registers instead of the maps just written: bit-identical partial sums)
-// block / n_blocks: the block's place among the blocks that run this body
-__device__ __forceinline__ void composite_loss_forward_body(const LossK& L, const float4* __restrict__ raw,
-                                                            const float* __restrict__ zv, const float* __restrict__ tgt_rgb,
-                                                            const float* __restrict__ tgt_d, int64_t n_rays, int S, float trunc,
-                                                            float sc, float* __restrict__ rgb_map, float* __restrict__ depth_map,
-                                                            double* __restrict__ sums, int block, int n_blocks, double* red) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
-    for (int64_t ray = (int64_t)block * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)n_blocks * wpb) {
-        float s[2], z[2];
-        float4 rv[2];
-        bool vs[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int j = lane + 64 * c;
-            vs[c] = j < S;
-            rv[c] = vs[c] ? raw[ray * S + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            z[c] = vs[c] ? zv[ray * S + j] : 0.f;
-            s[c] = rv[c].w;
-        }
-        const RayW rw = ray_weights(s, z, vs, S, lane, trunc, sc);
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, md = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            m0 += rw.w[c] * rv[c].x; m1 += rw.w[c] * rv[c].y; m2 += rw.w[c] * rv[c].z; md += rw.w[c] * z[c];
-        }
-        m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); md = wave_sum(md);
-        const float d = tgt_d[ray];
-        const bool valid = (d > 0.0f) && (d < L.depth_trunc);
-        if (lane == 0) {
-            rgb_map[ray * 3] = m0; rgb_map[ray * 3 + 1] = m1; rgb_map[ray * 3 + 2] = m2; depth_map[ray] = md;
-            const float w = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
-            const float mm[3] = {m0, m1, m2};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float e = mm[c] * w - tgt_rgb[ray * 3 + c] * w;
-                a_rgb += (double)(e * e);
-            }
-            if (valid) { const float e = md - d; a_dep += (double)(e * e); a_val += 1.0; }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (!vs[c]) continue;
-            const float zz = z[c], ss = s[c];
-            const float front = (zz < (d - L.trunc_loss)) ? 1.0f : 0.0f;
-            const float back = (zz > (d + L.trunc_loss)) ? 1.0f : 0.0f;
-            const float sm = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
-            a_nfs += front; a_nsdf += sm;
-            if (valid) {
-                const float ef = ss * front - front;
-                const float es = (zz + ss * L.trunc_loss) * sm - d * sm;
-                a_fs += (double)(ef * ef); a_sdf += (double)(es * es);
-            }
-        }
-    }
-    a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
-    a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
-    a_nsdf = block_sum_d(a_nsdf, red);
-    if (threadIdx.x == 0) {
-        double* o = sums + (size_t)block * 8;
-        o[0] = a_rgb; o[1] = a_dep; o[2] = a_val; o[3] = a_fs; o[4] = a_sdf; o[5] = a_nfs; o[6] = a_nsdf; o[7] = 0.0;
-    }
-}
-
-
-// lc[0..3] = losses (rgb, depth, sdf, fs), lc[4..7] = coef: d loss_i / d (its squared-error sum), from the per-block
-// partial sums; for a 256-thread block, lc in LDS, valid for all threads on return.
-__device__ __forceinline__ void loss_finalize(const double* __restrict__ partial, int n_partials, int64_t n_rays, int S, float* lc) {
-    __shared__ double part[32][8], sums[8];
-    {   // thread = (value v, slice q): partials q, q + 32, ... in order, then the 32 slices in order
-        const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
-        double a = 0.0;
-        for (int k = q; k < n_partials; k += 32) a += partial[k * 8 + v];
-        part[q][v] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        double a = 0.0;
-        for (int q = 0; q < 32; ++q) a += part[q][threadIdx.x];
-        sums[threadIdx.x] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double ns = (double)n_rays * (double)S;
-        const double tot = sums[5] + sums[6];
-        const float fs_w = (float)(1.0 - sums[5] / tot), sdf_w = (float)(1.0 - sums[6] / tot);
-        const float c_rgb = (float)(1.0 / (3.0 * (double)n_rays)), c_dep = (float)(1.0 / sums[2]);
-        const float c_sdf = (float)(1.0 / ns) * sdf_w, c_fs = (float)(1.0 / ns) * fs_w;
-        lc[0] = (float)sums[0] * c_rgb; lc[1] = (float)sums[1] * c_dep;
-        lc[2] = (float)sums[4] * c_sdf; lc[3] = (float)sums[3] * c_fs;
-        lc[4] = c_rgb; lc[5] = c_dep; lc[6] = c_sdf; lc[7] = c_fs;
-    }
-    __syncthreads();
-}
-
+// (loss_finalize: rfx_common.h)
 __global__ __launch_bounds__(256) void mapping_loss_finalize_kernel(const double* __restrict__ partial, int n_partials, int64_t n_rays,
                                                                     int S, float* __restrict__ losses, float* __restrict__ coef) {
     __shared__ float lc[8];
@@ -612,23 +516,152 @@ __global__ __launch_bounds__(256) void tv_backward_kernel(const float* __restric
     tv_backward_body(feat, P, Cn, scale, gscale, dfeat, blockIdx.x, gridDim.x);
 }
 
-// composite_forward + the loss sums of a BA iteration's rays (blocks [0, nb_loss)) and, beside them, the gradient of the
-// TV term w.r.t. the lattice features the prologue looked up (the remaining blocks): the two are independent, and both only
-// feed the backward that follows.
+// the TV backward as a block role of another launch (composite_loss_grad_tv_kernel): the gradient of the TV term w.r.t. the
+// lattice features the prologue looked up only feeds the backward, like the loss gradient made beside it
 struct TvBackK { const float* feat; int P, Cn; float scale; float* dfeat; };
 
-__global__ __launch_bounds__(LOSS_THREADS) void composite_loss_tv_kernel(LossK L, const float4* __restrict__ raw,
-                                                                         const float* __restrict__ zv,
-                                                                         const float* __restrict__ tgt_rgb,
-                                                                         const float* __restrict__ tgt_d, int64_t n_rays, int S,
-                                                                         float trunc, float sc, float* __restrict__ rgb_map,
-                                                                         float* __restrict__ depth_map, double* __restrict__ sums,
-                                                                         int nb_loss, TvBackK tv) {
+// R1 + L1 forward AND L1 backward of a BA iteration's rays in one launch.  The backward needs the whole batch's loss
+// coefficients -- 1 / #valid rays, and the free-space / sdf weights from the two sample counts (model/utils.py:170-198) -- which
+// is why forward and backward are two kernels everywhere else.  But those three counts depend on the target depths and the
+// sample depths only, not on the field's output: the prologue that made the samples counts them (cnt_partials, one triple per
+// block of rays), every block here adds the triples up (integers in double: exact in any order) and knows the coefficients
+// before it has rendered anything.  Per ray: composite (ray_weights) -> maps -> squared errors (partial sums, for the reported
+// losses only) -> d_raw with the maps still in registers.  Expression for expression composite_forward_kernel +
+// mapping_loss_forward_kernel + mapping_loss_backward_kernel: the same d_raw bit for bit.  The remaining blocks: the TV backward (tv_backward_body).
+constexpr int LOSS_GRAD_BLOCKS = 1024;            // partial sums: LOSS_GRAD_BLOCKS x 8 doubles
+
+__global__ __launch_bounds__(LOSS_THREADS) void composite_loss_grad_tv_kernel(LossK L, const float4* __restrict__ raw,
+                                                                              const float* __restrict__ zv,
+                                                                              const float* __restrict__ tgt_rgb,
+                                                                              const float* __restrict__ tgt_d, int64_t n_rays, int S,
+                                                                              float trunc, float sc, float* __restrict__ rgb_map,
+                                                                              float* __restrict__ depth_map, double* __restrict__ sums,
+                                                                              const double* __restrict__ cnt_partials, int n_cnt,
+                                                                              const float* __restrict__ gout, float4* __restrict__ d_raw,
+                                                                              int* __restrict__ ray_counts, int nb_loss, TvBackK tv) {
     __shared__ double red[LOSS_THREADS / 64];
-    if ((int)blockIdx.x < nb_loss) {
-        composite_loss_forward_body(L, raw, zv, tgt_rgb, tgt_d, n_rays, S, trunc, sc, rgb_map, depth_map, sums, blockIdx.x, nb_loss, red);
-    } else {
+    __shared__ double cpart[64][4], ctot[4];
+    __shared__ float coef[4];
+    if ((int)blockIdx.x >= nb_loss) {
         tv_backward_body(tv.feat, tv.P, tv.Cn, tv.scale, nullptr, tv.dfeat, (int)blockIdx.x - nb_loss, (int)gridDim.x - nb_loss);
+        return;
+    }
+    {   // the batch's counts: 0 valid rays, 1 front samples, 2 sdf samples (thread = (value, slice), slices in order)
+        const int v = threadIdx.x & 3, q = threadIdx.x >> 2;
+        double a = 0.0;
+        for (int k = q; k < n_cnt; k += 64) a += cnt_partials[k * 4 + v];
+        cpart[q][v] = a;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double t = 0.0;
+            for (int qq = 0; qq < 64; ++qq) t += cpart[qq][threadIdx.x];
+            ctot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {             // loss_finalize's coefficients (rfx_common.h), from the same three numbers
+            const double ns = (double)n_rays * (double)S;
+            const double tot = ctot[1] + ctot[2];
+            const float fs_w = (float)(1.0 - ctot[1] / tot), sdf_w = (float)(1.0 - ctot[2] / tot);
+            coef[0] = (float)(1.0 / (3.0 * (double)n_rays)); coef[1] = (float)(1.0 / ctot[0]);
+            coef[2] = (float)(1.0 / ns) * sdf_w; coef[3] = (float)(1.0 / ns) * fs_w;
+        }
+        __syncthreads();
+    }
+    const float k_rgb = gout[0] * coef[0], k_dep = gout[1] * coef[1], k_sdf = gout[2] * coef[2], k_fs = gout[3] * coef[3];
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    double a_rgb = 0, a_dep = 0, a_val = 0, a_fs = 0, a_sdf = 0, a_nfs = 0, a_nsdf = 0;
+    for (int64_t ray = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)nb_loss * wpb) {
+        float s[2], z[2];
+        float4 rv[2];
+        bool vs[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = lane + 64 * c;
+            vs[c] = j < S;
+            rv[c] = vs[c] ? raw[ray * S + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            z[c] = vs[c] ? zv[ray * S + j] : 0.f;
+            s[c] = rv[c].w;
+        }
+        const RayW rw = ray_weights(s, z, vs, S, lane, trunc, sc);
+        // ---- forward: maps and squared errors (composite_forward_kernel, mapping_loss_forward_kernel)
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, md = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            m0 += rw.w[c] * rv[c].x; m1 += rw.w[c] * rv[c].y; m2 += rw.w[c] * rv[c].z; md += rw.w[c] * z[c];
+        }
+        m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); md = wave_sum(md);
+        const float d = tgt_d[ray];
+        const bool valid = (d > 0.0f) && (d < L.depth_trunc);
+        const float mm[3] = {m0, m1, m2};
+        if (lane == 0) {
+            rgb_map[ray * 3] = m0; rgb_map[ray * 3 + 1] = m1; rgb_map[ray * 3 + 2] = m2; depth_map[ray] = md;
+            const float w = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float e = mm[c] * w - tgt_rgb[ray * 3 + c] * w;
+                a_rgb += (double)(e * e);
+            }
+            if (valid) { const float e = md - d; a_dep += (double)(e * e); a_val += 1.0; }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!vs[c]) continue;
+            const float zz = z[c], ss = s[c];
+            const float front = (zz < (d - L.trunc_loss)) ? 1.0f : 0.0f;
+            const float back = (zz > (d + L.trunc_loss)) ? 1.0f : 0.0f;
+            const float sm = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
+            a_nfs += front; a_nsdf += sm;
+            if (valid) {
+                const float ef = ss * front - front;
+                const float es = (zz + ss * L.trunc_loss) * sm - d * sm;
+                a_fs += (double)(ef * ef); a_sdf += (double)(es * es);
+            }
+        }
+        // ---- backward (mapping_loss_backward_kernel)
+        const float w2 = (valid || L.rgb_missing_on) ? 1.0f : 0.0f;
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = k_rgb * 2.0f * w2 * (mm[c] * w2 - tgt_rgb[ray * 3 + c] * w2);
+        const float gd = valid ? k_dep * 2.0f * (md - d) : 0.0f;
+        float gj[2], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            gj[c] = g[0] * rv[c].x + g[1] * rv[c].y + g[2] * rv[c].z + gd * z[c];
+            dot += rw.w[c] * gj[c];
+        }
+        dot = wave_sum(dot);
+        int nz = 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!vs[c]) continue;
+            float ds = 0.f;
+            if (rw.w[c] != 0.0f) {
+                const float a = s[c] / trunc;
+                const float sp = sigmoidf(a), sm = sigmoidf(-a);
+                ds = (gj[c] - dot) / rw.wsum * (sp * sm * (sm - sp) / trunc);
+            }
+            if (valid) {
+                const float front = (z[c] < (d - L.trunc_loss)) ? 1.0f : 0.0f;
+                const float back = (z[c] > (d + L.trunc_loss)) ? 1.0f : 0.0f;
+                const float smk = (1.0f - front) * (1.0f - back) * (d > 0.0f ? 1.0f : 0.0f);
+                ds += k_fs * 2.0f * (s[c] * front - front) * front;
+                ds += k_sdf * 2.0f * ((z[c] + s[c] * L.trunc_loss) * smk - d * smk) * (L.trunc_loss * smk);
+            }
+            const float4 o = make_float4(rw.w[c] * g[0], rw.w[c] * g[1], rw.w[c] * g[2], ds);
+            d_raw[ray * S + lane + 64 * c] = o;
+            nz += (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) ? 1 : 0;
+        }
+        if (ray_counts) {
+            nz = (int)wave_sum((float)nz);
+            if (lane == 0) ray_counts[ray] = nz;
+        }
+    }
+    a_rgb = block_sum_d(a_rgb, red); a_dep = block_sum_d(a_dep, red); a_val = block_sum_d(a_val, red);
+    a_fs = block_sum_d(a_fs, red); a_sdf = block_sum_d(a_sdf, red); a_nfs = block_sum_d(a_nfs, red);
+    a_nsdf = block_sum_d(a_nsdf, red);
+    if (threadIdx.x == 0) {
+        double* o = sums + (size_t)blockIdx.x * 8;
+        o[0] = a_rgb; o[1] = a_dep; o[2] = a_val; o[3] = a_fs; o[4] = a_sdf; o[5] = a_nfs; o[6] = a_nsdf; o[7] = 0.0;
     }
 }
 
@@ -791,8 +824,13 @@ struct RayOut {
     float *rays_o, *rays_d, *tgt_rgb, *tgt_d, *d_cam; int* pose_idx; float *z_vals, *x01;
 };
 
+// cnt (optional, this lane's share): [0] rays with a valid target depth, [1] front samples, [2] sdf samples -- the three
+// counts the loss coefficients are made of (get_masks, model/utils.py:170-198; counted as mapping_loss_forward_kernel does)
+struct LossCountK { float trunc_loss, depth_trunc; double* partials; };
+
 __device__ __forceinline__ void ray_setup_body(const GatherK& g, const SamplerK& s, const BoxK& box, const float* __restrict__ u01,
-                                               uint64_t seed_u, const RayOut& out, int block, int n_blocks, float (*zsh)[MAX_S]) {
+                                               uint64_t seed_u, const RayOut& out, int block, int n_blocks, float (*zsh)[MAX_S],
+                                               const LossCountK* lcnt = nullptr, double* cnt = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = s.n_range_d + s.n_samples_d;
     float* zs = zsh[wv];
@@ -839,7 +877,14 @@ __device__ __forceinline__ void ray_setup_body(const GatherK& g, const SamplerK&
             out.z_vals[i * S + j] = z;
 #pragma unroll
             for (int c = 0; c < 3; ++c) out.x01[(i * S + j) * 3 + c] = normalise(box, c, o[c] + d[c] * z);
+            if (cnt) {
+                const float front = (z < (td - lcnt->trunc_loss)) ? 1.0f : 0.0f;
+                const float back = (z > (td + lcnt->trunc_loss)) ? 1.0f : 0.0f;
+                const float sm = (1.0f - front) * (1.0f - back) * (td > 0.0f ? 1.0f : 0.0f);
+                cnt[1] += front; cnt[2] += sm;
+            }
         }
+        if (cnt && lane == 0 && (td > 0.0f) && (td < lcnt->depth_trunc)) cnt[0] += 1.0;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -858,13 +903,21 @@ struct TvEncK {
 __global__ __launch_bounds__(256) void ba_prologue_kernel(GatherK g, SamplerK s, BoxK box, const float* __restrict__ u01,
                                                           uint64_t seed_u, RayOut out, int nb_rays, FieldK f,
                                                           float* __restrict__ staged, int nb_stage, TvEncK tv, int nb_tv,
-                                                          float* __restrict__ zero, int64_t zero_floats) {
+                                                          float* __restrict__ zero, int64_t zero_floats, LossCountK lcnt) {
     __shared__ float zsh[4][MAX_S];
+    __shared__ double cred[4];
     // dispatch order = block index: the ray batch first (a chain of dependent latencies per ray: the launch's critical
     // path; with the lattice's lookups ahead of it the launch took 25 us instead of 20)
     const int b = blockIdx.x;
     if (b < nb_rays) {
-        ray_setup_body(g, s, box, u01, seed_u, out, b, nb_rays, zsh);
+        if (lcnt.partials) {
+            double cnt[3] = {0.0, 0.0, 0.0};
+            ray_setup_body(g, s, box, u01, seed_u, out, b, nb_rays, zsh, &lcnt, cnt);
+            const double c0 = block_sum_d(cnt[0], cred), c1 = block_sum_d(cnt[1], cred), c2 = block_sum_d(cnt[2], cred);
+            if (threadIdx.x == 0) { double* o = lcnt.partials + (size_t)b * 4; o[0] = c0; o[1] = c1; o[2] = c2; o[3] = 0.0; }
+        } else {
+            ray_setup_body(g, s, box, u01, seed_u, out, b, nb_rays, zsh);
+        }
     } else if (b < nb_rays + nb_stage) {
         const int i = (b - nb_rays) * 256 + threadIdx.x;
         if (i < ALL_SLOTS * 64) staged[i] = staged_weight(f, i >> 6, i & 63);
@@ -1219,7 +1272,8 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
-                rfx_stream stream) {
+                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream) {
+    if (n_count_partials) *n_count_partials = 0;
     const int64_t n = n_kf_samples + n_cur;
     if (n == 0) return RFX_OK;
     if (!rays_o || !rays_d || !target_rgb || !target_d || !d_cam || !pose_idx || !z_vals || !x01 || !bbox) return RFX_ERR_ARG;
@@ -1257,50 +1311,43 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
     if (nb_rays + nb_stage + nb_tv + nb_zero > 0x7fffffff) return RFX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(ba_prologue_kernel, dim3((unsigned)(nb_rays + nb_stage + nb_tv + nb_zero)), dim3(256), 0, as_stream(stream), g, k,
                        make_box(bbox, bbox_f64), seed_u ? nullptr : u01, seed_u, out, nb_rays, fk, staged, nb_stage, tv, nb_tv, zero,
-                       zero_floats);
+                       zero_floats, LossCountK{trunc_loss, depth_trunc, count_partials});
+    if (count_partials && n_count_partials) *n_count_partials = nb_rays;
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
 
-// rfx_composite_forward + the summing half of rfx_mapping_loss_forward: leaves the per-block partial sums in `sums`
-// (*n_partials of them) for loss_backward_from_partials, which finishes them
-int composite_loss_forward(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays,
-                           int S, float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on,
-                           float* rgb_map, float* depth_map, double* sums, int* n_partials, const float* tv_feat, int tv_P, int tv_C,
-                           float tv_scale, float* tv_dfeat, rfx_stream stream) {
+// rfx_composite_forward + rfx_mapping_loss_forward + rfx_mapping_loss_backward in one launch (composite_loss_grad_tv_kernel), for a batch whose three
+// loss counts the prologue left in count_partials.  sums: LOSS_GRAD_BLOCKS x 8 doubles; *n_partials of them are written and
+// wait for a finalize (loss_finalize: the selection's launch takes it along, or loss_finalize_launch below).
+int composite_loss_grad(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays, int S,
+                        float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, float* rgb_map,
+                        float* depth_map, double* sums, int* n_partials, const double* count_partials, int n_count_partials,
+                        const float* gout4, float* d_raw4, int32_t* ray_counts, const float* tv_feat, int tv_P, int tv_C, float tv_scale,
+                        float* tv_dfeat, rfx_stream stream) {
     *n_partials = 0;
     if (n_rays == 0) return RFX_OK;
-    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums) return RFX_ERR_ARG;
-    if (n_rays < 0 || S <= 0 || !(trunc > 0.f)) return RFX_ERR_ARG;
+    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !count_partials || !gout4 || !d_raw4)
+        return RFX_ERR_ARG;
+    if (n_rays < 0 || S <= 0 || !(trunc > 0.f) || n_count_partials <= 0) return RFX_ERR_ARG;
     if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
     if (tv_dfeat && (!tv_feat || tv_P <= 0 || tv_C <= 0)) return RFX_ERR_ARG;
-    hipStream_t st = as_stream(stream);
     LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
-    const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_BLOCKS);
+    const int blocks = (int)std::min<int64_t>((n_rays + LOSS_THREADS / 64 - 1) / (LOSS_THREADS / 64), LOSS_GRAD_BLOCKS);
     TvBackK tv = {tv_feat, tv_P, tv_C, tv_scale, tv_dfeat};
-    int nb_tv = 0;          // rfx_tv_backward's grid
+    int nb_tv = 0;
     if (tv_dfeat) nb_tv = (int)std::min<int64_t>(((int64_t)tv_P * tv_P * tv_P * tv_C + 255) / 256, 2048);
-    hipLaunchKernelGGL(composite_loss_tv_kernel, dim3(blocks + nb_tv), dim3(LOSS_THREADS), 0, st, L, reinterpret_cast<const float4*>(raw4),
-                       z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map, sums, blocks, tv);
+    hipLaunchKernelGGL(composite_loss_grad_tv_kernel, dim3(blocks + nb_tv), dim3(LOSS_THREADS), 0, as_stream(stream), L,
+                       reinterpret_cast<const float4*>(raw4), z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map,
+                       sums, count_partials, n_count_partials, gout4, reinterpret_cast<float4*>(d_raw4), ray_counts, blocks, tv);
     RFX_LAUNCH_CHECK();
     *n_partials = blocks;
     return RFX_OK;
 }
 
-// rfx_mapping_loss_forward's finalize + rfx_mapping_loss_backward: lc8 <- losses | coefficients, d_raw4 <- gradient
-int loss_backward_from_partials(const float* raw4, const float* z_vals, const float* rgb_map, const float* depth_map,
-                                const float* target_rgb, const float* target_d, int64_t n_rays, int S, float trunc, float sc_factor,
-                                float trunc_loss, float depth_trunc, int rgb_missing_on, const double* sums, int n_partials,
-                                const float* gout4, float* lc8, float* d_raw4, int32_t* ray_counts, rfx_stream stream) {
-    if (n_rays == 0) return RFX_OK;
-    if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !gout4 || !lc8 || !d_raw4) return RFX_ERR_ARG;
-    if (n_rays < 0 || S <= 0 || !(trunc > 0.f) || n_partials <= 0) return RFX_ERR_ARG;
-    if (S > MAX_S) return RFX_ERR_UNSUPPORTED;
-    LossK L; L.trunc_loss = trunc_loss; L.depth_trunc = depth_trunc; L.rgb_missing_on = rgb_missing_on ? 1 : 0;
-    hipLaunchKernelGGL(mapping_loss_backward_kernel<true>, dim3(ray_grid(n_rays)), dim3(256), 0, as_stream(stream), L,
-                       reinterpret_cast<const float4*>(raw4), z_vals, rgb_map, depth_map, target_rgb, target_d, n_rays, S, trunc,
-                       sc_factor, (const float*)nullptr, gout4, (const float*)nullptr, (const float*)nullptr,
-                       reinterpret_cast<float4*>(d_raw4), sums, n_partials, lc8, ray_counts);
+int loss_finalize_launch(const double* sums, int n_partials, int64_t n_rays, int S, float* lc8, rfx_stream stream) {
+    if (!sums || !lc8 || n_partials <= 0 || n_rays <= 0 || S <= 0) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(mapping_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, n_partials, n_rays, S, lc8, lc8 + 4);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
