@@ -155,7 +155,11 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
         int chained = 0;      // d rays -> d poses -> pose-MLP backward in one launch, when the caller hands the MLP over
         if (b->rba) {
             if (!b->rba_acts || !b->rba_grads || !b->rba_ws) return RFX_ERR_ARG;
-            RFX_TRY(pose_chain_backward(w.dx, w.z, w.d_cam, w.pidx, n, S, b->bbox, b->K, b->d_poses16, b->rba, b->rba_acts, b->rba_scale,
+            // one block per camera walks that camera's rays, 64 at a time: with few cameras (the first keyframes of a stream:
+            // 2 048 keyframe rays over 1-5 poses, 400-2 000 current-frame rays on the last) the separate, ray-parallel
+            // stages are faster; from ~800 rays on the heaviest camera downwards the single launch wins (30 -> 20 us at 13)
+            const int64_t heaviest = b->n_cur + (b->n_kf_samples + std::max(b->K - 1, 1) - 1) / std::max(b->K - 1, 1);
+            if (heaviest <= 800) RFX_TRY(pose_chain_backward(w.dx, w.z, w.d_cam, w.pidx, n, S, b->bbox, b->K, b->d_poses16, b->rba, b->rba_acts, b->rba_scale,
                                         b->rba_grads, b->rba_ws, stream, &chained));
         }
         if (!chained) {
