@@ -439,3 +439,69 @@ def test_uniform_draws_match_oracle_bit_exact():
         L.check(lib.rfx_uniform_draws(seed, stream, n, L.ptr(out), L.stream_ptr(out.device)), "rfx_uniform_draws")
         assert np.array_equal(out.cpu().numpy(), DO.uniform_draws(seed, stream, n)), (seed, stream, n)
     assert lib.rfx_uniform_draws(1, 0, 4, None, None) != 0          # no output buffer
+
+
+@pytest.mark.parametrize("sample,min_cur", [(128, 128), (512, 1024)])
+def test_one_call_iteration_equals_stagewise_on_both_sides_of_its_switches(sample, min_cur):
+    """rfx_ba_forward_backward against the same iteration issued through the public per-stage entry points, on the paths the
+    big tests do not reach: sample = 128 -> 256 rays x 59 < 16 384 points (no row selection: the losses are finished by a
+    launch of their own); 512 keyframe + 1 024 current-frame rays on 3 cameras -> more than 800 rays on the heaviest camera (the
+    pose phase's tail as separate stages instead of the one-launch chain).  Same seeds -> same draws (rfx_uniform_draws in the staged
+    issue): losses, decoder gradients and d_raw-derived quantities equal, hash / pose-MLP gradients to atomic / grouping order."""
+    import random
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    from remixfusion_amd.mp_slam.direct import DirectIterations
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+    cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+    cfg["mapping"].update({"first_iters": 5, "sample": sample, "iters": 2, "BA_iters": 2, "min_pixels_cur": min_cur})
+    cfg["training"].update({"smooth_pts": 16})
+    pipe = MappingPipeline(cfg, n_frames=30, seed=1)
+    frames = pipe.prefetch(list(range(12)))
+    pipe.start(frames[0])
+    for i in range(1, 11):
+        pipe.step(i, frames[i])
+    mp, model, slam = pipe.mapper, pipe.model, pipe.slam
+    direct = DirectIterations(mp)
+    S = int(cfg["training"]["n_range_d"]) + int(cfg["training"]["n_samples_d"])
+    n = direct._n_rays()
+    assert n == sample + min_cur and (n * S < 16384) == (sample == 128)
+    b = frames[10]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    K = len(mp.keyframe) + 1
+    assert K == 3
+    all_index = torch.arange(0, K, device="cuda").unsqueeze(-1)
+    params = [model.embed_res_fn.params] + list(model.decoder_res.fused_weights())
+    rba_params = list(model.rba.parameters())
+
+    def run(every, phase):
+        for p in params + rba_params:
+            p.grad = None
+        random.seed(21); torch.manual_seed(21)
+        direct.stagewise_every = every
+        if phase == "map":
+            poses = slam.est_c2w_data[0:11:5].clone().cuda().float()
+            poses = torch.cat([poses, poses[-1:]], 0)[:K]
+            lc = direct.map_gradients(cur, poses).clone()
+        else:
+            lc = direct.pose_gradients(cur, all_index.reshape(-1).contiguous(), map_grads=False).clone()
+        torch.cuda.synchronize()
+        return lc, [p.grad.clone() for p in params if p.grad is not None], [p.grad.clone() for p in rba_params if p.grad is not None]
+
+    for phase in ("map", "pose"):
+        lc1, m1, r1 = run(0, phase)          # one call
+        lc2, m2, r2 = run(1, phase)          # stage by stage
+        assert torch.isfinite(lc1).all() and float(lc1[:4].abs().sum()) > 0
+        assert float((lc1[:4] - lc2[:4]).abs().max()) <= 1e-6 * float(lc2[:4].abs().max())        # losses (sums grouped differently)
+        assert torch.equal(lc1[4:], lc2[4:])                                                       # coefficients: exact counts
+        if phase == "map":
+            for g, r in zip(m1[1:], m2[1:]):
+                assert torch.equal(g, r)                                   # dW: deterministic reductions, identical kernels
+            assert float((m1[0] - m2[0]).abs().max()) <= 1e-4 * float(m2[0].abs().max())
+        else:
+            assert not m1 and not m2
+            for g, r in zip(r1, r2):
+                assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
+            assert float(r1[0].abs().max()) > 0
+    direct.stagewise_every = 0
