@@ -214,6 +214,10 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
  * workspace (optional, dev, >= rfx_grid_encode_backward_workspace_bytes): enables the LDS-privatised
  * scatter (per-segment accumulation in LDS, contiguous flush); NULL = direct atomics. */
 size_t rfx_grid_encode_backward_workspace_bytes(int64_t n, int n_levels);
+/* The size that lets the scatter keep ALL binned levels of grid `g` (levels of >= 16 segments: T >= 2^19) in flight at
+ * once -- four launches per sweep instead of four per level; with the minimum above they go one level at a time.  Any size
+ * in between is used for as many levels per group as fit.  Equals the minimum for grids without binned levels. (ABI 5) */
+size_t rfx_grid_encode_backward_workspace_bytes_for(const rfx_grid_desc* g, int64_t n);
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
                              const float* dfeat, float* dtable, float* dx01, void* workspace, size_t workspace_bytes,
                              rfx_stream stream);
@@ -516,6 +520,9 @@ typedef struct rfx_ba_desc {
 } rfx_ba_desc;
 size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign binding verify its mirror of the struct */
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);
+/* the same with the scatter's share sized by rfx_grid_encode_backward_workspace_bytes_for(hash, points): whatever lies behind
+ * the minimum is the scatter's (its region is the workspace's last) */
+size_t rfx_ba_workspace_bytes_for(int64_t n_rays, int S, int tv_P, const rfx_grid_desc* hash);
 /* workspace: dev, 256-byte aligned, >= rfx_ba_workspace_bytes(n_kf_samples + n_cur, S, tv_P, L*F, L). */
 int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream);
 /* Where the iteration's intermediates live inside the workspace after a call (byte offsets from its base), so that a

@@ -46,7 +46,8 @@ struct BaWs {
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_levels) {
+// scat_bytes_given: bytes the caller's workspace has for the scatter region (the last one); 0 = the minimum
+static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_levels, size_t scat_bytes_given = 0) {
     BaWs w;
     size_t off = 0;
     char* b0 = reinterpret_cast<char*>(base);
@@ -61,7 +62,7 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     w.d_raw = (float*)take(nS * 16); w.dx = (float*)take(nS * 12); w.go = (float*)take(n * 12); w.gd = (float*)take(n * 12);
     w.bwd_bytes = rfx_field_backward_workspace_bytes((int64_t)nS);
     w.bwd_ws = take(w.bwd_bytes);
-    w.scat_bytes = rfx_grid_encode_backward_workspace_bytes((int64_t)(nS + nt), n_levels);
+    w.scat_bytes = std::max(rfx_grid_encode_backward_workspace_bytes((int64_t)(nS + nt), n_levels), scat_bytes_given);
     w.scat_ws = take(w.scat_bytes);
     w.total = off;
     return w;
@@ -78,6 +79,13 @@ size_t rfx_ba_desc_bytes(void) { return sizeof(rfx_ba_desc); }
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat, int n_levels) {
     if (n_rays <= 0 || S <= 0 || tv_P <= 0 || n_feat <= 0 || n_levels <= 0) return 0;
     return carve_ba(nullptr, n_rays, S, tv_P, n_feat, n_levels).total;
+}
+
+size_t rfx_ba_workspace_bytes_for(int64_t n_rays, int S, int tv_P, const rfx_grid_desc* hash) {
+    if (n_rays <= 0 || S <= 0 || tv_P <= 0 || !hash || hash->n_levels <= 0 || hash->n_feat <= 0) return 0;
+    const int64_t pts = n_rays * S + (int64_t)tv_P * tv_P * tv_P;
+    return carve_ba(nullptr, n_rays, S, tv_P, hash->n_levels * hash->n_feat, hash->n_levels,
+                    rfx_grid_encode_backward_workspace_bytes_for(hash, pts)).total;
 }
 
 int rfx_ba_workspace_layout(int64_t n_rays, int S, int tv_P, int n_feat, int n_levels, size_t* offsets, int count) {
@@ -108,7 +116,10 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     if ((b->d_hash != nullptr) != (b->d_w != nullptr) || (!map_grads && !b->d_poses16)) return RFX_ERR_ARG;
     if ((uintptr_t)workspace & 255) return RFX_ERR_ARG;
     if (workspace_bytes < rfx_ba_workspace_bytes(n, S, P, L * F, L)) return RFX_ERR_WORKSPACE;
-    const BaWs w = carve_ba(workspace, n, S, P, L * F, L);
+    // everything behind the minimum belongs to the scatter (its region is the last): more binned levels per group of launches
+    const size_t min_total = rfx_ba_workspace_bytes(n, S, P, L * F, L);
+    const size_t min_scat = rfx_grid_encode_backward_workspace_bytes(n * S + (int64_t)P * P * P, L);
+    const BaWs w = carve_ba(workspace, n, S, P, L * F, L, min_scat + (workspace_bytes - min_total));
     hipStream_t st = as_stream(stream);
     const int64_t nS = n * S, nt = (int64_t)P * P * P;
     // ---- ray batch (rays, S1, points); beside it in the same launch: decoder weights -> MFMA operand image (the optimizers

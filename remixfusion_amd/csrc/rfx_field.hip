@@ -20,6 +20,8 @@
 //    scatters the hash-grid gradients (float atomics) and evaluates d/dx of the encodings.
 #include "rfx_field_mlp.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rfx {
 
@@ -584,9 +586,28 @@ __device__ __forceinline__ unsigned bin_take(unsigned* counters, unsigned seg, b
 }
 
 constexpr int BIN_PPT = 2;            // points per thread in the count / record kernels: 2 048 points per block
-__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(Level lv, int level, ScatterSrc a, ScatterSrc b, int n_seg, int n_blk,
-                                                                unsigned* __restrict__ counts) {
+
+// The binned levels of one sweep that are in flight TOGETHER (as many as the caller's scratch holds records for: 96 B per point
+// and level).  One level at a time meant four launches per level -- 44 dependent launches per scatter at T = 2^19, each a few
+// hundred blocks at most -- so the kernels below take a group of levels: blockIdx.y (count, records), blockIdx.x (scan) or a
+// flattened (level, segment) index (reduce) says which.
+struct BinLevels {
+    int n;                                   // levels in the group
+    Level lv[RFX_MAX_LEVELS];
+    int level[RFX_MAX_LEVELS];               // index of the level in the grid (its column pair in dfeat)
+    int n_seg[RFX_MAX_LEVELS];
+    int seg_base[RFX_MAX_LEVELS + 1];        // first flattened (level, segment) index of each level
+    unsigned* counts[RFX_MAX_LEVELS];        // [seg][blk]
+    unsigned* offsets[RFX_MAX_LEVELS];       // [seg][blk]
+    unsigned* seg_start[RFX_MAX_LEVELS];     // [n_seg + 1]
+    BinRec* rec[RFX_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(BinLevels B, ScatterSrc a, ScatterSrc b, int n_blk) {
     __shared__ unsigned h[BIN_MAX_SEGS];
+    const int g = blockIdx.y;
+    const Level lv = B.lv[g];
+    const int n_seg = B.n_seg[g], level = B.level[g];
     for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) h[i] = 0u;
     __syncthreads();
 #pragma unroll
@@ -602,14 +623,19 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(Level lv, int le
         for (int k = 0; k < 8; ++k) bin_take(h, idx8[k] >> BIN_SEG_SHIFT, act);
     }
     __syncthreads();
+    unsigned* __restrict__ counts = B.counts[g];
     for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) counts[(size_t)i * n_blk + blockIdx.x] = h[i];      // [seg][blk]
 }
 
 // counts / offsets are [seg][blk].  offsets[seg][blk] = start of block blk's range in segment seg's bin; seg_start[seg] =
-// start of the bin (seg_start[n_seg] = total).  One block; a wave takes a segment at a time, lanes over the blocks.
-__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(const unsigned* __restrict__ counts, int n_blk, int n_seg,
-                                                               unsigned* __restrict__ offsets, unsigned* __restrict__ seg_start) {
+// start of the bin (seg_start[n_seg] = total).  One block per level; a wave takes a segment at a time, lanes over the blocks.
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(BinLevels B, int n_blk) {
     __shared__ unsigned tot[BIN_MAX_SEGS + 1];
+    const int g = blockIdx.x;
+    const int n_seg = B.n_seg[g];
+    const unsigned* __restrict__ counts = B.counts[g];
+    unsigned* __restrict__ offsets = B.offsets[g];
+    unsigned* __restrict__ seg_start = B.seg_start[g];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_wv = BIN_THREADS / 64;
     for (int s = wv; s < n_seg; s += n_wv) {
         unsigned t = 0;
@@ -655,9 +681,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(const unsigned* _
     }
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(Level lv, int level, ScatterSrc a, ScatterSrc b, int n_seg, int n_blk,
-                                                                  const unsigned* __restrict__ offsets, BinRec* __restrict__ rec) {
+__global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(BinLevels B, ScatterSrc a, ScatterSrc b, int n_blk) {
     __shared__ unsigned cur[BIN_MAX_SEGS];
+    const int g = blockIdx.y;
+    const Level lv = B.lv[g];
+    const int n_seg = B.n_seg[g], level = B.level[g];
+    const unsigned* __restrict__ offsets = B.offsets[g];
+    BinRec* __restrict__ rec = B.rec[g];
     for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) cur[i] = offsets[(size_t)i * n_blk + blockIdx.x];
     __syncthreads();
 #pragma unroll
@@ -682,11 +712,15 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(Level lv, int 
     }
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(Level lv, const unsigned* __restrict__ seg_start,
-                                                                 const BinRec* __restrict__ rec, float* __restrict__ dtable) {
+__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     double* acc = reinterpret_cast<double*>(acc_raw);
-    const unsigned seg = blockIdx.x, base = seg << BIN_SEG_SHIFT;
+    int g = 0;
+    while (g + 1 < B.n && (int)blockIdx.x >= B.seg_base[g + 1]) ++g;
+    const Level lv = B.lv[g];
+    const unsigned* __restrict__ seg_start = B.seg_start[g];
+    const BinRec* __restrict__ rec = B.rec[g];
+    const unsigned seg = blockIdx.x - (unsigned)B.seg_base[g], base = seg << BIN_SEG_SHIFT;
     const unsigned cnt = min(BIN_SEG, lv.size - base);
     // gridDim.y blocks share a segment's bin (a level has 64-256 segments: one block each would leave most CUs idle)
     const unsigned s0 = seg_start[seg], s1 = seg_start[seg + 1];
@@ -713,34 +747,62 @@ static bool level_is_binned(const rfx_grid_desc& g, int l) {
     return segs >= (unsigned)SCATTER_BIN_MIN_SEGMENTS && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
 }
 
-// one level through the four kernels above; scratch: >= n_all * 96 + (2 n_blk + 1) * (n_seg + 1) * 4 bytes
-static int launch_binned_level(const rfx_grid_desc& g, int l, const ScatterSrc& a, const ScatterSrc& b, float* dtable, float* scratch,
-                               size_t scratch_floats, hipStream_t st) {
+// scratch one binned level needs: its records (8 per point) + counts and offsets [seg][blk] + the bins' starts
+static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) {
+    const size_t n_seg = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
+    const size_t n_blk = (size_t)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
+    return (size_t)n_all * 8 * 3 + 2 * n_blk * n_seg + n_seg + 1 + 4;      // (+4: keeps the next level's records 16-byte aligned)
+}
+
+// the binned levels `levels[0..n_lv)` through the four kernels above, as many levels per group of launches as the scratch
+// holds (at least one: the caller's minimum, rfx_grid_encode_backward_workspace_bytes, covers one level)
+static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n_lv, const ScatterSrc& a, const ScatterSrc& b,
+                                float* dtable, float* scratch, size_t scratch_floats, hipStream_t st) {
     const int64_t n_all = a.n + b.n;
-    const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
     const int n_blk = (int)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
-    const size_t rec_floats = (size_t)n_all * 8 * 3, cnt_words = (size_t)n_blk * n_seg;
-    if (rec_floats + 2 * cnt_words + n_seg + 1 > scratch_floats) return RFX_ERR_WORKSPACE;
-    BinRec* rec = reinterpret_cast<BinRec*>(scratch);
-    unsigned* counts = reinterpret_cast<unsigned*>(scratch + rec_floats);
-    unsigned* offsets = counts + cnt_words;
-    unsigned* seg_start = offsets + cnt_words;
-    Level lv;
-    lv.scale = g.scale[l]; lv.res = g.res[l]; lv.size = g.size[l]; lv.offset = g.offset[l]; lv.hashed = g.hashed[l];
-    hipLaunchKernelGGL(bin_count_kernel, dim3(n_blk), dim3(BIN_THREADS), 0, st, lv, l, a, b, n_seg, n_blk, counts);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, st, counts, n_blk, n_seg, offsets, seg_start);
-    hipLaunchKernelGGL(bin_records_kernel, dim3(n_blk), dim3(BIN_THREADS), 0, st, lv, l, a, b, n_seg, n_blk, offsets, rec);
     const size_t lds = (size_t)BIN_SEG * 2 * sizeof(double);
     static bool attr_set[64] = {};            // per device (the attribute is per device; benign if raced)
+    static const bool debug = getenv("RFX_DEBUG_BINS") != nullptr;
     int dev = 0;
     RFX_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bin_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
-    const int split = std::max(1, std::min(8, 256 / std::max(1, n_seg)));
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3(n_seg, split), dim3(BIN_THREADS), lds, st, lv, seg_start, rec, dtable);
-    RFX_LAUNCH_CHECK();
+    int i = 0;
+    while (i < n_lv) {
+        BinLevels B;
+        B.n = 0;
+        B.seg_base[0] = 0;
+        size_t used = 0;
+        while (i < n_lv && B.n < RFX_MAX_LEVELS) {
+            const int l = levels[i];
+            const size_t need = (binned_level_floats(g, l, n_all) + 3) & ~(size_t)3;
+            if (used + need > scratch_floats) break;
+            const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
+            const size_t rec_floats = (size_t)n_all * 8 * 3, cnt_words = (size_t)n_blk * n_seg;
+            const int k = B.n++;
+            B.lv[k].scale = g.scale[l]; B.lv[k].res = g.res[l]; B.lv[k].size = g.size[l]; B.lv[k].offset = g.offset[l]; B.lv[k].hashed = g.hashed[l];
+            B.level[k] = l; B.n_seg[k] = n_seg; B.seg_base[k + 1] = B.seg_base[k] + n_seg;
+            float* base = scratch + used;
+            B.rec[k] = reinterpret_cast<BinRec*>(base);
+            B.counts[k] = reinterpret_cast<unsigned*>(base + rec_floats);
+            B.offsets[k] = B.counts[k] + cnt_words;
+            B.seg_start[k] = B.offsets[k] + cnt_words;
+            used += need;
+            ++i;
+        }
+        if (debug) fprintf(stderr, "[bins] group of %d levels (%d of %d done), %zu of %zu floats, %lld points\n", B.n, i, n_lv, used, scratch_floats, (long long)n_all);
+        if (B.n == 0) return RFX_ERR_WORKSPACE;
+        for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.seg_base[k] = B.seg_base[B.n];
+        const int total_seg = B.seg_base[B.n];
+        hipLaunchKernelGGL(bin_count_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(B.n), dim3(BIN_THREADS), 0, st, B, n_blk);
+        hipLaunchKernelGGL(bin_records_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
+        const int split = std::max(1, std::min(8, 512 / std::max(1, total_seg)));
+        hipLaunchKernelGGL(bin_reduce_kernel, dim3(total_seg, split), dim3(BIN_THREADS), lds, st, B, dtable);
+        RFX_LAUNCH_CHECK();
+    }
     return RFX_OK;
 }
 
@@ -749,7 +811,8 @@ static int launch_binned_level(const rfx_grid_desc& g, int l, const ScatterSrc& 
 static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const float* x01, int64_t n, const float* dfeat,
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
                                const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0, const int* perm = nullptr,
-                               const int* n_sel = nullptr, const DwJob* dw = nullptr, bool* dw_taken = nullptr) {
+                               const int* n_sel = nullptr, const DwJob* dw = nullptr, bool* dw_taken = nullptr,
+                               size_t scratch_avail_floats = 0) {
     ScatterPlan plan;
     if (dw_taken) *dw_taken = false;
     const int64_t n_all = n + n_b;
@@ -814,9 +877,10 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
                                g.n_levels, scratch, dtable);
         RFX_LAUNCH_CHECK();
     }
-    for (int l = 0; l < g.n_levels; ++l) {
-        if (!binned[l]) continue;
-        const int rc = launch_binned_level(g, l, a, b, dtable, scratch, scratch_floats, st);
+    int bl[RFX_MAX_LEVELS], n_bl = 0;
+    for (int l = 0; l < g.n_levels; ++l) if (binned[l]) bl[n_bl++] = l;
+    if (n_bl > 0) {       // (after the sweep: the records re-use the staging buffer)
+        const int rc = launch_binned_levels(g, bl, n_bl, a, b, dtable, scratch, std::max(scratch_floats, scratch_avail_floats), st);
         if (rc) return rc;
     }
     return RFX_OK;
@@ -1517,6 +1581,15 @@ size_t rfx_grid_encode_backward_workspace_bytes(int64_t n, int n_levels) {
     return scatter_scratch_floats(n, n_levels) * sizeof(float);
 }
 
+size_t rfx_grid_encode_backward_workspace_bytes_for(const rfx_grid_desc* g, int64_t n) {
+    if (!g || n <= 0 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return 0;
+    size_t need = scatter_scratch_floats(n, g->n_levels), all = 0;
+    if (n >= SCATTER_MIN_POINTS)
+        for (int l = 0; l < g->n_levels; ++l)
+            if (level_is_binned(*g, l)) all += (binned_level_floats(*g, l, n) + 3) & ~(size_t)3;
+    return std::max(need, all) * sizeof(float);
+}
+
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
                              const float* dfeat, float* dtable, float* dx01, void* workspace, size_t workspace_bytes,
                              rfx_stream stream) {
@@ -1528,7 +1601,8 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
         if (workspace && (workspace_bytes < rfx_grid_encode_backward_workspace_bytes(n, g->n_levels) || ((uintptr_t)workspace & 7)))
             return RFX_ERR_WORKSPACE;
         int rc = launch_grid_scatter(*g, table, x01, n, dfeat, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
-                                     as_stream(stream));
+                                     as_stream(stream), nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                                     workspace ? workspace_bytes / sizeof(float) : 0);
         if (rc) return rc;
         RFX_LAUNCH_CHECK();
     }
@@ -1791,7 +1865,7 @@ int rfx_field_backward_scatter_merged(const rfx_field_desc* f, const float* x01,
     if (n > 0) ws = carve(workspace, n);
     rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
                              extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n, sel_on(n) ? ws.perm : nullptr,
-                             sel_on(n) ? ws.sel_hdr : nullptr);
+                             sel_on(n) ? ws.sel_hdr : nullptr, nullptr, nullptr, scatter_ws ? scatter_bytes / sizeof(float) : 0);
     if (rc) return rc;
     RFX_LAUNCH_CHECK();
     return RFX_OK;
@@ -1855,7 +1929,8 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
     bool taken = false;
     rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
                              extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n, sel_on(n) ? ws.perm : nullptr,
-                             sel_on(n) ? ws.sel_hdr : nullptr, job.partial ? &job : nullptr, &taken);
+                             sel_on(n) ? ws.sel_hdr : nullptr, job.partial ? &job : nullptr, &taken,
+                             scatter_ws ? scatter_bytes / sizeof(float) : 0);
     if (rc) return rc;
     if (job.partial && !taken) {          // no staging launch on this path: the stand-alone second stage
         hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, as_stream(stream), job.partial,

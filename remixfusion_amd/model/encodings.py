@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -74,7 +76,7 @@ class _GridEncodeFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = None
         if dparams is not None:       # staging buffer of the LDS-privatised scatter
-            nb = int(lib.rfx_grid_encode_backward_workspace_bytes(n, int(module.desc.n_levels)))
+            nb = int(lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(module.desc), n))
             ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
         check(lib.rfx_grid_encode_backward(module.desc, ptr(params), ptr(x), n, ptr(dout), ptr(dparams), ptr(dx),
                                            ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(x.device)),

@@ -28,7 +28,7 @@ class _Buffers:
     iteration shrinks as keyframes accumulate (sample // num_kf current-frame rays) and the camera count grows:
     allocating per shape would hit the allocator (hundreds of MB of workspace) on every mapper step."""
 
-    def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K):
+    def __init__(self, lib, dev, n, S, P, n_feat, n_levels, table, weights, K, grid_desc=None):
         f32 = dict(dtype=torch.float32, device=dev)
         t = self.t = SimpleNamespace()
         self.cap_n, self.cap_K, self._u_views = n, K, {}
@@ -38,7 +38,9 @@ class _Buffers:
         t.tv_acc = torch.empty(1, dtype=torch.float64, device=dev)
         t.dt = torch.empty_like(table)
         t.dw_flat = torch.empty(sum(w.numel() for w in weights), **f32)
-        self.ws_bytes = int(lib.rfx_ba_workspace_bytes(n, S, P, n_feat, n_levels))
+        # with the grid known the scatter's share is sized so that all its binned levels (T >= 2^19) are in flight at once
+        self.ws_bytes = int(lib.rfx_ba_workspace_bytes_for(n, S, P, C.byref(grid_desc)) if grid_desc is not None
+                            else lib.rfx_ba_workspace_bytes(n, S, P, n_feat, n_levels))
         t.ws = torch.empty(self.ws_bytes // 4 + 64, **f32)
         self.dws, off = [], 0
         for w in weights:
@@ -65,8 +67,9 @@ class _StageBuffers:
     """buffers of the stage-by-stage issue (every intermediate is a torch tensor the host can look at): views of one
     arena sized for up to cap_n rays / cap_K cameras, re-bound when the shape of the iteration changes."""
 
-    def __init__(self, lib, dev, cap_n, S, P, n_feat, n_levels, table, weights, cap_K):
+    def __init__(self, lib, dev, cap_n, S, P, n_feat, n_levels, table, weights, cap_K, grid_desc=None):
         self.lib, self.dev, self.cap_n, self.cap_K = lib, dev, cap_n, cap_K
+        self.grid_desc = grid_desc
         self.S, self.P, self.n_feat, self.n_levels = S, P, n_feat, n_levels
         f32 = dict(dtype=torch.float32, device=dev)
         self.arena = torch.empty(sum(-(-fl // 64) * 64 for _, _, _, fl in self._layout(cap_n, cap_K)), **f32)
@@ -88,7 +91,9 @@ class _StageBuffers:
                ("u", (n, S), f), ("z", (n, S), f), ("x01", (n * S, 3), f), ("raw", (n * S, 4), f), ("rgb_map", (n, 3), f),
                ("depth_map", (n,), f), ("sums", (_lib.LOSS_WS_DOUBLES,), f64), ("lc", (8,), f), ("u6", (6,), f), ("pts", (nt, 3), f), ("feat", (nt, F), f),
                ("tv_acc", (1,), f64), ("d_raw", (n * S, 4), f), ("dx", (n * S, 3), f), ("dfeat", (nt, F), f),
-               ("ws2", (int(self.lib.rfx_grid_encode_backward_workspace_bytes(n * S + nt, self.n_levels)) // 4,), f)]
+               ("ws2", (int(self.lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(self.grid_desc), n * S + nt)
+                            if self.grid_desc is not None else
+                            self.lib.rfx_grid_encode_backward_workspace_bytes(n * S + nt, self.n_levels)) // 4,), f)]
         if K:
             lay += [("poses", (K, 4, 4), f), ("acts", (int(self.lib.rfx_rba_acts_floats(K)),), f), ("dposes", (K, 4, 4), f),
                     ("wsr", (int(self.lib.rfx_rba_grads_floats(K)),), f)]
@@ -163,7 +168,7 @@ class DirectIterations:
         if b is None or b.cap_n < n or b.cap_K < K:
             cap_n, cap_K = self._capacity(n, K, b)
             b = self._cache[key] = _Buffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                            self._weights, cap_K)
+                                            self._weights, cap_K, grid_desc=enc.desc)
         b.n = n
         return b
 
@@ -340,7 +345,7 @@ class DirectIterations:
         if B is None or B.cap_n < n or B.cap_K < K:
             cap_n, cap_K = self._capacity(n, K, B)
             B = self._cache[key] = _StageBuffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                                 self._weights, cap_K)
+                                                 self._weights, cap_K, grid_desc=enc.desc)
         B.bind(n, K)
         if self.before_stagewise is not None:
             self.before_stagewise()

@@ -45,7 +45,7 @@ class ShardedIterations(DirectIterations):
         if B is None or B.cap_n < n_loc or B.cap_K < K or B.dt.data_ptr() == 0:
             cap_n, cap_K = self._capacity(n_loc, K, B)
             B = self._loc = _StageBuffers(self.lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                          self._weights, cap_K)
+                                          self._weights, cap_K, grid_desc=enc.desc)
         return B.bind(n_loc, K)
 
     def _run_stagewise(self, current_rays, poses_ptr, K, clamp, want_pose_grads, dev, st, map_grads=True):
@@ -60,7 +60,7 @@ class ShardedIterations(DirectIterations):
         if G is None or G.cap_n < n or G.cap_K < K:
             cap_n, cap_K = self._capacity(n, K, G)
             G = self._cache[key] = _StageBuffers(lib, dev, cap_n, S, P, enc.n_output_dims, int(enc.desc.n_levels), enc.params,
-                                                 self._weights, cap_K)
+                                                 self._weights, cap_K, grid_desc=enc.desc)
         G.bind(n, K)
         self._rays(G, current_rays, poses_ptr, K, st)           # same seeds on every rank: the same n rays
         if self.torch_draws:

@@ -8,6 +8,8 @@ import os
 import random
 from typing import Dict
 
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.optim as optim
@@ -45,7 +47,7 @@ class _SmoothFn(torch.autograd.Function):
         gs = g.reshape(1).to(torch.float32).contiguous()
         check(lib.rfx_tv_backward(ptr(feat), ctx.P, ctx.enc.n_output_dims, 1.0 / ctx.denom, ptr(gs), ptr(dfeat), st), "rfx_tv_backward")
         dt = torch.zeros_like(table)
-        nb = int(lib.rfx_grid_encode_backward_workspace_bytes(x.shape[0], int(ctx.enc.desc.n_levels)))
+        nb = int(lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(ctx.enc.desc), x.shape[0]))
         ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)      # staging of the LDS-privatised scatter
         check(lib.rfx_grid_encode_backward(ctx.enc.desc, ptr(table), ptr(x), x.shape[0], ptr(dfeat), ptr(dt), None,
                                            ptr(ws), ws.numel() * 4, st), "rfx_grid_encode_backward")

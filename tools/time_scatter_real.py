@@ -24,7 +24,9 @@ def run(xx, k, reps=10):
     n = xx.shape[0]
     df = torch.randn((n, 2 * k), device="cuda", generator=g)
     dt = torch.zeros_like(enc.params)
-    ws = torch.empty(int(lib.rfx_grid_encode_backward_workspace_bytes(n, 16)) // 4, device="cuda")
+    import ctypes as C
+    nb = lib.rfx_grid_encode_backward_workspace_bytes(n, 16) if os.environ.get("MIN_WS") else lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(enc.desc), n)
+    ws = torch.empty(int(nb) // 4, device="cuda")
     desc = type(enc.desc).from_buffer_copy(enc.desc); desc.n_levels = k
     call = lambda: lib.rfx_grid_encode_backward(desc, L.ptr(enc.params), L.ptr(xx), n, L.ptr(df), L.ptr(dt), None, L.ptr(ws), ws.numel() * 4, st)
     for _ in range(3): L.check(call(), "b")
