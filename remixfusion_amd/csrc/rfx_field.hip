@@ -597,11 +597,17 @@ struct BinLevels {
     int level[RFX_MAX_LEVELS];               // index of the level in the grid (its column pair in dfeat)
     int n_seg[RFX_MAX_LEVELS];
     int seg_base[RFX_MAX_LEVELS + 1];        // first flattened (level, segment) index of each level
-    unsigned* counts[RFX_MAX_LEVELS];        // [seg][blk]
-    unsigned* offsets[RFX_MAX_LEVELS];       // [seg][blk]
+    unsigned* counts[RFX_MAX_LEVELS];        // [blk][seg]
+    unsigned* offsets[RFX_MAX_LEVELS];       // [blk][seg]
     unsigned* seg_start[RFX_MAX_LEVELS];     // [n_seg + 1]
+    unsigned* chunk_start[RFX_MAX_LEVELS];   // [n_seg + 1]: first BIN_CHUNK-record piece of each segment's bin (see bin_reduce_kernel)
+    int blk_base[RFX_MAX_LEVELS + 1];        // first reduce block of each level (an upper bound of its pieces)
     BinRec* rec[RFX_MAX_LEVELS];
 };
+#ifndef BIN_CHUNK_RECORDS
+#define BIN_CHUNK_RECORDS 32768
+#endif
+constexpr unsigned BIN_CHUNK = BIN_CHUNK_RECORDS;      // records one reduce block adds at most
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(BinLevels B, ScatterSrc a, ScatterSrc b, int n_blk) {
     __shared__ unsigned h[BIN_MAX_SEGS];
@@ -624,31 +630,37 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(BinLevels B, Sca
     }
     __syncthreads();
     unsigned* __restrict__ counts = B.counts[g];
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) counts[(size_t)i * n_blk + blockIdx.x] = h[i];      // [seg][blk]
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) counts[(size_t)blockIdx.x * n_seg + i] = h[i];      // [blk][seg]
 }
 
-// counts / offsets are [seg][blk].  offsets[seg][blk] = start of block blk's range in segment seg's bin; seg_start[seg] =
-// start of the bin (seg_start[n_seg] = total).  One block per level; a wave takes a segment at a time, lanes over the blocks.
+// counts / offsets are [blk][seg].  offsets[blk][seg] = start of block blk's range in segment seg's bin; seg_start[seg] =
+// start of the bin (seg_start[n_seg] = total); chunk_start: the bins cut into pieces for the reduce kernel.  One block per
+// level, one THREAD per segment (n_seg <= 1 024): every pass reads a row of counts per step, coalesced across the threads.
+// (A wave per segment with lanes over the blocks, [seg][blk] layout, took 53 us at T = 2^21: 16 segments per wave in turn.)
 __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(BinLevels B, int n_blk) {
-    __shared__ unsigned tot[BIN_MAX_SEGS + 1];
+    __shared__ unsigned tot[BIN_MAX_SEGS + 1], first[BIN_MAX_SEGS];
     const int g = blockIdx.x;
     const int n_seg = B.n_seg[g];
     const unsigned* __restrict__ counts = B.counts[g];
     unsigned* __restrict__ offsets = B.offsets[g];
     unsigned* __restrict__ seg_start = B.seg_start[g];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_wv = BIN_THREADS / 64;
-    for (int s = wv; s < n_seg; s += n_wv) {
-        unsigned t = 0;
-        for (int b0 = 0; b0 < n_blk; b0 += 64) t += (b0 + lane < n_blk) ? counts[(size_t)s * n_blk + b0 + lane] : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        if (lane == 0) tot[s] = t;
+    unsigned* __restrict__ chunk_start = B.chunk_start[g];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sg = threadIdx.x;
+    unsigned mine = 0;
+    if (sg < n_seg) {
+#pragma unroll 8
+        for (int b = 0; b < n_blk; ++b) mine += counts[(size_t)b * n_seg + sg];
+        tot[sg] = mine;
     }
     __syncthreads();
-    if (wv == 0) {                    // exclusive scan of the segment totals by one wave: a run of consecutive segments per lane
+    if (wv < 2) {       // wave 0: exclusive scan of the segment totals; wave 1: of their piece counts.  A run of segments per lane
         const int per = (n_seg + 63) / 64;
         unsigned run = 0;
-        for (int i = 0; i < per; ++i) run += (lane * per + i < n_seg) ? tot[lane * per + i] : 0u;
+        for (int i = 0; i < per; ++i) {
+            const int sidx = lane * per + i;
+            if (sidx < n_seg) run += wv == 0 ? tot[sidx] : (tot[sidx] + BIN_CHUNK - 1) / BIN_CHUNK;
+        }
         unsigned incl = run;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -656,27 +668,25 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(BinLevels B, int 
             if (lane >= d) incl += v;
         }
         unsigned start = incl - run;
+        unsigned* __restrict__ dst = wv == 0 ? seg_start : chunk_start;
         for (int i = 0; i < per; ++i) {
             const int sidx = lane * per + i;
-            if (sidx < n_seg) { const unsigned v = tot[sidx]; tot[sidx] = start; start += v; }
+            if (sidx < n_seg) {
+                dst[sidx] = start;
+                if (wv == 0) first[sidx] = start;
+                start += wv == 0 ? tot[sidx] : (tot[sidx] + BIN_CHUNK - 1) / BIN_CHUNK;
+            }
         }
-        if (lane == 63) tot[n_seg] = incl;
+        if (lane == 63) dst[n_seg] = incl;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= n_seg; i += BIN_THREADS) seg_start[i] = tot[i];
-    for (int s = wv; s < n_seg; s += n_wv) {
-        unsigned run = tot[s];
-        for (int b0 = 0; b0 < n_blk; b0 += 64) {
-            const bool in = b0 + lane < n_blk;
-            const unsigned v = in ? counts[(size_t)s * n_blk + b0 + lane] : 0u;
-            unsigned incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned u = __shfl_up(incl, d);
-                if (lane >= d) incl += u;
-            }
-            if (in) offsets[(size_t)s * n_blk + b0 + lane] = run + incl - v;
-            run += __shfl(incl, 63);
+    if (sg < n_seg) {
+        unsigned run = first[sg];
+#pragma unroll 8
+        for (int b = 0; b < n_blk; ++b) {
+            const unsigned v = counts[(size_t)b * n_seg + sg];
+            offsets[(size_t)b * n_seg + sg] = run;
+            run += v;
         }
     }
 }
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(BinLevels B, S
     const int n_seg = B.n_seg[g], level = B.level[g];
     const unsigned* __restrict__ offsets = B.offsets[g];
     BinRec* __restrict__ rec = B.rec[g];
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) cur[i] = offsets[(size_t)i * n_blk + blockIdx.x];
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) cur[i] = offsets[(size_t)blockIdx.x * n_seg + i];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < BIN_PPT; ++q) {
@@ -712,34 +722,60 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(BinLevels B, S
     }
 }
 
+#ifdef BIN_PROF          // dev builds only (tools/bin_prof.py): per-block clocks of the last bin_reduce launch: start, zeroed, added, end
+__device__ unsigned long long g_bin_prof[4 * 4096];
+#define BIN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_bin_prof[4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define BIN_STAMP(k) do { } while (0)
+#endif
+
+// One block adds one PIECE of a segment's bin (at most BIN_CHUNK records) into 128 KB of LDS and adds the non-zero sums to the
+// table.  Pieces, not segments: on a dense level a segment is a slab of space, and a scene fills a few of them (one block per
+// segment took 230 us on the fullest while the rest were done in 20); the scan kernel cut every bin into pieces and left
+// their prefix in chunk_start.  The grid holds an upper bound of pieces per level (n_seg + records / BIN_CHUNK); the blocks
+// behind the last piece leave at once.
 __global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     double* acc = reinterpret_cast<double*>(acc_raw);
+    __shared__ int seg_s;
+    BIN_STAMP(0);
     int g = 0;
-    while (g + 1 < B.n && (int)blockIdx.x >= B.seg_base[g + 1]) ++g;
+    while (g + 1 < B.n && (int)blockIdx.x >= B.blk_base[g + 1]) ++g;
     const Level lv = B.lv[g];
+    const int n_seg = B.n_seg[g];
+    const unsigned* __restrict__ chunk_start = B.chunk_start[g];
+    const unsigned piece = blockIdx.x - (unsigned)B.blk_base[g];
+    if (piece >= chunk_start[n_seg]) return;                // block-uniform
+    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS)
+        if (chunk_start[i] <= piece && piece < chunk_start[i + 1]) seg_s = i;      // exactly one i (empty segments have no piece)
+    __syncthreads();
+    const unsigned seg = (unsigned)seg_s, base = seg << BIN_SEG_SHIFT;
+    const unsigned cnt = min(BIN_SEG, lv.size - base);
     const unsigned* __restrict__ seg_start = B.seg_start[g];
     const BinRec* __restrict__ rec = B.rec[g];
-    const unsigned seg = blockIdx.x - (unsigned)B.seg_base[g], base = seg << BIN_SEG_SHIFT;
-    const unsigned cnt = min(BIN_SEG, lv.size - base);
-    // gridDim.y blocks share a segment's bin (a level has 64-256 segments: one block each would leave most CUs idle)
-    const unsigned s0 = seg_start[seg], s1 = seg_start[seg + 1];
-    const unsigned per = (s1 - s0 + gridDim.y - 1) / gridDim.y;
-    const unsigned r0 = min(s1, s0 + blockIdx.y * per), r1 = min(s1, r0 + per);
-    if (r0 == r1) return;                                   // block-uniform
+    // the segment's pieces are equally long (ceil(records / pieces)), not BIN_CHUNK and a remainder
+    const unsigned s0 = seg_start[seg], s1 = seg_start[seg + 1], n_pc = chunk_start[seg + 1] - chunk_start[seg];
+    const unsigned len = (s1 - s0 + n_pc - 1) / n_pc;
+    const unsigned r0 = min(s1, s0 + (piece - chunk_start[seg]) * len), r1 = min(s1, r0 + len);
     for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) acc[i] = 0.0;
     __syncthreads();
+    BIN_STAMP(1);
     for (unsigned r = r0 + threadIdx.x; r < r1; r += BIN_THREADS) {
         const BinRec q = rec[r];
         atomicAdd(&acc[2 * q.slot], (double)q.a);
         atomicAdd(&acc[2 * q.slot + 1], (double)q.b);
     }
     __syncthreads();
+    BIN_STAMP(2);
     float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
     for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) {
         const float v = (float)acc[i];
         if (v != 0.f) atomicAdd(out + i, v);                // contiguous float atomics: the memory side's fast path
     }
+#ifdef BIN_PROF
+    __syncthreads();
+#endif
+    BIN_STAMP(3);
 }
 
 static bool level_is_binned(const rfx_grid_desc& g, int l) {
@@ -751,7 +787,7 @@ static bool level_is_binned(const rfx_grid_desc& g, int l) {
 static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) {
     const size_t n_seg = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
     const size_t n_blk = (size_t)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
-    return (size_t)n_all * 8 * 3 + 2 * n_blk * n_seg + n_seg + 1 + 4;      // (+4: keeps the next level's records 16-byte aligned)
+    return (size_t)n_all * 8 * 3 + 2 * n_blk * n_seg + 2 * (n_seg + 1) + 4;      // (+4: keeps the next level's records 16-byte aligned)
 }
 
 // the binned levels `levels[0..n_lv)` through the four kernels above, as many levels per group of launches as the scratch
@@ -784,23 +820,25 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
             const int k = B.n++;
             B.lv[k].scale = g.scale[l]; B.lv[k].res = g.res[l]; B.lv[k].size = g.size[l]; B.lv[k].offset = g.offset[l]; B.lv[k].hashed = g.hashed[l];
             B.level[k] = l; B.n_seg[k] = n_seg; B.seg_base[k + 1] = B.seg_base[k] + n_seg;
+            if (k == 0) B.blk_base[0] = 0;
+            B.blk_base[k + 1] = B.blk_base[k] + n_seg + (int)(((size_t)n_all * 8 + BIN_CHUNK - 1) / BIN_CHUNK);      // >= its pieces
             float* base = scratch + used;
             B.rec[k] = reinterpret_cast<BinRec*>(base);
             B.counts[k] = reinterpret_cast<unsigned*>(base + rec_floats);
             B.offsets[k] = B.counts[k] + cnt_words;
             B.seg_start[k] = B.offsets[k] + cnt_words;
+            B.chunk_start[k] = B.seg_start[k] + n_seg + 1;
             used += need;
             ++i;
         }
         if (debug) fprintf(stderr, "[bins] group of %d levels (%d of %d done), %zu of %zu floats, %lld points\n", B.n, i, n_lv, used, scratch_floats, (long long)n_all);
         if (B.n == 0) return RFX_ERR_WORKSPACE;
         for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.seg_base[k] = B.seg_base[B.n];
-        const int total_seg = B.seg_base[B.n];
         hipLaunchKernelGGL(bin_count_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
         hipLaunchKernelGGL(bin_scan_kernel, dim3(B.n), dim3(BIN_THREADS), 0, st, B, n_blk);
         hipLaunchKernelGGL(bin_records_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
-        const int split = std::max(1, std::min(8, 512 / std::max(1, total_seg)));
-        hipLaunchKernelGGL(bin_reduce_kernel, dim3(total_seg, split), dim3(BIN_THREADS), lds, st, B, dtable);
+        for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.blk_base[k] = B.blk_base[B.n];
+        hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable);
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;
@@ -1612,6 +1650,12 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
     }
     return RFX_OK;
 }
+
+#ifdef BIN_PROF
+extern "C" int rfx_debug_bin_prof(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_prof), sizeof(unsigned long long) * (size_t)std::min(n, 4 * 4096)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 #ifdef SCATTER_PROF
 extern "C" int rfx_debug_scatter_prof(unsigned long long* out, int n) {

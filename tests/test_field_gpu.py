@@ -252,6 +252,42 @@ def test_grid_encode_backward_standalone(name, n):
     _grad_close(xg.grad, xo.grad, xq.grad, "dx", k=8.0)
 
 
+@pytest.mark.parametrize("name", ["scene0000", "cafeteria"])
+def test_binned_scatter_is_the_same_one_level_or_all_levels_at_a_time(name):
+    """T >= 2^19: the binned levels go through their four kernels in groups as large as the workspace allows --
+    rfx_grid_encode_backward_workspace_bytes (the minimum): one level per group; ..._workspace_bytes_for(grid): all at once.
+    Both against the oracle per element, and against each other to the order of the final float atomics."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    n = 9000
+    cfg, m = _model(name, gbv_fill=False)
+    fp = _oracle_params(cfg, m)
+    enc = m.embed_res_fn
+    x = _points(n, seed=5, lo=0.0, hi=1.0)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn((n, 32), generator=g)
+    fp.hash_table.requires_grad_(True)
+    FO.grid_encode(x.clone(), fp.hash_table, fp.hash_meta).backward(dy)
+    t64 = fp.hash_table.detach().double().requires_grad_(True)
+    FO.grid_encode(x.clone(), t64, fp.hash_meta).backward(dy.double())
+    small = int(lib.rfx_grid_encode_backward_workspace_bytes(n, 16))
+    big = int(lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(enc.desc), n))
+    assert big > 4 * small                              # several binned levels
+    xg, dyg = x.cuda().contiguous(), dy.cuda().contiguous()
+    got = []
+    for nb in (small, big, (small + big) // 2 // 16 * 16):
+        ws = torch.empty(nb // 4, device="cuda")
+        dt = torch.zeros_like(enc.params)
+        L.check(lib.rfx_grid_encode_backward(enc.desc, L.ptr(enc.params), L.ptr(xg), n, L.ptr(dyg), L.ptr(dt), None, L.ptr(ws), nb,
+                                             L.stream_ptr(xg.device)), "rfx_grid_encode_backward")
+        torch.cuda.synchronize()
+        _grad_close(dt.view_as(enc.params), fp.hash_table.grad, t64.grad, f"dtable ({nb} B of workspace)", _level_groups(fp.hash_meta))
+        got.append(dt)
+    for other in got[1:]:
+        assert float((got[0] - other).abs().max()) <= 1e-5 * float(got[0].abs().max())
+
+
 def _rays(n, cfg, seed=0):
     g = torch.Generator().manual_seed(seed)
     o = torch.tensor([0.1, -0.6, 0.2]) + 0.05 * torch.randn((n, 3), generator=g)
