@@ -536,7 +536,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 // ---------------------------------------------------------------- E1 backward, binned scatter (large tables)
 // A level cut into many LDS segments makes every segment's block scan every point for the few corners that land in it:
 // 32-256 scans of the point list per level at T = 2^19-2^21.  Such a level (>= SCATTER_BIN_MIN_SEGMENTS segments) is
-// instead sorted by segment first, one level at a time:
+// instead sorted by segment first (the levels in groups, see BinLevels):
 //   bin_count   : per block of 1 024 points, an LDS histogram of the segments its 8 x points corners fall into
 //   bin_scan    : exclusive offsets per (segment, block): every block gets a range of its own inside every segment's bin
 //   bin_records : the same walk again; each corner becomes a 12-byte record (slot in segment, w*g0, w*g1) at the next
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 //                 non-zero sums to the table with contiguous float atomics.
 // Records of one level take 96 B per point: they re-use the staging buffer the LDS sweep of the small levels is done with.
 #ifndef SCATTER_BIN_MIN_SEGMENTS
-#define SCATTER_BIN_MIN_SEGMENTS 16
+#define SCATTER_BIN_MIN_SEGMENTS 12      // with grouped launches: 12 against 16 = -5 % at scene0000 (its 15-segment level), 10 and 8 no better
 #endif
 #ifndef SCATTER_BIN_MAX_SEGMENTS
 #define SCATTER_BIN_MAX_SEGMENTS 1024
