@@ -119,11 +119,12 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     // everything behind the minimum belongs to the scatter (its region is the last): more binned levels per group of launches
     const size_t min_total = rfx_ba_workspace_bytes(n, S, P, L * F, L);
     const size_t min_scat = rfx_grid_encode_backward_workspace_bytes(n * S + (int64_t)P * P * P, L);
-    const BaWs w = carve_ba(workspace, n, S, P, L * F, L, min_scat + (workspace_bytes - min_total));
+    const BaWs w = carve_ba(workspace, n, S, P, L * F, L, min_scat + ((workspace_bytes - min_total) & ~(size_t)255));     // (whole 256-B units)
     hipStream_t st = as_stream(stream);
     const int64_t nS = n * S, nt = (int64_t)P * P * P;
     // ---- ray batch (rays, S1, points); beside it in the same launch: decoder weights -> MFMA operand image (the optimizers
-    //      update the weights in place between calls) the TV lattice with its table lookups and the zero-fill of the hash gradient, which depend on nothing computed here
+    //      update the weights in place between calls), the TV lattice with its table lookups and the zero-fill of the hash gradient:
+    //      none of them depends on anything computed here
     const bool tv_on = map_grads || b->tv_sum;
     if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
     const float trunc_loss = b->trunc * b->sc_factor;
