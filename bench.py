@@ -13,10 +13,14 @@ Workload at N=1: BASELINE config 2 (office0 bound, 640x480, 800x800x600 voxels @
 At N>1 the workload is ONE scene mapped by the N GPUs together (north_star: the scene volume partitioned spatially over the
 GPUs of one node) -- BASELINE config 4 (cafeteria: 1280x720, 700x700x300 voxels @ 2 cm, hash 2^21) at N = 2 and 4, config 5
 (apartment: 720x480, 1600x1600x600 voxels @ 1 cm, S = 117, a marching-cubes mesh per keyframe) at N = 8: the moving volume cut
-into x-slabs that all integrate the frame rank 0 broadcasts, the field replicated, each rank rendering a share of every ray
-batch, loss sums and gradients all-reduced over RCCL (remixfusion_amd/dist.py, mp_slam/sharded.py).  `value` = frames/s of
-that one camera stream (strong scaling: the scene does not grow with N).  `--rooms` adds, as a side field, the round-1
-figure of N independent rooms (one spatial partition of an N-times larger scene per GPU).
+into x-slabs that all integrate the frame rank 0 broadcasts, the hash table partitioned by LEVEL (each rank looks up,
+scatters into and steps its own levels for every sample point; per-point feature rows travel, all-to-all over RCCL, never
+the table), each rank running the decoder on a share of every ray batch (remixfusion_amd/dist.py, mp_slam/sharded.py).
+`value` = frames/s of that one camera stream (strong scaling: the scene does not grow with N).  Because the scene differs
+from the N = 1 line's, the N > 1 line carries `n1_same_workload`: the SAME scene, stream and schedule on one GPU, measured in
+the same process right after the sharded run (every rank maps it alone on its own GPU; rank 0's figure is printed) -- the
+number a scaling efficiency has to be formed against -- and `exchange`: the bytes a rank receives per iteration.  `--rooms`
+adds, as a side field, the round-1 figure of N independent rooms (one spatial partition of an N-times larger scene per GPU).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream) and `cpu_baseline` (the C / torch CPU oracle timed on this host's cores).
@@ -63,6 +67,9 @@ def parse():
     ap.add_argument("--rooms", action="store_true", help="N>1: also time N independent rooms (one per GPU), reported as a side field")
     ap.add_argument("--one-scene-timeout", type=float, default=900.0, help="N>1: seconds the sharded run may take before the watchdog ends it")
     ap.add_argument("--sharded-config", default=None, help="N>1: synthetic config of the ONE scene (default: cafeteria, apartment at N >= 8)")
+    ap.add_argument("--shard-field", default="auto", choices=("auto", "levels", "replicas"),
+                    help="N>1: hash table partitioned by level (per-point rows exchanged) or replicated (dense gradient all-reduced)")
+    ap.add_argument("--no-n1", action="store_true", help="N>1: skip the one-GPU run of the same scene (n1_same_workload)")
     ap.add_argument("--no-mv-stream", action="store_true", help="V1 on the mapper's stream instead of a stream of its own (A/B)")
     ap.add_argument("--stagewise-every", type=int, default=-1,
                     help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
@@ -233,10 +240,78 @@ def wrap_entry_points(timer, lib):
     timer.wrap(lib, "rfx_field_forward_stash", "rfx_field_forward")
     for name in ("rfx_field_backward_chain", "rfx_field_backward_chain_inputs", "rfx_field_backward_chain_weights"):
         timer.wrap(lib, name + "_stashed", name)
+    for name in ("rfx_ba_shard_lookup", "rfx_ba_shard_render", "rfx_ba_shard_scatter", "rfx_ba_shard_pose"):      # N > 1, table partitioned by level
+        timer.wrap(lib, name)
+
+
+def shard_rooflines(summ, exchange, k_own, n_lattice):
+    """rooflines of the level-partitioned iteration's phases on rank 0 (HIP events around the library calls): the render phase
+    (decoder forward + backward chain + weight gradients of the own rays: 3 x 10 624 FLOP per point) against the
+    fp32 MFMA peak, the scatter phase (own levels, all points + lattice: 12 B + per level 8 B of gradient read and 8 corners x
+    8 B scattered) against HBM"""
+    out = {}
+    pts_all = exchange["points_per_iteration"]
+    if "rfx_ba_shard_render" in summ and exchange.get("rays_own"):
+        cnt, ms, _ = summ["rfx_ba_shard_render"]
+        pts = exchange["rays_own"] * (pts_all // exchange["rays_per_iteration"])
+        ach = 3 * MLP_FLOP_PER_POINT * pts / (ms * 1e-3) / 1e12
+        out["shard_render"] = {"kernel": "rfx_ba_shard_render (stash_put, field_forward<.,2>, composite_loss_grad, field_backward, field_dw_recompute, demb_rows)",
+                               "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "points_per_launch": int(pts), "avg_ms": round(ms, 4),
+                               "note": "map and pose iterations mixed (the pose phase runs no weight gradients)"}
+    if "rfx_ba_shard_scatter" in summ:
+        cnt, ms, _ = summ["rfx_ba_shard_scatter"]
+        pts = pts_all + n_lattice
+        nbytes = pts * (12 + k_own * (8 + 64))
+        ach = nbytes / (ms * 1e-3) / 1e9
+        out["shard_scatter"] = {"kernel": f"rfx_ba_shard_scatter ({k_own} own levels: scatter_stage + grid_scatter_lds / bin_* kernels; pose phase: grid_encode_dx_lp)",
+                                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                "traffic": None, "points_per_launch": int(pts), "avg_ms": round(ms, 4)}
+    return out
 
 
 def sharded_workload(args, world):
     return args.sharded_config or ("apartment" if world >= 8 else "cafeteria")
+
+
+def metric_name(cfg):
+    cam, v = cfg["cam"], cfg["volume"]
+    return f"RGB-D frames/sec mapping ({cam['W']}x{cam['H']}, {v['voxel_size'] * 100:g}cm TSDF)"
+
+
+def sharded_cfg(args, world):
+    from remixfusion_amd.config import synthetic_config
+    cfg = synthetic_config(sharded_workload(args, world))
+    if args.first_iters is not None:
+        cfg["mapping"]["first_iters"] = args.first_iters
+    cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
+    cfg["mapping"]["shard_field"] = args.shard_field
+    if args.pos_fp16:
+        cfg["pos"]["fp16_opt_in"] = True
+    cfg["data"]["output"] = os.path.join(ROOT, "gpurun_out", "bench_meshes")      # config 5 writes a mesh per keyframe
+    return cfg
+
+
+def run_same_scene_alone(args, world, device):
+    """the N > 1 line's scene, stream, schedule and step counts on ONE GPU (MappingPipeline, no process group): what the
+    one-scene figure has to be compared with.  Every rank runs it on its own GPU at the same time (no rank waits for another
+    inside a collective meanwhile); no collective is issued in here."""
+    from remixfusion_amd.pipeline import MappingPipeline
+    cfg = sharded_cfg(args, world)
+    n_frames = 1 + args.warmup + args.steps
+    pipe = MappingPipeline(cfg, device=device, n_frames=n_frames + 8, seed=0)
+    frames = pipe.prefetch(list(range(n_frames)))
+    pipe.start(frames[0])
+    for i in range(1, 1 + args.warmup):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1 + args.warmup, n_frames):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    del pipe, frames
+    return el
 
 
 def run_one_scene(args, dist, rank, world, device, timer):
@@ -244,16 +319,9 @@ def run_one_scene(args, dist, rank, world, device, timer):
     x-slabs, every rank integrating the frame rank 0 broadcast; keyframes integrated into every replica of the global
     volume; each BA iteration's ray batch shared out, loss sums and gradients all-reduced.  Barrier +
     torch.cuda.synchronize() on both sides of the timed region, elapsed = max over ranks."""
-    from remixfusion_amd.config import synthetic_config
-    from remixfusion_amd.dist import ShardedPipeline, broadcast_
+    from remixfusion_amd.dist import ShardedPipeline, broadcast_, field_exchange_model
     name = sharded_workload(args, world)
-    cfg = synthetic_config(name)
-    if args.first_iters is not None:
-        cfg["mapping"]["first_iters"] = args.first_iters
-    cfg["mapping"]["unused_gradients"] = bool(args.unused_gradients)
-    if args.pos_fp16:
-        cfg["pos"]["fp16_opt_in"] = True
-    cfg["data"]["output"] = os.path.join(ROOT, "gpurun_out", "bench_meshes")      # config 5 writes a mesh per keyframe
+    cfg = sharded_cfg(args, world)
     n_frames = 1 + args.warmup + args.steps
     pipe = ShardedPipeline(cfg, dist, rank, world, device=device, n_frames=n_frames + 8, seed=0)
     frames = pipe.prefetch(list(range(n_frames)))            # rank 0 renders, the others receive (resident before timing)
@@ -288,19 +356,37 @@ def run_one_scene(args, dist, rank, world, device, timer):
     S = tr["n_range_d"] + tr["n_samples_d"]
     hash_mb = int(pipe.model.embed_res_fn.params.numel() * 4 / 1e6 * 10) / 10
     meshes = "" if cfg["mesh"]["only_final"] else f", a marching-cubes mesh every {cfg['mesh']['vis']} frames (rank 0)"
+    levels = type(direct).__name__ == "LevelShardedIterations"
+    n_rays = direct._n_rays()
+    P3 = (int(tr["smooth_pts"]) - 1) ** 3
+    model = field_exchange_model(pipe.model.embed_res_fn.desc, n_rays * S, P3, world)
     info = {"workload": f"{name} (BASELINE config {'5' if name == 'apartment' else '4' if name == 'cafeteria' else '?'}), ONE scene on "
                         f"{world} GPUs: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume {'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ "
-                        f"{cfg['volume']['voxel_size']} m in {world} x-slabs of {x1 - x0} planes, GBV 200^3 + hash 2^{cfg['grid']['hash_size']} "
-                        f"x16 levels replicated, {S} samples/ray, {m['iters']} map + {m['BA_iters']} pose iters every {m['map_every']} frames"
-                        + meshes,
-            "partition": "every rank integrates the frame rank 0 broadcasts into its x-slab (no voxel exchange; point-to-point plane "
-                         "exchange when the volume follows the camera); each rank renders rays r, r + N, ... of every batch; loss sums "
-                         "(64 B) and gradients all-reduced, identical Adam step on every replica",
-            "collectives_per_frame": f"broadcast 16*H*W B (depth + rgb); per BA iteration all-reduce 64 B + gradients ({hash_mb} MB hash "
-                                     "table, 21 KB decoder)",
+                        f"{cfg['volume']['voxel_size']} m in {world} x-slabs of {x1 - x0} planes, GBV 200^3 replicated, hash 2^{cfg['grid']['hash_size']} "
+                        f"x16 levels ({hash_mb} MB) " + (f"partitioned by level {model['level_cuts']}" if levels else "replicated")
+                        + f", {S} samples/ray, {m['iters']} map + {m['BA_iters']} pose iters every {m['map_every']} frames" + meshes,
+            "partition": ("every rank integrates the frame rank 0 broadcasts into its x-slab (no voxel exchange; point-to-point plane "
+                          "exchange when the volume follows the camera); "
+                          + ("rank q keeps a contiguous range of the hash levels: it looks them up for all points of a batch, receives their "
+                             "gradient rows, scatters and takes their Adam step; each rank runs the decoder on a contiguous share of the rays"
+                             if levels else "each rank renders rays r, r + N, ... of every batch; loss sums (64 B) and gradients "
+                             "all-reduced, identical Adam step on every replica")),
+            "collectives_per_frame": "broadcast 16*H*W B (depth + rgb); per BA iteration "
+                                     + ("2 all-to-alls of per-point rows (8 B per point and level) + all-reduce of 21 KB decoder gradients and "
+                                        "64 B loss sums; pose iterations: + all-to-all of 12 B per point and all-reduce of the pose gradients"
+                                        if levels else f"all-reduce 64 B + gradients ({hash_mb} MB hash table, 21 KB decoder)"),
             "backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (rehearsal: device tensors staged through the host)"),
             "unused_gradients": bool(args.unused_gradients), "pos_fp16_opt_in": bool(args.pos_fp16)}
-    return elapsed, iters, cfg, info
+    exchange = {"field": "levels" if levels else "replicas", "rays_per_iteration": n_rays, "points_per_iteration": n_rays * S,
+                "recv_bytes_per_iteration_model": {k: int(model[k]["recv_bytes"]) for k in ("replicas", "points", "levels")},
+                "scatter_share_of_one_gpu_model": {k: round(model[k]["scatter_share"], 3) for k in ("replicas", "points", "levels")}}
+    if levels:
+        exchange["rays_own"], exchange["k_own"], exchange["n_lattice"] = direct.last_exchange.get("rays_own"), direct.k_own, P3
+        exchange["recv_bytes_last_iteration_rank0"] = direct.last_exchange.get("recv_bytes")
+        its = max(1, direct.iterations["map"] + direct.iterations["pose"])
+        exchange["recv_bytes_per_iteration_rank0_mean"] = int(direct.exchanged_bytes / its)
+    del pipe, frames
+    return elapsed, iters, cfg, info, exchange
 
 
 def run_rooms(args, dist, rank, world, device):
@@ -338,7 +424,11 @@ def main_sharded(args, dist, rank, world, device):
     import threading
     from remixfusion_amd import _lib
     done = threading.Event()
-    base = {"metric": "RGB-D frames/sec mapping (640x480, 1cm TSDF)", "value": None, "unit": "frames/s", "n_gpus": world,
+    try:
+        metric = metric_name(sharded_cfg(args, world))
+    except Exception:                   # an unknown configuration is reported below, by the run itself
+        metric = "RGB-D frames/sec mapping"
+    base = {"metric": metric, "value": None, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": {"workload": sharded_workload(args, world)}}
 
@@ -360,7 +450,21 @@ def main_sharded(args, dist, rank, world, device):
         timer = KernelTimer()
         wrap_entry_points(timer, lib)
         timer.every = 4
-        elapsed, iters, cfg, info = run_one_scene(args, dist, rank, world, device, timer)
+        elapsed, iters, cfg, info, exchange = run_one_scene(args, dist, rank, world, device, timer)
+        n1 = None
+        if not args.no_n1:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            alone = run_same_scene_alone(args, world, device)              # symmetric: every rank, no collective inside
+            ta = torch.tensor([alone, -alone], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            n1 = {"value": round(args.steps / alone, 2), "unit": "frames/s", "ms_per_step": round(alone / args.steps * 1e3, 3),
+                  "n_gpus": 1, "slowest_rank_value": round(args.steps / float(ta[0].item()), 2),
+                  "fastest_rank_value": round(args.steps / -float(ta[1].item()), 2),
+                  "what": "the same scene, stream, schedule, --steps and --warmup on ONE GPU (MappingPipeline), measured by every rank "
+                          "on its own GPU right after the sharded run; value = rank 0's"
+                          + ("; REHEARSAL: the ranks share one GPU here, so these runs contended with each other" if dist.get_backend() != "nccl" else "")}
         rooms = run_rooms(args, dist, rank, world, device) if args.rooms else None
     except Exception as e:          # noqa: BLE001 -- reported, then a non-zero exit
         import traceback
@@ -372,13 +476,16 @@ def main_sharded(args, dist, rank, world, device):
         per_kernel = {k: {"calls_timed": c, "avg_ms": round(ms, 4), "median_ms": round(timer.spread[k][0], 4), "max_ms": round(timer.spread[k][1], 4),
                           "outliers_dropped": timer.spread[k][2]} for k, (c, ms, _) in summ.items()}
         rl = field_rooflines(summ, cfg)
+        if exchange.get("field") == "levels":
+            rl.update(shard_rooflines(summ, exchange, exchange["k_own"], exchange["n_lattice"]))
         # dominant entry point of rank 0's share by summed device time (every 4th call was timed)
         step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
         dominant = max(step_kernels, key=lambda k: step_kernels[k][0] * step_kernels[k][1]) if step_kernels else None
         key = {"rfx_field_forward": "field_forward", "rfx_field_backward_chain": "field_backward_chain",
                "rfx_field_backward_chain_weights": "field_backward_chain", "rfx_field_backward_chain_inputs": "field_backward_chain",
                "rfx_field_backward_weights": "field_backward_weights", "rfx_field_backward_scatter": "field_backward_scatter",
-               "rfx_field_backward_scatter_merged": "field_backward_scatter"}.get(dominant)
+               "rfx_field_backward_scatter_merged": "field_backward_scatter", "rfx_ba_shard_render": "shard_render",
+               "rfx_ba_shard_scatter": "shard_scatter"}.get(dominant)
         roofline = rl.get(key) if key else None
         if roofline is None and rl:
             roofline = max(rl.values(), key=lambda r: r["avg_ms"])
@@ -386,7 +493,8 @@ def main_sharded(args, dist, rank, world, device):
         out.update({"value": round(args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                     "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32",
                     "config": info, "roofline": roofline, "rooflines": rl, "kernels": per_kernel, "dominant_call": dominant,
-                    "iterations_timed": iters, "cpu_baseline": None,
+                    "iterations_timed": iters, "cpu_baseline": None, "n1_same_workload": n1, "exchange": exchange,
+                    "speedup_vs_n1_same_workload": round((args.steps / elapsed) / n1["value"], 3) if n1 else None,
                     "note": "rooflines are rank 0's share of each launch (1/N of the batch); cpu_baseline is reported at N = 1 only"})
         if rooms is not None:
             out["independent_rooms"] = rooms

@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 5
+#define RFX_ABI_VERSION 6
 
 typedef void* rfx_stream;
 
@@ -289,6 +289,40 @@ int rfx_field_backward_scatter_merged(const rfx_field_desc* f, const float* x01,
 int rfx_field_backward_dx(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dx01,
                           void* workspace, size_t workspace_bytes, rfx_stream stream);
 
+/* ---- a hash table partitioned by LEVEL over several GPUs (ABI 6) -------------------------------------------------
+ * One scene on N GPUs (the reference is single-GPU, mp_slam/mapper.py:392-423 is the iteration whose result
+ * is reproduced): rank q keeps -- looks up, accumulates gradients for, steps -- the hash levels [l_q, l_{q+1}) only, for
+ * EVERY sample point of the iteration, and each rank runs the decoder on its share of the rays.  What travels between the
+ * ranks is per-point rows (8 B per point and level, twice per iteration: features out, feature gradients back) instead of
+ * the dense table gradient (6.6 ... 166 MB).  The four entry points below are the pieces that differ from the
+ * single-GPU path; everything else is the public stages above, given a sub-grid descriptor (rfx_grid_desc with
+ * n_levels = the own levels and their true offsets into the full table). */
+typedef struct rfx_level_rows {          /* where the two features of hash level l of point p live:            */
+    const float* rows[RFX_MAX_LEVELS];  /*   rows[l][p * ld[l] + col[l] + {0, 1}]   (dev, 8-byte aligned;       */
+    int32_t      ld[RFX_MAX_LEVELS];    /*   ld, col even) -- e.g. one row-major block [points, 2 k_q] per       */
+    int32_t      col[RFX_MAX_LEVELS];   /*   owning rank q, col = 2 (l - l_q)                                    */
+} rfx_level_rows;
+/* rows -> the forward's stash inside `workspace` (rfx_field_backward_workspace_bytes(n)): what rfx_field_forward_stash
+ * would have left there had it looked all 16 levels up itself. */
+int rfx_field_stash_put(const rfx_level_rows* rows, int64_t n, void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* rfx_field_forward for points whose hash features are in the stash (rfx_field_stash_put, or an earlier
+ * rfx_field_forward_stash on the same points): the hash table is not read.  Bit-identical to rfx_field_forward on the
+ * features' table.  The _stashed chain stages follow it as they follow rfx_field_forward_stash. */
+int rfx_field_forward_stashed(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, void* workspace,
+                              size_t workspace_bytes, rfx_stream stream);
+/* After a chain stage on n points: its d_emb rows (gradient w.r.t. the 32 hash features) written back as level rows
+ * (the pointers are written through), in the caller's point order, zeros for the points the selection dropped.
+ * Optionally (loss_partials != NULL) the same launch adds n_loss_partials x 8 doubles of per-block loss sums up to
+ * loss_total8 dev double[8], the quantity rfx_mapping_loss_finalize takes after the ranks have summed it. */
+int rfx_field_backward_demb_rows(int64_t n, const rfx_level_rows* rows, const double* loss_partials, int n_loss_partials,
+                                 double* loss_total8, void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* rfx_grid_encode_backward's table gradient for TWO point sets in one sweep (e.g. the sample points with the gradient
+ * rows received from the rendering ranks, and the TV lattice with its own): dtable += scatter(a) + scatter(b).
+ * workspace (optional): >= rfx_grid_encode_backward_workspace_bytes(n_a + n_b, g->n_levels). */
+int rfx_grid_encode_backward_merged(const rfx_grid_desc* g, const float* table, const float* x01_a, int64_t n_a,
+                                    const float* dfeat_a, const float* x01_b, int64_t n_b, const float* dfeat_b, float* dtable,
+                                    void* workspace, size_t workspace_bytes, rfx_stream stream);
+
 /* Q2 point queries (model/scene_rep.py:212-310).  out dev [n] or [n,3] as documented. */
 int rfx_field_query_sdf(const rfx_field_desc* f, const float* x01, int64_t n, float* sdf, rfx_stream stream);          /* query_sdf_res      */
 int rfx_field_query_color(const rfx_field_desc* f, const float* x01, int64_t n, float* rgb3, rfx_stream stream);       /* query_color_residual */
@@ -533,6 +567,43 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
  * Returns the number of offsets written (<= count), or RFX_ERR_ARG. */
 #define RFX_BA_LAYOUT_FIELDS 15
 int rfx_ba_workspace_layout(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels, size_t* offsets, int count);
+
+/* ---- the same iteration with the hash table partitioned by level over `world` GPUs (ABI 6) ----------------------------
+ * Every rank fills the same rfx_ba_desc (same seeds: the same ray batch and lattice on every rank; field.hash describes
+ * the FULL grid, field.hash_table / d_hash are full-size buffers of which only the own levels' part is read / written) and
+ * calls the phases in turn; between them the caller moves the exchange buffers with its collective library
+ * (torch.distributed: RCCL over xGMI):
+ *   rfx_ba_shard_lookup   ray batch of all n rays (+ TV lattice and its own-level features, zero-fill of the own part of
+ *                         d_hash), own levels' features of all n*S points -> feat_send [n*S, 2k]
+ *      all-to-all: rank q's rays' rows of feat_send -> q's feat_recv
+ *   rfx_ba_shard_render   stash <- feat_recv; decoder forward, compositing, losses and their gradient, backward chain and
+ *                         weight gradients on the OWN rays -> demb_send, d_w (partial), loss_sums8 (partial)
+ *      all-to-all: demb_send block q -> q's demb_recv;  all-reduce: d_w, loss_sums8
+ *   rfx_ba_shard_scatter  map gradients: own levels' table gradient from demb_recv (all points) + the TV term of the own
+ *                         levels -> d_hash;  pose phase: d loss / d x01 through the own levels, all points -> dx_send
+ *      all-to-all (pose phase): rank q's rows of dx_send -> q's dx_recv[rank]
+ *   rfx_ba_shard_pose     (pose phase) sums dx_recv over the ranks, adds the OneBlob / GBV part, reduces to ray and pose
+ *                         gradients of the own rays -> d_poses16 (partial: all-reduce, then rfx_rba_backward)
+ * The loss coefficients need no exchange: they are made of counts over target and sample depths (rfx_ba_forward_backward),
+ * which every rank has for the whole batch.  Results equal the single-GPU iteration's up to the order of the sums. */
+typedef struct rfx_ba_shard {
+    int32_t      rank, world;                          /* 1 <= world <= RFX_MAX_LEVELS                                  */
+    int32_t      level_start[RFX_MAX_LEVELS + 1];      /* rank q owns hash levels [level_start[q], level_start[q+1])    */
+    int64_t      ray_start[RFX_MAX_LEVELS + 1];        /* rank q renders rays [ray_start[q], ray_start[q+1]) of the n   */
+    float*       feat_send;                            /* dev [n*S, 2k]: k = own levels                                 */
+    const float* feat_recv;                            /* dev: for q = 0..world-1 in turn [n_own*S, 2k_q]               */
+    float*       demb_send;                            /* dev: for q = 0..world-1 in turn [n_own*S, 2k_q]               */
+    const float* demb_recv;                            /* dev [n*S, 2k]                                                 */
+    double*      loss_sums8;                           /* dev double[8]: the own rays' loss sums                        */
+    float*       dx_send;                              /* dev [n*S, 3] (pose phase)                                     */
+    const float* dx_recv;                              /* dev [world, n_own*S, 3] (pose phase)                          */
+} rfx_ba_shard;
+size_t rfx_ba_shard_bytes(void);        /* sizeof(rfx_ba_shard), for foreign bindings */
+/* workspace for all four: the one rfx_ba_forward_backward takes (rfx_ba_workspace_bytes[_for] of the WHOLE batch). */
+int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_ba_shard_render(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_ba_shard_scatter(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_ba_shard_pose(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
 
 /* ---- optimizer step (M1) ------------------------------------------------------------------------------------
  * torch.optim.Adam as the reference builds it (mp_slam/slam.py:271-286; betas (0.9, 0.99), per-group lr / eps /

@@ -59,6 +59,17 @@ class BaDesc(C.Structure):
                 ("rba_scale", C.c_float), ("rba_grads", C.c_void_p), ("rba_ws", C.c_void_p)]
 
 
+class LevelRows(C.Structure):
+    _fields_ = [("rows", C.c_void_p * RFX_MAX_LEVELS), ("ld", C.c_int32 * RFX_MAX_LEVELS), ("col", C.c_int32 * RFX_MAX_LEVELS)]
+
+
+class BaShard(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("level_start", C.c_int32 * (RFX_MAX_LEVELS + 1)),
+                ("ray_start", C.c_int64 * (RFX_MAX_LEVELS + 1)), ("feat_send", C.c_void_p), ("feat_recv", C.c_void_p),
+                ("demb_send", C.c_void_p), ("demb_recv", C.c_void_p), ("loss_sums8", C.c_void_p), ("dx_send", C.c_void_p),
+                ("dx_recv", C.c_void_p)]
+
+
 class RbaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("hidden", C.c_int32)]
 
@@ -146,6 +157,15 @@ PROTOTYPES = {
     "rfx_ba_workspace_bytes": (C.c_size_t, [_l, _i, _i, _i, _i]),
     "rfx_ba_forward_backward": (_i, [C.POINTER(BaDesc), _P, C.c_size_t, _P]),
     "rfx_ba_workspace_layout": (_i, [_l, _i, _i, _i, _i, C.POINTER(C.c_size_t), _i]),
+    "rfx_field_stash_put": (_i, [C.POINTER(LevelRows), _l, _P, _sz, _P]),
+    "rfx_field_forward_stashed": (_i, [C.POINTER(FieldDesc), _P, _l, _P, _P, _sz, _P]),
+    "rfx_field_backward_demb_rows": (_i, [_l, C.POINTER(LevelRows), _P, _i, _P, _P, _sz, _P]),
+    "rfx_grid_encode_backward_merged": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _l, _P, _P, _P, _sz, _P]),
+    "rfx_ba_shard_bytes": (C.c_size_t, []),
+    "rfx_ba_shard_lookup": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
+    "rfx_ba_shard_render": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
+    "rfx_ba_shard_scatter": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
+    "rfx_ba_shard_pose": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
     "rfx_rba_acts_floats": (C.c_size_t, [_l]),
     "rfx_rba_grads_floats": (C.c_size_t, [_l]),
     "rfx_frame_pose": (_i, [_P, _P, _P, _P, _P]),
@@ -174,12 +194,14 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 5:
+    if lib.rfx_abi_version() != 6:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")
     if lib.rfx_ba_desc_bytes() != C.sizeof(BaDesc):
         raise RfxError("rfx_ba_desc layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
+    if lib.rfx_ba_shard_bytes() != C.sizeof(BaShard):
+        raise RfxError("rfx_ba_shard layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
     _lib = lib
     return lib
 

@@ -68,6 +68,84 @@ static BaWs carve_ba(void* base, int64_t n, int S, int P, int n_feat, int n_leve
     return w;
 }
 
+// dst[i] = sum over q of src[q * stride + i] (in rank order): the ranks' partial d loss / d x01 of the own points
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ src, int parts, int64_t stride, int64_t count,
+                                                        float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float a = 0.f;
+    for (int q = 0; q < parts; ++q) a += src[q * stride + i];
+    dst[i] = a;
+}
+
+// what a rank of a level-partitioned iteration owns (rfx_ba_shard): levels [l0, l1) as a sub-grid with the true table
+// offsets, rays [r0, r1) of the batch
+struct ShardGeom {
+    int l0, l1, k;
+    int64_t r0, r1, n_own;
+    rfx_grid_desc own;
+};
+
+static int shard_geom(const rfx_ba_desc* b, const rfx_ba_shard* s, int64_t n, ShardGeom* g) {
+    if (!s || s->world < 1 || s->world > RFX_MAX_LEVELS || s->rank < 0 || s->rank >= s->world) return RFX_ERR_ARG;
+    const int L = b->field.hash.n_levels;
+    if (s->level_start[0] != 0 || s->level_start[s->world] != L || s->ray_start[0] != 0 || s->ray_start[s->world] != n) return RFX_ERR_ARG;
+    for (int q = 0; q < s->world; ++q)
+        if (s->level_start[q + 1] <= s->level_start[q] || s->ray_start[q + 1] < s->ray_start[q]) return RFX_ERR_ARG;
+    g->l0 = s->level_start[s->rank]; g->l1 = s->level_start[s->rank + 1]; g->k = g->l1 - g->l0;
+    g->r0 = s->ray_start[s->rank]; g->r1 = s->ray_start[s->rank + 1]; g->n_own = g->r1 - g->r0;
+    g->own = b->field.hash;
+    g->own.n_levels = g->k;
+    for (int i = 0; i < RFX_MAX_LEVELS; ++i) {
+        const int l = i < g->k ? g->l0 + i : g->l1 - 1;        // (unused slots repeat the last level: never read)
+        g->own.scale[i] = b->field.hash.scale[l]; g->own.res[i] = b->field.hash.res[l]; g->own.size[i] = b->field.hash.size[l];
+        g->own.offset[i] = b->field.hash.offset[l]; g->own.hashed[i] = b->field.hash.hashed[l];
+    }
+    return RFX_OK;
+}
+
+// the level rows of the blocks [points, 2 k_q], q = 0..world-1 in turn, at `base`
+static void shard_rows(const rfx_ba_shard* s, const float* base, int64_t points, rfx_level_rows* r) {
+    for (int q = 0; q < s->world; ++q) {
+        const int a = s->level_start[q], e = s->level_start[q + 1];
+        for (int l = a; l < e; ++l) {
+            r->rows[l] = base + (size_t)points * 2 * a;
+            r->ld[l] = 2 * (e - a);
+            r->col[l] = 2 * (l - a);
+        }
+    }
+}
+
+struct ShardCall {
+    int64_t n, nS, nt;
+    int S, P, L, F;
+    bool map_grads;
+    BaWs w;
+    ShardGeom g;
+};
+
+static int shard_call(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, ShardCall* c) {
+    if (!b || !workspace) return RFX_ERR_ARG;
+    c->n = b->n_kf_samples + b->n_cur;
+    c->S = b->sampler.n_range_d + b->sampler.n_samples_d; c->P = b->tv_P;
+    c->L = b->field.hash.n_levels; c->F = b->field.hash.n_feat;
+    if (c->n <= 0 || c->S <= 0 || c->P <= 0 || !b->poses16 || b->K <= 0 || !b->loss_w_dev || b->hash_entries <= 0) return RFX_ERR_ARG;
+    if (c->L != RFX_MAX_LEVELS || c->F != 2) return RFX_ERR_UNSUPPORTED;
+    c->map_grads = b->d_hash != nullptr;
+    if ((b->d_hash != nullptr) != (b->d_w != nullptr) || (!c->map_grads && !b->d_poses16)) return RFX_ERR_ARG;
+    if ((uintptr_t)workspace & 255) return RFX_ERR_ARG;
+    const size_t min_total = rfx_ba_workspace_bytes(c->n, c->S, c->P, c->L * c->F, c->L);
+    if (workspace_bytes < min_total) return RFX_ERR_WORKSPACE;
+    const size_t min_scat = rfx_grid_encode_backward_workspace_bytes(c->n * c->S + (int64_t)c->P * c->P * c->P, c->L);
+    c->w = carve_ba(workspace, c->n, c->S, c->P, c->L * c->F, c->L, min_scat + ((workspace_bytes - min_total) & ~(size_t)255));
+    c->nS = c->n * c->S; c->nt = (int64_t)c->P * c->P * c->P;
+    int rc = shard_geom(b, s, c->n, &c->g);
+    if (rc) return rc;
+    if (!s->feat_send || !s->feat_recv || !s->demb_send || !s->demb_recv || !s->loss_sums8) return RFX_ERR_ARG;
+    if (b->d_poses16 && (!s->dx_send || !s->dx_recv)) return RFX_ERR_ARG;
+    return RFX_OK;
+}
+
 }  // namespace rfx
 
 using namespace rfx;
@@ -187,6 +265,102 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
                                                   w.scat_bytes, stream));
     }
     return RFX_OK;
+}
+
+// ---- the same iteration on a level-partitioned table (rfx.h: rfx_ba_shard) ------------------------------------------------
+size_t rfx_ba_shard_bytes(void) { return sizeof(rfx_ba_shard); }
+
+int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    ShardCall c;
+    RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
+    const BaWs& w = c.w;
+    const bool tv_on = c.map_grads || b->tv_sum;
+    if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
+    // the part of the gradient buffer that belongs to the own levels (a contiguous range of levels: one contiguous range)
+    const int64_t z0 = (int64_t)c.g.own.offset[0] * c.F;
+    const int64_t z1 = ((int64_t)c.g.own.offset[c.g.k - 1] + c.g.own.size[c.g.k - 1]) * c.F;
+    int n_cnt = 0;
+    RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
+                        b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
+                        b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, c.P, b->tv_voxel,
+                        b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
+                        c.map_grads ? b->d_hash + z0 : nullptr, c.map_grads ? z1 - z0 : 0, b->trunc * b->sc_factor, b->depth_trunc,
+                        w.cnt, &n_cnt, stream, &c.g.own));
+    return rfx_grid_encode_forward(&c.g.own, b->field.hash_table, w.x01, c.nS, s->feat_send, stream);
+}
+
+int rfx_ba_shard_render(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    ShardCall c;
+    RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
+    const BaWs& w = c.w;
+    const int S = c.S;
+    const int64_t m = c.g.n_own, mS = m * S;
+    hipStream_t st = as_stream(stream);
+    const float* x01 = w.x01 + c.g.r0 * S * 3;
+    const float* z = w.z + c.g.r0 * S;
+    int n_partials = 0;
+    if (m > 0) {
+        rfx_level_rows rows;
+        shard_rows(s, s->feat_recv, mS, &rows);
+        RFX_TRY(rfx_field_stash_put(&rows, mS, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_TRY(rfx_field_forward_stashed(&b->field, x01, mS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
+    }
+    // R1 + L1 forward and backward of the own rays with the WHOLE batch's coefficients (the prologue counted all n rays on
+    // every rank); the TV backward of the own levels beside them
+    RFX_TRY(composite_loss_grad(w.raw, z, w.tgt + c.g.r0 * 3, w.td + c.g.r0, m, S, b->trunc, b->sc_factor, b->trunc * b->sc_factor,
+                                b->depth_trunc, b->rgb_missing_on, w.rgb_map, w.depth_map, w.lsum, &n_partials, w.cnt,
+                                ba_count_partials(c.n), b->loss_w_dev, w.d_raw, w.ray_cnt, c.map_grads ? w.feat : nullptr, c.P,
+                                c.g.k * c.F, b->tv_scale, c.map_grads ? w.dfeat : nullptr, stream, c.n));
+    if (m == 0 && c.map_grads) RFX_TRY(rfx_tv_backward(w.feat, c.P, c.g.k * c.F, b->tv_scale, nullptr, w.dfeat, stream));
+    if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, c.P, c.g.k * c.F, b->tv_sum, stream));     // the own levels' share of the sum
+    int finalized = 0;
+    RFX_TRY(field_backward_chain_stashed_counted(&b->field, x01, mS, w.d_raw, w.bwd_ws, w.bwd_bytes,
+                                                 c.map_grads && b->d_poses16 ? 0 : c.map_grads ? 2 : 1, w.ray_cnt, S, nullptr, 0, nullptr,
+                                                 &finalized, stream));
+    if (c.map_grads) {
+        float* dw1 = b->d_w; float* dw2 = dw1 + 32 * 81; float* dw3 = dw2 + 16 * 32; float* dw4 = dw3 + 32 * 66;
+        RFX_TRY(field_backward_weights_overwrite(mS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    }
+    rfx_level_rows out;
+    shard_rows(s, s->demb_send, mS, &out);
+    if (n_partials == 0) RFX_HIP_TRY(hipMemsetAsync(s->loss_sums8, 0, 8 * sizeof(double), st));
+    return rfx_field_backward_demb_rows(mS, &out, w.lsum, n_partials, s->loss_sums8, w.bwd_ws, w.bwd_bytes, stream);
+}
+
+int rfx_ba_shard_scatter(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    ShardCall c;
+    RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
+    const BaWs& w = c.w;
+    if (c.map_grads)
+        RFX_TRY(rfx_grid_encode_backward_merged(&c.g.own, b->field.hash_table, w.x01, c.nS, s->demb_recv, w.pts, c.nt, w.dfeat,
+                                                b->d_hash, w.scat_ws, w.scat_bytes, stream));
+    if (b->d_poses16)
+        RFX_TRY(rfx_grid_encode_backward(&c.g.own, b->field.hash_table, w.x01, c.nS, s->demb_recv, nullptr, s->dx_send, nullptr, 0,
+                                         stream));
+    return RFX_OK;
+}
+
+int rfx_ba_shard_pose(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    ShardCall c;
+    RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
+    if (!b->d_poses16) return RFX_ERR_ARG;
+    const BaWs& w = c.w;
+    const int S = c.S;
+    const int64_t m = c.g.n_own, mS = m * S;
+    hipStream_t st = as_stream(stream);
+    if (m == 0) {
+        RFX_HIP_TRY(hipMemsetAsync(b->d_poses16, 0, (size_t)b->K * 16 * sizeof(float), st));
+        return RFX_OK;
+    }
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((mS * 3 + 255) / 256)), dim3(256), 0, st, s->dx_recv, s->world, mS * 3, mS * 3,
+                       w.dx);
+    RFX_LAUNCH_CHECK();
+    RFX_TRY(rfx_field_backward_dx(&b->field, w.x01 + c.g.r0 * S * 3, mS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
+    const float ex = (float)(b->bbox[1] - b->bbox[0]), ey = (float)(b->bbox[3] - b->bbox[2]), ez = (float)(b->bbox[5] - b->bbox[4]);
+    hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, w.dx, w.z + c.g.r0 * S, m, S, ex, ey, ez,
+                       w.go, w.gd);
+    RFX_LAUNCH_CHECK();
+    return rfx_pose_grad(w.go, w.gd, w.d_cam + c.g.r0 * 3, w.pidx + c.g.r0, m, b->K, b->d_poses16, stream);
 }
 
 }  // extern "C"

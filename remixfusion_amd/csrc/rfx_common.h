@@ -71,12 +71,14 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
-                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream);
+                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream,
+                const rfx_grid_desc* tv_grid = nullptr);     // (tv_grid: the lattice's lookups use it instead of field->hash)
+int ba_count_partials(int64_t n_rays);                       // count_partials triples ba_prologue writes for a batch of n_rays
 int composite_loss_grad(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays, int S,
                         float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, float* rgb_map,
                         float* depth_map, double* sums, int* n_partials, const double* count_partials, int n_count_partials,
                         const float* gout4, float* d_raw4, int32_t* ray_counts, const float* tv_feat, int tv_P, int tv_C, float tv_scale,
-                        float* tv_dfeat, rfx_stream stream);
+                        float* tv_dfeat, rfx_stream stream, int64_t n_rays_total = 0);   // (> n_rays: a share of a larger batch)
 int loss_finalize_launch(const double* sums, int n_partials, int64_t n_rays, int S, float* lc8, rfx_stream stream);
 int field_backward_weights_overwrite(int64_t n, const float* draw4, float* dw1, float* dw2, float* dw3, float* dw4,
                                      void* workspace, size_t workspace_bytes, rfx_stream stream);   // rfx_field.hip

@@ -28,7 +28,9 @@ namespace rfx {
 // ---------------------------------------------------------------- Q1 forward kernel
 // STASH: also leave the interpolated hash features in `emb` (piece-major tiles, see the backward workspace layout) for the
 // backward chain of the same iteration, which then needs no hash lookups of its own.
-template <bool POS16, bool STASH>
+// EMB (mlp_forward_123): 0 look the hash features up, 1 look them up and stash them, 2 read them from the stash (the table is not
+// touched: a level-partitioned table's features arrive from the ranks that own the levels, rfx_field_stash_put).
+template <bool POS16, int EMB>
 __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
                                                             float* __restrict__ raw4, float* __restrict__ emb) {
     __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f,
         Enc e;
         encode_point(f, x, e);
         Mlp m;
-        mlp_forward_123<STASH ? 1 : 0, false, POS16>(f, x, wl, lane, e, m, STASH ? emb + (p >> 6) * (8 * ROW_PIECE) + (p & 63) * 4 : nullptr,
-                                                     nullptr, p < n);
+        mlp_forward_123<EMB, false, POS16>(f, x, wl, lane, e, m, EMB ? emb + (p >> 6) * (8 * ROW_PIECE) + (p & 63) * 4 : nullptr,
+                                           nullptr, p < n);
         float raw[4];
         mlp_forward_4(wl, lane, e, m, raw);
         if (p < n) reinterpret_cast<float4*>(raw4)[p] = make_float4(raw[0], raw[1], raw[2], raw[3]);
@@ -290,10 +292,17 @@ static void scatter_shape(int64_t n, int total_segments, int* chunks, int* K) {
     *K = (int)((per + SCATTER_THREADS - 1) / SCATTER_THREADS);
 }
 
-// upper bound of staged slots for any plan of scatter_shape(): each chunk pads to a multiple of 1024 points
+// upper bound of staged slots for any plan of scatter_shape(): each chunk pads to a multiple of 1024 points.  The same
+// buffer holds the records of the binned levels afterwards, one level at a time when it is no larger than this minimum:
+// 24 floats per point + the [blk][seg] counters of the level with the most segments the binned path accepts -- more than
+// the sweep's (2 L + 3) floats per point when the grid has 8 levels or fewer (a sub-grid of a level-partitioned table).
 static size_t scatter_scratch_floats(int64_t n, int n_levels) {
     const size_t slots = (size_t)n + (size_t)((n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS + 1) * SCATTER_THREADS;
-    return slots * (size_t)(2 * n_levels + 3);
+    const size_t sweep = slots * (size_t)(2 * n_levels + 3);
+    if (n < SCATTER_MIN_POINTS) return sweep;              // below it nothing is staged or binned (direct atomics)
+    const size_t n_blk = (size_t)((n + 2 * 1024 - 1) / (2 * 1024));         // BIN_THREADS * BIN_PPT points per block
+    const size_t one_binned = (size_t)n * 8 * 3 + 2 * n_blk * 1024 + 2 * (1024 + 1) + 8;      // SCATTER_BIN_MAX_SEGMENTS = 1024
+    return std::max(sweep, one_binned);
 }
 
 // LDS slot of table entry r of a segment.  On the dense levels the vertices of neighbouring cells are res or res^2
@@ -586,6 +595,7 @@ __device__ __forceinline__ unsigned bin_take(unsigned* counters, unsigned seg, b
 }
 
 constexpr int BIN_PPT = 2;            // points per thread in the count / record kernels: 2 048 points per block
+static_assert(BIN_THREADS * BIN_PPT == 2 * 1024 && SCATTER_BIN_MAX_SEGMENTS <= 1024 && BIN_MAX_SEGS <= 1024, "scatter_scratch_floats() prices one binned level with these");
 
 // The binned levels of one sweep that are in flight TOGETHER (as many as the caller's scratch holds records for: 96 B per point
 // and level).  One level at a time meant four launches per level -- 44 dependent launches per scatter at T = 2^19, each a few
@@ -791,7 +801,8 @@ static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) 
 }
 
 // the binned levels `levels[0..n_lv)` through the four kernels above, as many levels per group of launches as the scratch
-// holds (at least one: the caller's minimum, rfx_grid_encode_backward_workspace_bytes, covers one level)
+// holds (at least one: the caller's minimum, rfx_grid_encode_backward_workspace_bytes = scatter_scratch_floats, covers one
+// level of any admissible segment count for every n_levels)
 static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n_lv, const ScatterSrc& a, const ScatterSrc& b,
                                 float* dtable, float* scratch, size_t scratch_floats, hipStream_t st) {
     const int64_t n_all = a.n + b.n;
@@ -1542,6 +1553,60 @@ __global__ __launch_bounds__(256) void field_dx_kernel(FieldK f, const float* __
     dx01[p * 3] += dx[0]; dx01[p * 3 + 1] += dx[1]; dx01[p * 3 + 2] += dx[2];
 }
 
+// ---------------------------------------------------------------- level-partitioned table: features in, feature gradients out
+// One scene on several GPUs (mp_slam/sharded.py): rank q keeps the hash levels [level_start[q], level_start[q+1]) and looks them
+// up for every sample point of the iteration; the ranks that render the points receive the features as row-major blocks
+// [points, 2 k_q] (one block per owning rank) and put them where the forward of a single GPU leaves them: the stash.
+struct LevelRowsK { const float* src[RFX_MAX_LEVELS]; int ld[RFX_MAX_LEVELS]; int col[RFX_MAX_LEVELS]; };
+
+// thread = (tile of 64 points, float4 piece q = levels 2q and 2q+1, lane = point): a wave's store is one contiguous 1 KiB run
+__global__ __launch_bounds__(256) void stash_put_kernel(LevelRowsK r, int64_t n, float* __restrict__ emb) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = gid >> 9;
+    const int q = (int)((gid >> 6) & 7), lane = (int)(gid & 63);
+    const int64_t p = tile * 64 + lane;
+    if (tile * 64 >= n) return;
+    float2 a = make_float2(0.f, 0.f), b = a;          // the tail of the last tile is read by the forward's idle lanes: zeros
+    if (p < n) {
+        a = *reinterpret_cast<const float2*>(r.src[2 * q] + p * (int64_t)r.ld[2 * q] + r.col[2 * q]);
+        b = *reinterpret_cast<const float2*>(r.src[2 * q + 1] + p * (int64_t)r.ld[2 * q + 1] + r.col[2 * q + 1]);
+    }
+    *reinterpret_cast<float4*>(emb + tile * (8 * ROW_PIECE) + q * ROW_PIECE + lane * 4) = make_float4(a.x, a.y, b.x, b.y);
+}
+
+// The way back: the chain's d_emb (columns 0..31 of its dX1 rows, in the selection's order) as row-major blocks per owning rank,
+// in the caller's point order, zeros for the points without a gradient.  thread = (row, level): a row's 16 threads read its
+// 128 bytes contiguously.  One more block adds the loss kernel's partial sums up (total8: what the ranks all-reduce).
+struct LevelRowsOutK { float* dst[RFX_MAX_LEVELS]; int ld[RFX_MAX_LEVELS]; int col[RFX_MAX_LEVELS]; };
+struct LossSumJob { const double* partial; int n_partials; double* total8; };
+
+__global__ __launch_bounds__(256) void demb_rows_kernel(const float* __restrict__ dx1, const int* __restrict__ perm,
+                                                        const int* __restrict__ n_sel, int64_t n, LevelRowsOutK o, int nb_rows,
+                                                        LossSumJob job) {
+    if ((int)blockIdx.x >= nb_rows) {
+        __shared__ double part[32][8];
+        const int v = threadIdx.x & 7, q = threadIdx.x >> 3;
+        double a = 0.0;
+        for (int k = q; k < job.n_partials; k += 32) a += job.partial[k * 8 + v];
+        part[q][v] = a;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            double t = 0.0;
+            for (int qq = 0; qq < 32; ++qq) t += part[qq][threadIdx.x];
+            job.total8[threadIdx.x] = t;
+        }
+        return;
+    }
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 4;
+    const int l = (int)(gid & 15);
+    if (i >= n) return;
+    const int64_t p = perm ? (int64_t)perm[i] : i;
+    const bool live = !n_sel || i < *n_sel;
+    const float2 v = live ? *reinterpret_cast<const float2*>(dx1 + i * LD_DX1 + 2 * l) : make_float2(0.f, 0.f);
+    *reinterpret_cast<float2*>(o.dst[l] + p * (int64_t)o.ld[l] + o.col[l]) = v;
+}
+
 // ---------------------------------------------------------------- host side
 int make_fieldk(const rfx_field_desc* d, FieldK* k) {
     if (!d || !d->hash_table || !d->gbv || !d->w1 || !d->w2 || !d->w3 || !d->w4) return RFX_ERR_ARG;
@@ -1674,20 +1739,24 @@ int rfx_oneblob_forward(const float* x01, int64_t n, int n_bins, int pos_fp16, f
     return RFX_OK;
 }
 
-static int launch_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, float* emb, rfx_stream stream) {
+static int launch_forward(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, float* emb, rfx_stream stream,
+                          bool from_stash = false) {
     if (n == 0) return RFX_OK;
     FieldK k;
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
-    if (!x01 || !raw4 || n < 0) return RFX_ERR_ARG;
+    if (!x01 || !raw4 || n < 0 || (from_stash && !emb)) return RFX_ERR_ARG;
     const dim3 grid(wave_grid(n, 256 * 4));
     hipStream_t st = as_stream(stream);
-    if (emb) {
-        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, true>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
-        else hipLaunchKernelGGL((field_forward_kernel<false, true>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+    if (from_stash) {
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+    } else if (emb) {
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
     } else {
-        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, false>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
-        else hipLaunchKernelGGL((field_forward_kernel<false, false>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
     }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
@@ -1738,6 +1807,82 @@ int rfx_field_forward_stash(const rfx_field_desc* f, const float* x01, int64_t n
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
     return launch_forward(f, x01, n, raw4, carve(workspace, n).emb, stream);
+}
+
+static int level_rows_ok(const rfx_level_rows* r) {
+    if (!r) return RFX_ERR_ARG;
+    for (int l = 0; l < RFX_MAX_LEVELS; ++l)
+        if (!r->rows[l] || r->ld[l] < 2 || (r->ld[l] & 1) || r->col[l] < 0 || (r->col[l] & 1) || r->col[l] + 2 > r->ld[l] ||
+            ((uintptr_t)r->rows[l] & 7))
+            return RFX_ERR_ARG;
+    return RFX_OK;
+}
+
+int rfx_field_stash_put(const rfx_level_rows* rows, int64_t n, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
+    if (n < 0) return RFX_ERR_ARG;
+    int rc = level_rows_ok(rows);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
+    LevelRowsK k;
+    for (int l = 0; l < RFX_MAX_LEVELS; ++l) { k.src[l] = rows->rows[l]; k.ld[l] = rows->ld[l]; k.col[l] = rows->col[l]; }
+    const int64_t threads = (n + 63) / 64 * 512;
+    hipLaunchKernelGGL(stash_put_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), k, n,
+                       carve(workspace, n).emb);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_field_forward_stashed(const rfx_field_desc* f, const float* x01, int64_t n, float* raw4, void* workspace,
+                              size_t workspace_bytes, rfx_stream stream) {
+    if (n == 0) return RFX_OK;
+    if (n < 0) return RFX_ERR_ARG;
+    if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+    if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
+    return launch_forward(f, x01, n, raw4, carve(workspace, n).emb, stream, true);
+}
+
+int rfx_field_backward_demb_rows(int64_t n, const rfx_level_rows* rows, const double* loss_partials, int n_loss_partials,
+                                 double* loss_total8, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    const bool sum_job = loss_partials && loss_total8 && n_loss_partials > 0;
+    if (n == 0 && !sum_job) return RFX_OK;
+    if (n < 0) return RFX_ERR_ARG;
+    LevelRowsOutK o = {};
+    BwdWs ws = {};
+    if (n > 0) {
+        int rc = level_rows_ok(rows);
+        if (rc) return rc;
+        if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
+        if ((uintptr_t)workspace & 15) return RFX_ERR_ARG;
+        for (int l = 0; l < RFX_MAX_LEVELS; ++l) { o.dst[l] = const_cast<float*>(rows->rows[l]); o.ld[l] = rows->ld[l]; o.col[l] = rows->col[l]; }
+        ws = carve(workspace, n);
+    }
+    const int nb_rows = (int)((n * 16 + 255) / 256);
+    hipLaunchKernelGGL(demb_rows_kernel, dim3((unsigned)(nb_rows + (sum_job ? 1 : 0))), dim3(256), 0, as_stream(stream), ws.dx1,
+                       sel_on(n) ? ws.perm : nullptr, sel_on(n) ? ws.sel_hdr : nullptr, n, o, nb_rows,
+                       LossSumJob{loss_partials, sum_job ? n_loss_partials : 0, loss_total8});
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_grid_encode_backward_merged(const rfx_grid_desc* g, const float* table, const float* x01_a, int64_t n_a,
+                                    const float* dfeat_a, const float* x01_b, int64_t n_b, const float* dfeat_b, float* dtable,
+                                    void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    if (n_a < 0 || n_b < 0) return RFX_ERR_ARG;
+    if (n_a + n_b == 0) return RFX_OK;
+    if (!g || !table || !dtable || (n_a > 0 && (!x01_a || !dfeat_a)) || (n_b > 0 && (!x01_b || !dfeat_b))) return RFX_ERR_ARG;
+    if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
+    if (workspace && (workspace_bytes < rfx_grid_encode_backward_workspace_bytes(n_a + n_b, g->n_levels) || ((uintptr_t)workspace & 7)))
+        return RFX_ERR_WORKSPACE;
+    if (n_a == 0) {           // the first source carries the selection in the fused callers: keep it the non-empty one
+        return launch_grid_scatter(*g, table, x01_b, n_b, dfeat_b, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
+                                   as_stream(stream), nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                                   workspace ? workspace_bytes / sizeof(float) : 0);
+    }
+    return launch_grid_scatter(*g, table, x01_a, n_a, dfeat_a, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
+                               as_stream(stream), x01_b, dfeat_b, g->n_levels * 2, n_b, nullptr, nullptr, nullptr, nullptr,
+                               workspace ? workspace_bytes / sizeof(float) : 0);
 }
 
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,

@@ -538,7 +538,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void composite_loss_grad_tv_kernel(Lo
                                                                               float* __restrict__ depth_map, double* __restrict__ sums,
                                                                               const double* __restrict__ cnt_partials, int n_cnt,
                                                                               const float* __restrict__ gout, float4* __restrict__ d_raw,
-                                                                              int* __restrict__ ray_counts, int nb_loss, TvBackK tv) {
+                                                                              int* __restrict__ ray_counts, int nb_loss, TvBackK tv,
+                                                                              int64_t n_total) {
     __shared__ double red[LOSS_THREADS / 64];
     __shared__ double cpart[64][4], ctot[4];
     __shared__ float coef[4];
@@ -558,11 +559,12 @@ __global__ __launch_bounds__(LOSS_THREADS) void composite_loss_grad_tv_kernel(Lo
             ctot[threadIdx.x] = t;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {             // loss_finalize's coefficients (rfx_common.h), from the same three numbers
-            const double ns = (double)n_rays * (double)S;
+        if (threadIdx.x == 0) {             // loss_finalize's coefficients (rfx_common.h), from the same three numbers; n_total:
+            // the rays of the whole batch (the counts are the whole batch's), of which this launch renders n_rays
+            const double ns = (double)n_total * (double)S;
             const double tot = ctot[1] + ctot[2];
             const float fs_w = (float)(1.0 - ctot[1] / tot), sdf_w = (float)(1.0 - ctot[2] / tot);
-            coef[0] = (float)(1.0 / (3.0 * (double)n_rays)); coef[1] = (float)(1.0 / ctot[0]);
+            coef[0] = (float)(1.0 / (3.0 * (double)n_total)); coef[1] = (float)(1.0 / ctot[0]);
             coef[2] = (float)(1.0 / ns) * sdf_w; coef[3] = (float)(1.0 / ns) * fs_w;
         }
         __syncthreads();
@@ -1272,7 +1274,8 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 const double bbox[6], int bbox_f64, float* rays_o, float* rays_d, float* target_rgb, float* target_d,
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
-                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream) {
+                float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream,
+                const rfx_grid_desc* tv_grid) {
     if (n_count_partials) *n_count_partials = 0;
     const int64_t n = n_kf_samples + n_cur;
     if (n == 0) return RFX_OK;
@@ -1298,10 +1301,11 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
     int nb_tv = 0;
     if (tv_pts) {
         if (!field || !tv_feat || tv_P <= 0 || !(tv_voxel > 0.f) || (!u6 && !seed_u)) return RFX_ERR_ARG;
-        if (field->hash.n_feat != 2 || field->hash.n_levels < 1 || field->hash.n_levels > 16) return RFX_ERR_UNSUPPORTED;
+        const rfx_grid_desc& tg = tv_grid ? *tv_grid : field->hash;        // (a level-partitioned table: the own levels only)
+        if (tg.n_feat != 2 || tg.n_levels < 1 || tg.n_levels > 16) return RFX_ERR_UNSUPPORTED;
         for (int d = 0; d < 3; ++d) { tv.L.lo[d] = bbox[2 * d]; tv.L.hi[d] = bbox[2 * d + 1]; }
         tv.L.f64 = bbox_f64 ? 1 : 0; tv.L.normalise = tv_normalise ? 1 : 0; tv.L.P = tv_P; tv.L.voxel = tv_voxel; tv.L.margin = tv_margin;
-        tv.g = field->hash; tv.table = field->hash_table; tv.u6 = seed_u ? nullptr : u6; tv.pts = tv_pts; tv.feat = tv_feat;
+        tv.g = tg; tv.table = field->hash_table; tv.u6 = seed_u ? nullptr : u6; tv.pts = tv_pts; tv.feat = tv_feat;
         nb_tv = (int)(((int64_t)tv_P * tv_P * tv_P * 16 + 255) / 256);
     }
     const RayOut out = {rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01};
@@ -1317,6 +1321,8 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
     return RFX_OK;
 }
 
+int ba_count_partials(int64_t n_rays) { return n_rays > 0 ? ray_grid(n_rays) : 0; }
+
 // rfx_composite_forward + rfx_mapping_loss_forward + rfx_mapping_loss_backward in one launch (composite_loss_grad_tv_kernel), for a batch whose three
 // loss counts the prologue left in count_partials.  sums: LOSS_GRAD_BLOCKS x 8 doubles; *n_partials of them are written and
 // wait for a finalize (loss_finalize: the selection's launch takes it along, or loss_finalize_launch below).
@@ -1324,8 +1330,9 @@ int composite_loss_grad(const float* raw4, const float* z_vals, const float* tar
                         float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, float* rgb_map,
                         float* depth_map, double* sums, int* n_partials, const double* count_partials, int n_count_partials,
                         const float* gout4, float* d_raw4, int32_t* ray_counts, const float* tv_feat, int tv_P, int tv_C, float tv_scale,
-                        float* tv_dfeat, rfx_stream stream) {
+                        float* tv_dfeat, rfx_stream stream, int64_t n_rays_total) {
     *n_partials = 0;
+    if (n_rays_total < n_rays) n_rays_total = n_rays;
     if (n_rays == 0) return RFX_OK;
     if (!raw4 || !z_vals || !rgb_map || !depth_map || !target_rgb || !target_d || !sums || !count_partials || !gout4 || !d_raw4)
         return RFX_ERR_ARG;
@@ -1339,7 +1346,8 @@ int composite_loss_grad(const float* raw4, const float* z_vals, const float* tar
     if (tv_dfeat) nb_tv = (int)std::min<int64_t>(((int64_t)tv_P * tv_P * tv_P * tv_C + 255) / 256, 2048);
     hipLaunchKernelGGL(composite_loss_grad_tv_kernel, dim3(blocks + nb_tv), dim3(LOSS_THREADS), 0, as_stream(stream), L,
                        reinterpret_cast<const float4*>(raw4), z_vals, target_rgb, target_d, n_rays, S, trunc, sc_factor, rgb_map, depth_map,
-                       sums, count_partials, n_count_partials, gout4, reinterpret_cast<float4*>(d_raw4), ray_counts, blocks, tv);
+                       sums, count_partials, n_count_partials, gout4, reinterpret_cast<float4*>(d_raw4), ray_counts, blocks, tv,
+                       n_rays_total);
     RFX_LAUNCH_CHECK();
     *n_partials = blocks;
     return RFX_OK;

@@ -190,6 +190,102 @@ def all_reduce_sum_(dist, tensors) -> None:
             o += n
 
 
+def all_to_all_rows_(dist, out: torch.Tensor, out_splits: List[int], inp: torch.Tensor, in_splits: List[int]) -> None:
+    """all-to-all of flat fp32 buffers with per-rank element counts: inp is cut into in_splits (piece q goes to rank q), out
+    receives the pieces of ranks 0..world-1 in turn (out_splits).  nccl (RCCL): on the device; gloo: through the host."""
+    if dist is None or dist.get_world_size() == 1:
+        out[:sum(out_splits)].copy_(inp[:sum(in_splits)])
+        return
+    o, i = out[:sum(out_splits)], inp[:sum(in_splits)]
+    if _host_staged(dist, inp):
+        ho = torch.empty(o.shape, dtype=o.dtype)
+        dist.all_to_all_single(ho, i.cpu(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
+        o.copy_(ho)
+    else:
+        dist.all_to_all_single(o, i, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
+
+
+# ---- the residual field over N GPUs: the hash table partitioned by LEVEL (mp_slam/sharded.py) -----------------------------
+_BIN_SEG, _BIN_MIN_SEGMENTS = 8192, 12       # csrc/rfx_field.hip: levels of >= 12 segments of 8 192 entries take the binned scatter
+_BINNED_LEVEL_COST = 3.6                     # measured at cafeteria sizes (profiles/r3_notes.md): 62 us per binned level against
+                                             # 17 us per level of the LDS sweep, per merged scatter
+
+
+def level_costs(desc) -> List[float]:
+    """relative cost of keeping one hash level (lookups + gradient scatter + TV term): every level sees every point, so the
+    cost is per level, not per entry; levels large enough for the binned scatter cost more."""
+    return [_BINNED_LEVEL_COST if -(-int(desc.size[l]) // _BIN_SEG) >= _BIN_MIN_SEGMENTS else 1.0 for l in range(int(desc.n_levels))]
+
+
+def level_partition(desc, world: int) -> List[int]:
+    """cuts [0 = c_0 < c_1 < ... < c_world = n_levels]: rank q keeps the CONTIGUOUS levels [c_q, c_{q+1}) (one contiguous
+    range of the table, of its gradient and of the Adam state), chosen to minimise the largest rank's cost."""
+    L = int(desc.n_levels)
+    if not 1 <= world <= L:
+        raise ValueError(f"a {L}-level table can be partitioned over at most {L} ranks (asked: {world})")
+    cost = level_costs(desc)
+    pre = [0.0]
+    for c in cost:
+        pre.append(pre[-1] + c)
+    INF = float("inf")
+    best = [[INF] * (L + 1) for _ in range(world + 1)]       # best[q][l]: smallest possible maximum over q ranks keeping levels [0, l)
+    arg = [[0] * (L + 1) for _ in range(world + 1)]
+    best[0][0] = 0.0
+    for q in range(1, world + 1):
+        for l in range(q, L - (world - q) + 1):
+            for a in range(q - 1, l):
+                v = max(best[q - 1][a], pre[l] - pre[a])
+                if v < best[q][l]:
+                    best[q][l], arg[q][l] = v, a
+    cuts = [L]
+    for q in range(world, 0, -1):
+        cuts.append(arg[q][cuts[-1]])
+    return cuts[::-1]
+
+
+def ray_partition(n: int, world: int) -> List[int]:
+    """rank q renders the contiguous rays [n q / world, n (q + 1) / world) of an iteration's batch"""
+    return [(n * q) // world for q in range(world + 1)]
+
+
+def level_exchange_splits(n: int, S: int, cuts: List[int], rank: int) -> Dict:
+    """element counts (fp32) of an iteration's three all-to-alls on a level-partitioned table, for `rank` of
+    world = len(cuts) - 1: name -> (what goes to rank q, what comes from rank q), q = 0..world-1.
+      feat   own levels' features of every rank's points out; every rank's levels for the own points in (blocks [m S, 2 k_q])
+      demb   the way back: gradient rows of the own points, per owning rank, out; all points' rows for the own levels in
+      dx     (pose phase) d loss / d x01 through the own levels of every rank's points out; world partial sums for the own points in"""
+    world = len(cuts) - 1
+    rs = ray_partition(n, world)
+    nq = [rs[q + 1] - rs[q] for q in range(world)]
+    kq = [cuts[q + 1] - cuts[q] for q in range(world)]
+    m, k = nq[rank], kq[rank]
+    feat = ([nq[q] * S * 2 * k for q in range(world)], [m * S * 2 * kq[q] for q in range(world)])
+    return {"rays": rs, "m": m, "feat": feat, "demb": (feat[1], feat[0]),
+            "dx": ([nq[q] * S * 3 for q in range(world)], [m * S * 3] * world)}
+
+
+def field_exchange_model(desc, n_points: int, n_lattice: int, world: int, selected: float = 0.63) -> Dict:
+    """bytes each rank RECEIVES per map iteration under the three ways of spreading the field over `world` GPUs, and what
+    part of the single-GPU scatter work a rank still does:
+      replicas   the table replicated, its dense gradient all-reduced (ring: 2 (N-1)/N of the buffer)
+      points     the verdict's alternative: all-gather of the selected points' (x01, d_emb) rows, every rank scatters ALL of them
+      levels     the table partitioned by level: features out, feature gradients back, each rank scatters its levels only"""
+    N = world
+    table_bytes = 4 * int(desc.n_feat) * sum(int(desc.size[l]) for l in range(int(desc.n_levels)))
+    row = 8 * int(desc.n_levels)                 # features (or their gradient) of one point, all levels
+    f = (N - 1) / N
+    cost = level_costs(desc)
+    cuts = level_partition(desc, N)
+    share = max(sum(cost[cuts[q]:cuts[q + 1]]) for q in range(N)) / sum(cost)
+    return {
+        "replicas": {"recv_bytes": 2 * f * table_bytes,          # (the lattice is rank 0's: its share of the points is the largest)
+                     "scatter_share": (n_points / N + n_lattice) / max(n_points + n_lattice, 1)},
+        "points": {"recv_bytes": f * selected * n_points * (row + 12), "scatter_share": 1.0},
+        "levels": {"recv_bytes": 2 * f * (n_points / N) * row, "scatter_share": share},
+        "table_bytes": table_bytes, "level_cuts": cuts,
+    }
+
+
 def shift_plan(cuts: List[int], need: List) -> List:
     """who sends which old x-planes to whom when the volume moves: need[r] = (a_r, b_r) are the old planes rank r's new
     slab reads; cuts are the (unchanged) slab boundaries of the old volume.  Returns [(src, dst, p0, p1)] with src != dst,

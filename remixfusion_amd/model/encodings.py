@@ -54,6 +54,9 @@ class _GridEncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x01, params, module):
         lib = _lib.load()
+        if getattr(module, "partition_stale", False):
+            raise _lib.RfxError("this grid is partitioned by level over several GPUs and the local copy is out of date: "
+                                "Mapper.sync_field() first")
         x = x01.detach().to(torch.float32).contiguous()
         n = x.shape[0]
         out = torch.empty((n, module.n_output_dims), dtype=torch.float32, device=x.device)

@@ -274,7 +274,10 @@ class JointEncoding(nn.Module):
         self.rba = RBA(self.num_kf, scale=config["mapping"]["pose_scale"])
 
     # -- librfx plumbing --------------------------------------------------------------------
-    def _field_desc(self, clamp: bool) -> FieldDesc:
+    def _field_desc(self, clamp: bool, partitioned_ok: bool = False) -> FieldDesc:
+        if not partitioned_ok and getattr(self.embed_res_fn, "partition_stale", False):
+            raise _lib.RfxError("the hash table is partitioned by level over several GPUs and this rank's copy of the other ranks' "
+                                "levels is out of date: call Mapper.sync_field() on every rank first")
         tr = self.config["training"]
         w1, w2, w3, w4 = self.decoder_res.fused_weights()
         d = FieldDesc()

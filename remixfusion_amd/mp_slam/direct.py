@@ -196,7 +196,7 @@ class DirectIterations:
         cfg = model.config
         tr, m = cfg["training"], cfg["mapping"]
         d = _lib.BaDesc()
-        d.field = model._field_desc(clamp)              # .staged set: rfx_ba_forward_backward refreshes the image itself
+        d.field = self._field(clamp)                    # .staged set: rfx_ba_forward_backward refreshes the image itself
         d.sampler = model._sampler_desc()
         d.bbox, d.bbox_f64 = model._bbox6, model._bbox_f64
         d.sc_factor, d.depth_trunc, d.trunc = float(cfg["data"]["sc_factor"]), float(cfg["cam"]["depth_trunc"]), float(tr["trunc"])
@@ -213,9 +213,17 @@ class DirectIterations:
         self._perturb = tr["perturb"] > 0.0
         return d
 
+    def _field(self, clamp):
+        return self.model._field_desc(clamp)
+
     def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True, rba=None):
         """fill in what changes per iteration and launch it (forward + backward).  rba = (params, acts, scale, grads, workspace):
         the call carries on into the pose MLP's backward (rfx_ba_desc.rba)."""
+        self._fill(B, current_rays, poses_ptr, K, clamp, d_poses_ptr, map_grads, rba)
+        check(self.lib.rfx_ba_forward_backward(self._descs[clamp][2], B.p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
+
+    def _fill(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, map_grads=True, rba=None):
+        """the iteration's rfx_ba_desc: what changes per iteration filled in (the random draws are taken here)"""
         t, p = B.t, B.p
         n = B.n
         d = self._descriptor(B, clamp, t.u.device)
@@ -244,7 +252,7 @@ class DirectIterations:
             d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, (p.tv_acc if self.report_tv else None)
         else:                           # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
             d.d_hash = d.d_w = d.tv_sum = None
-        check(self.lib.rfx_ba_forward_backward(self._descs[clamp][2], p.ws, B.ws_bytes, st), "rfx_ba_forward_backward")
+        return d
 
     # ------------------------------------------------------------------ stage-by-stage issue (instrumentation / cross-check)
     # The same iteration as rfx_ba_forward_backward, one foreign call per stage, so that bench.py can put HIP events

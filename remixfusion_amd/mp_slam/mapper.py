@@ -106,6 +106,7 @@ class Mapper:
         self.trunc_margin = self.config["training"]["c_trunc"]
 
     def save_ckpt(self, save_path):
+        self.sync_field()               # (a sharded scene: the table whole on every rank; collective)
         torch.save({"pose": self.est_c2w_data, "pose_rel": self.est_c2w_data_rel, "model": self.model.state_dict()}, save_path)
 
     # ---- GBV kernels --------------------------------------------------------------------
@@ -285,11 +286,20 @@ class Mapper:
             from .direct import DirectIterations
             sh = getattr(self, "scene_shard", None)        # dist.ShardedPipeline: ONE scene over several GPUs
             if sh is not None:
-                from .sharded import ShardedIterations
+                from .sharded import LevelShardedIterations, ShardedIterations
                 if not DirectIterations.supported(self):
                     raise _lib.RfxError("the sharded scene needs the configuration DirectIterations supports "
                                         "(device ray sampling, accumulation steps of 1, TV term on)")
-                self._direct = ShardedIterations(self, sh.dist, sh.rank, sh.world)
+                # mapping.shard_field: "levels" (hash table partitioned by level: per-point rows travel), "replicas" (table
+                # replicated, dense gradient all-reduced), "auto" = levels whenever the table has a level per rank
+                mode = str(self.config["mapping"].get("shard_field", "auto"))
+                levels = int(self.model.embed_res_fn.desc.n_levels)
+                if mode not in ("auto", "levels", "replicas"):
+                    raise _lib.RfxError(f"mapping.shard_field: {mode!r}")
+                if mode == "levels" or (mode == "auto" and 1 < sh.world <= levels == 16):
+                    self._direct = LevelShardedIterations(self, sh.dist, sh.rank, sh.world)
+                else:
+                    self._direct = ShardedIterations(self, sh.dist, sh.rank, sh.world)
             else:
                 self._direct = DirectIterations(self) if DirectIterations.supported(self) else False
         return self._direct or None
@@ -333,14 +343,25 @@ class Mapper:
             self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
         self._meshes_in_loop(current_map_id, batch)
 
+    def sync_field(self):
+        """collective on a sharded scene (every rank calls it): make this rank's copy of the hash table whole again before
+        something reads all of it -- meshing, rendering, a checkpoint.  A no-op elsewhere."""
+        d = getattr(self, "_direct", None)
+        if d and getattr(d, "stale", False):
+            d.sync_table()
+
     def _meshes_in_loop(self, idx: int, batch):
         """the mesh exports the reference makes inside its loop (:908-918): a mesh per `video.save_freq` frames when a video is
         recorded, and one per `mesh.vis` frames unless mesh.only_final (BASELINE config 5: a marching-cubes mesh per
         keyframe = mesh.vis: keyframe_every, only_final: 0).  On a sharded scene every rank holds the same field: rank 0 writes."""
         cfg = self.config
         sh = getattr(self, "scene_shard", None)
-        if sh is not None and sh.rank != 0:
-            return
+        mesh_now = (cfg["video"]["save"] and idx % cfg["video"]["save_freq"] == 0) or (idx % cfg["mesh"]["vis"] == 0 and not cfg["mesh"]["only_final"])
+        if sh is not None:
+            if mesh_now:
+                self.sync_field()           # every rank: rank 0 is about to read the whole table
+            if sh.rank != 0:
+                return
         if cfg["video"]["save"] and idx % cfg["video"]["save_freq"] == 0:
             self.last_mesh = self.slam.save_mesh(idx, voxel_size=0.075)
         if idx % cfg["mesh"]["vis"] == 0:

@@ -1,5 +1,20 @@
 """Bundle-adjustment iterations of ONE scene on several GPUs.
 
+Two ways of spreading the residual field, chosen by ``mapping.shard_field`` ("auto" = levels):
+
+``LevelShardedIterations`` (round 4, the default): the hash table is PARTITIONED BY LEVEL.  Rank q keeps a contiguous range
+of the 16 levels -- it alone looks them up, accumulates their gradient, evaluates their share of the TV term and takes their
+Adam step -- for every sample point of the iteration; each rank runs the decoder on a contiguous share of the rays.  What
+travels is per-point rows: 8 B per point and level of features before the decoder (all-to-all), the same of feature
+gradients after it (all-to-all), 21 KB of decoder gradients and 64 B of loss sums (all-reduce); in the pose phase also 12 B
+per point of d loss / d x and the pose gradients.  No table-sized buffer is ever exchanged, and the scatter -- the largest
+stage of an iteration at T >= 2^19 -- is divided over the ranks instead of repeated on each.  The iteration is issued as four
+library calls (rfx_ba_shard_lookup / _render / _scatter / _pose: the fused launches of the single-GPU call) with the
+collectives between them.
+
+``ShardedIterations`` (round 3, ``mapping.shard_field: replicas``): the table replicated, its dense gradient all-reduced.
+
+Below: the replicated form.
 The residual field, the decoder and the global explicit volume are replicated; an iteration's ray batch is the SAME
 on every rank (same seeds, same device random draws, so it is the batch the single-GPU run would take) and rank r
 renders the rays r, r + world, r + 2 world, ...  Two exchanges make the step identical to the single-GPU one:
@@ -24,7 +39,7 @@ import torch
 
 from .. import _lib
 from .._lib import check, stream_ptr
-from ..dist import all_reduce_sum_
+from ..dist import all_reduce_sum_, all_to_all_rows_, broadcast_, level_exchange_splits, level_partition
 from .direct import DirectIterations, _StageBuffers
 
 
@@ -174,3 +189,112 @@ class ShardedIterations(DirectIterations):
         for w, g in zip(params, grads):
             w.grad = g
         return B.t.lc
+
+
+class LevelShardedIterations(DirectIterations):
+    """one scene on `world` GPUs with the hash table partitioned by level (module docstring; include/rfx.h: rfx_ba_shard).
+    The reference has no counterpart (single GPU); the iteration reproduced is mp_slam/mapper.py:392-423 / :470-505."""
+
+    def __init__(self, mapper, dist, rank: int, world: int):
+        super().__init__(mapper)
+        self.dist, self.rank, self.world = dist, int(rank), int(world)
+        enc = self.model.embed_res_fn
+        self.cuts = level_partition(enc.desc, self.world)
+        F = int(enc.desc.n_feat)
+        lo_l, hi_l = self.cuts[self.rank], self.cuts[self.rank + 1]
+        self.k_own = hi_l - lo_l
+        # the own levels' part of the flat table (and of its gradient, and of the Adam state): one contiguous range
+        self.slices = [(int(enc.desc.offset[self.cuts[q]]) * F,
+                        (int(enc.desc.offset[self.cuts[q + 1] - 1]) + int(enc.desc.size[self.cuts[q + 1] - 1])) * F) for q in range(self.world)]
+        self.own_slice = self.slices[self.rank]
+        opt = self.mp.map_optimizer
+        if not hasattr(opt, "slices"):
+            raise _lib.RfxError("the level-partitioned field needs remixfusion_amd.optim.Adam (it steps the own levels only)")
+        opt.slices[enc.params] = self.own_slice
+        self._x = None                  # exchange buffers
+        self._shard = None
+        self.stale = False              # other ranks' levels of the local table copy are out of date
+        self.exchanged_bytes = 0        # received by this rank, summed over the iterations issued
+        self.last_exchange = {}
+
+    def _stagewise_now(self) -> bool:
+        self._count += 1
+        return False                    # always the four fused phases
+
+    def _field(self, clamp):
+        return self.model._field_desc(clamp, partitioned_ok=True)
+
+    # -- exchange buffers and the rfx_ba_shard descriptor
+    def _exchange(self, B, n, S, dev):
+        X = self._x
+        cap = B.cap_n
+        if X is None or X["cap"] < cap or X["S"] != S:
+            f32 = dict(dtype=torch.float32, device=dev)
+            m_cap = cap // self.world + 1
+            X = self._x = {"cap": cap, "S": S,
+                           "feat_send": torch.empty(cap * S * 2 * self.k_own, **f32), "feat_recv": torch.empty(m_cap * S * 32, **f32),
+                           "demb_send": torch.empty(m_cap * S * 32, **f32), "demb_recv": torch.empty(cap * S * 2 * self.k_own, **f32),
+                           "dx_send": torch.empty(cap * S * 3, **f32), "dx_recv": torch.empty(self.world * m_cap * S * 3, **f32),
+                           "sums8": torch.zeros(8, dtype=torch.float64, device=dev), "n": None}
+            sh = self._shard = _lib.BaShard()
+            sh.rank, sh.world = self.rank, self.world
+            for q in range(self.world + 1):
+                sh.level_start[q] = self.cuts[q]
+            for k in ("feat_send", "feat_recv", "demb_send", "demb_recv", "dx_send", "dx_recv"):
+                setattr(sh, k, X[k].data_ptr())
+            sh.loss_sums8 = X["sums8"].data_ptr()
+        if X["n"] != n:
+            sp = level_exchange_splits(n, S, self.cuts, self.rank)      # element counts of the all-to-alls: (to rank q, from rank q)
+            for q in range(self.world + 1):
+                self._shard.ray_start[q] = sp["rays"][q]
+            X.update(n=n, m=sp["m"], feat=sp["feat"], demb=sp["demb"], dx=sp["dx"])
+        return X
+
+    def _run(self, B, current_rays, poses_ptr, K, clamp, d_poses_ptr, st, map_grads=True, rba=None):
+        lib, dist = self.lib, self.dist
+        self._fill(B, current_rays, poses_ptr, K, clamp, d_poses_ptr, map_grads, None)      # (the pose MLP's backward follows the all-reduce)
+        d, dref = self._descs[clamp][1], self._descs[clamp][2]
+        n, S = B.n, B.S
+        X = self._exchange(B, n, S, B.t.u.device)
+        sref = C.byref(self._shard)
+        ws, wb = B.p.ws, B.ws_bytes
+        check(lib.rfx_ba_shard_lookup(dref, sref, ws, wb, st), "rfx_ba_shard_lookup")
+        all_to_all_rows_(dist, X["feat_recv"], X["feat"][1], X["feat_send"], X["feat"][0])
+        check(lib.rfx_ba_shard_render(dref, sref, ws, wb, st), "rfx_ba_shard_render")
+        all_to_all_rows_(dist, X["demb_recv"], X["demb"][1], X["demb_send"], X["demb"][0])
+        small = [X["sums8"]]
+        if map_grads:
+            small.append(B.t.dw_flat)
+            if self.report_tv:
+                small.append(B.t.tv_acc)
+        all_reduce_sum_(dist, small)
+        check(lib.rfx_ba_shard_scatter(dref, sref, ws, wb, st), "rfx_ba_shard_scatter")
+        recv = 4 * (sum(X["feat"][1]) - X["feat"][1][self.rank] + sum(X["demb"][1]) - X["demb"][1][self.rank])      # bytes from OTHER ranks
+        if d_poses_ptr:
+            all_to_all_rows_(dist, X["dx_recv"], X["dx"][1], X["dx_send"], X["dx"][0])
+            check(lib.rfx_ba_shard_pose(dref, sref, ws, wb, st), "rfx_ba_shard_pose")
+            all_reduce_sum_(dist, [B.t.dposes[:K]])
+            recv += 4 * (sum(X["dx"][1]) - X["dx"][1][self.rank])
+            if rba is not None:
+                check(lib.rfx_rba_backward(C.byref(rba[0]), rba[1], K, d_poses_ptr, rba[2], C.byref(rba[3]), rba[4], st), "rfx_rba_backward")
+        # the four losses of the WHOLE batch (and the coefficients the backward used, re-derived from the summed counts)
+        check(lib.rfx_mapping_loss_finalize(X["sums8"].data_ptr(), n, S, B.p.lc, B.p.lc + 16, st), "rfx_mapping_loss_finalize")
+        self.last_exchange = {"recv_bytes": recv, "points": n * S, "rays_own": X["m"]}
+        self.exchanged_bytes += recv
+        if map_grads:
+            self.stale = True
+            self.model.embed_res_fn.partition_stale = True
+
+    # -- the whole table on every rank again (meshing, rendering, checkpoints: whatever reads all 16 levels of one point)
+    def sync_table(self, with_optimizer_state: bool = False):
+        enc = self.model.embed_res_fn
+        with torch.no_grad():
+            tensors = [enc.params.data]
+            if with_optimizer_state:
+                stt = self.mp.map_optimizer.state.get(enc.params, {})
+                tensors += [stt[k] for k in ("exp_avg", "exp_avg_sq") if k in stt]
+            for t in tensors:
+                for q, (lo, hi) in enumerate(self.slices):
+                    broadcast_(self.dist, t[lo:hi], q)
+        self.stale = False
+        enc.partition_stale = False

@@ -19,6 +19,9 @@ class Adam(torch.optim.Adam):
         kw.pop("fused", None)
         kw.pop("foreach", None)
         self._views = {}                # parameter -> (its state's `step` tensor, numpy view of it)
+        # parameter -> (lo, hi): only the elements [lo, hi) of it are stepped (state tensors stay full-size).  A hash table
+        # partitioned by level over several GPUs: each rank steps the levels it keeps (mp_slam/sharded.py).
+        self.slices = {}
         super().__init__(params, **kw)
 
     def _patch_step_function(self) -> None:
@@ -33,6 +36,8 @@ class Adam(torch.optim.Adam):
                     or getattr(_o, "_global_optimizer_pre_hooks", None) or getattr(_o, "_global_optimizer_post_hooks", None))
 
     def _native(self) -> bool:
+        if self.slices and not all(p.is_cuda for p in self.slices):
+            raise _lib.RfxError("a sliced Adam step needs device parameters (there is no CPU path)")
         for g in self.param_groups:
             if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
                 return False
@@ -86,8 +91,10 @@ class Adam(torch.optim.Adam):
                 k = int(ent[1].item()) + 1
                 ent[1][...] = k
                 bc1, bc2 = 1.0 - b1 ** k, 1.0 - b2 ** k
-                t = _lib.AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                    b1, b2, 1.0 - b1, 1.0 - b2, g["eps"], g["weight_decay"], -(g["lr"] / bc1), math.sqrt(bc2))
+                lo, hi = self.slices.get(p, (0, p.numel()))
+                o = 4 * lo
+                t = _lib.AdamTensor(p.data_ptr() + o, p.grad.data_ptr() + o, st["exp_avg"].data_ptr() + o, st["exp_avg_sq"].data_ptr() + o,
+                                    hi - lo, b1, b2, 1.0 - b1, 1.0 - b2, g["eps"], g["weight_decay"], -(g["lr"] / bc1), math.sqrt(bc2))
                 per_device.setdefault(p.device, []).append(t)
         for dev, ts in per_device.items():
             stream = _lib.stream_ptr(dev)

@@ -56,5 +56,5 @@ def small_frame(H=120, W=160, seed=0, frame=0, name="office0"):
     cfg["synthetic"]["seed"] = 20251205 + seed
     ds = get_dataset(cfg, n_frames=frame + 1)
     b = ds[frame]
-    rgb255 = np.floor(b["rgb"].numpy() * 255.0 + 0.5).astype(np.float32)
+    rgb255 = np.floor(b["rgb"].numpy() * 255.0).astype(np.float32)      # the reference's quantisation (model/ROtracker.py:82), as pipeline.py
     return ds.K(), b["c2w"].numpy(), rgb255, b["depth"].numpy(), b["rgb"].numpy()

@@ -41,6 +41,22 @@ def test_bench_two_ranks_reports_one_scene_as_the_headline():
     assert "ONE scene on 2 GPUs" in d["config"]["workload"] and "2 x-slabs" in d["config"]["workload"]
     assert d["roofline"] is not None and d["cpu_baseline"] is None and "error" not in d
     assert d["iterations_timed"]["map"] > 0
+    # the same scene on one GPU, measured in the same run, and what an iteration moved between the ranks
+    n1 = d["n1_same_workload"]
+    assert n1["n_gpus"] == 1 and n1["value"] > 0 and abs(d["speedup_vs_n1_same_workload"] - d["value"] / n1["value"]) < 2e-3
+    ex = d["exchange"]
+    assert ex["field"] == "levels" and 0 < ex["recv_bytes_per_iteration_rank0_mean"] < 12e6
+    assert ex["recv_bytes_per_iteration_model"]["levels"] < ex["recv_bytes_per_iteration_model"]["replicas"]
+    assert d["metric"] == "RGB-D frames/sec mapping (640x480, 1cm TSDF)"          # office0's camera and voxel size
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_replicated_field_still_runs():
+    res = _torchrun(["--steps", "6", "--warmup", "5", "--first-iters", "5", "--sharded-config", "office0", "--shard-field", "replicas",
+                     "--no-n1"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d["exchange"]["field"] == "replicas" and d["n1_same_workload"] is None and d["value"] > 0
 
 
 @pytest.mark.timeout(900)

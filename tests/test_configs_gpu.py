@@ -78,7 +78,7 @@ def test_moving_volume_sizes_of_configs_4_and_5(name):
     mv = moving_volume(cfg, Trajectory(), ds.poses[0].numpy().astype(np.float64))
     dims = tuple(int(v) for v in mv.vol_dim)
     assert dims == {"cafeteria": (700, 700, 300), "apartment": (1600, 1600, 600)}[name]
-    rgb255 = torch.floor(b["rgb"] * 255.0 + 0.5)
+    rgb255 = torch.floor(b["rgb"] * 255.0)
     mv.integrate(rgb255, b["depth"], ds.K(), b["c2w"].numpy(), None)
     n = int(np.prod(dims))
     vol = [np.ones(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)]

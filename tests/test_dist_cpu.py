@@ -120,3 +120,103 @@ def test_collective_helpers_world2(tmp_path):
         assert torch.equal(c["d"], torch.full((8,), 1.5, dtype=torch.float64))
         assert torch.equal(c["f"], torch.full((4,), 3.0))
         assert torch.equal(c["big"], torch.arange(70000, dtype=torch.float32) * 3)
+
+
+# ---- the hash table partitioned by level (mp_slam/sharded.py::LevelShardedIterations): host logic and the exchange protocol
+def _hash_desc(name):
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.encodings import make_grid_desc
+    cfg = synthetic_config(name)
+    b = np.array(cfg["mapping"]["bound"], dtype=np.float64)
+    R = int((b[:, 1] - b[:, 0]).max() / cfg["grid"]["voxel_sdf"])
+    pls = np.exp2(np.log2(R / 16) / 15)
+    return make_grid_desc(16, 2, cfg["grid"]["hash_size"], 16, pls, True)[0]
+
+
+def test_level_partition_is_contiguous_complete_and_optimal():
+    import itertools
+    from remixfusion_amd.dist import level_costs, level_partition, ray_partition
+    for name in ("office0", "scene0000", "cafeteria", "apartment"):
+        desc = _hash_desc(name)
+        cost = level_costs(desc)
+        assert len(cost) == 16 and (name == "office0") == all(c == 1.0 for c in cost)      # T = 2^16: no binned level
+        for world in range(1, 17):
+            cuts = level_partition(desc, world)
+            assert cuts[0] == 0 and cuts[-1] == 16 and len(cuts) == world + 1
+            assert all(b > a for a, b in zip(cuts[:-1], cuts[1:]))                           # every rank keeps at least one level
+            got = max(sum(cost[a:b]) for a, b in zip(cuts[:-1], cuts[1:]))
+            if world <= 4:                                                                   # brute force: the smallest possible maximum
+                best = min(max(sum(cost[a:b]) for a, b in zip((0,) + c, c + (16,))) for c in itertools.combinations(range(1, 16), world - 1))
+                assert abs(got - best) < 1e-9, (name, world, cuts)
+    with __import__("pytest").raises(ValueError):
+        level_partition(_hash_desc("office0"), 17)
+    assert ray_partition(2304, 4) == [0, 576, 1152, 1728, 2304]
+    r = ray_partition(2148, 8)
+    assert r[0] == 0 and r[-1] == 2148 and max(b - a for a, b in zip(r[:-1], r[1:])) - min(b - a for a, b in zip(r[:-1], r[1:])) <= 1
+
+
+def test_field_exchange_model_prefers_level_rows_to_the_dense_gradient():
+    """bytes a rank receives per map iteration at cafeteria sizes (T = 2^21, 2 148 rays x 59 + 63^3 lattice)"""
+    from remixfusion_amd.dist import field_exchange_model
+    desc = _hash_desc("cafeteria")
+    mdl = field_exchange_model(desc, 2148 * 59, 63 ** 3, 4)
+    assert 160e6 < mdl["table_bytes"] < 170e6
+    assert mdl["replicas"]["recv_bytes"] > 240e6                     # 2 (N-1)/N of 166 MB
+    assert mdl["levels"]["recv_bytes"] < 7e6                         # 2 x 3/4 x (1.27e5 / 4) x 128 B
+    assert mdl["points"]["recv_bytes"] < mdl["replicas"]["recv_bytes"] and mdl["points"]["scatter_share"] == 1.0
+    assert mdl["levels"]["scatter_share"] < 0.32 < 0.7 < mdl["replicas"]["scatter_share"]      # the lattice alone is 2/3 of the replicas' rank 0
+    assert mdl["levels"]["recv_bytes"] < mdl["points"]["recv_bytes"]
+
+
+def _worker_level_exchange(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from remixfusion_amd.dist import all_to_all_rows_, level_exchange_splits, level_partition
+    n, S = 37, 5                                   # rays do not divide by the world: uneven shares
+    cuts = level_partition(_hash_desc("scene0000"), world)
+    sp = level_exchange_splits(n, S, cuts, rank)
+    rs, m, k = sp["rays"], sp["m"], cuts[rank + 1] - cuts[rank]
+    pt = torch.arange(n * S, dtype=torch.float32)
+    # ---- features out: feat_send[p, 2 j + c] of the own level cuts[rank] + j encodes (point, level, component)
+    lv = torch.arange(cuts[rank], cuts[rank + 1], dtype=torch.float32)
+    feat_send = (pt[:, None, None] * 1000 + lv[None, :, None] * 10 + torch.arange(2.0)[None, None, :]).reshape(n * S, 2 * k)
+    feat_recv = torch.full((m * S * 32,), -1.0)
+    all_to_all_rows_(dist, feat_recv, sp["feat"][1], feat_send.reshape(-1), sp["feat"][0])
+    ok = True
+    for q in range(world):                         # the addressing rfx_ba_shard_render uses (csrc/rfx_ba.hip: shard_rows)
+        a, e = cuts[q], cuts[q + 1]
+        blk = feat_recv[m * S * 2 * a: m * S * 2 * e].view(m * S, 2 * (e - a))
+        for l in range(a, e):
+            for c in range(2):
+                want = (pt[rs[rank] * S: rs[rank + 1] * S] * 1000 + l * 10 + c)
+                ok &= bool(torch.equal(blk[:, 2 * (l - a) + c], want))
+    # ---- gradients back: demb_send block q [m S, 2 k_q] encodes (own point, level of q, component)
+    own_pt = pt[rs[rank] * S: rs[rank + 1] * S]
+    blocks = []
+    for q in range(world):
+        lq = torch.arange(cuts[q], cuts[q + 1], dtype=torch.float32)
+        blocks.append((own_pt[:, None, None] * 1000 + lq[None, :, None] * 10 + torch.arange(2.0)[None, None, :] + 0.5).reshape(-1))
+    demb_recv = torch.full((n * S * 2 * k,), -1.0)
+    all_to_all_rows_(dist, demb_recv, sp["demb"][1], torch.cat(blocks), sp["demb"][0])
+    ok &= bool(torch.equal(demb_recv.view(n * S, 2 * k), feat_send + 0.5))          # all points, own levels, point order
+    # ---- pose phase: every rank's partial d loss / d x01 of the own points, in rank order
+    dx_send = (pt[:, None] * 10 + torch.arange(3.0)[None, :] + 100000.0 * rank).reshape(-1)
+    dx_recv = torch.full((world * m * S * 3,), -1.0)
+    all_to_all_rows_(dist, dx_recv, sp["dx"][1], dx_send, sp["dx"][0])
+    for q in range(world):
+        want = (own_pt[:, None] * 10 + torch.arange(3.0)[None, :] + 100000.0 * q).reshape(-1)
+        ok &= bool(torch.equal(dx_recv[q * m * S * 3:(q + 1) * m * S * 3], want))
+    torch.save({"ok": ok, "m": m, "cuts": cuts}, os.path.join(out_dir, f"x{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_exchange_protocol_world3(tmp_path):
+    """the three all-to-alls of a level-partitioned iteration on 3 gloo ranks (uneven ray shares and level ranges): every
+    (point, level) lands where the phases of csrc/rfx_ba.hip read it"""
+    world = 3
+    mp.spawn(_worker_level_exchange, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"x{r}.pt")) for r in range(world)]
+    assert all(r["ok"] for r in res)
+    assert sum(r["m"] for r in res) == 37 and res[0]["cuts"] == res[2]["cuts"]

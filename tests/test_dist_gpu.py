@@ -11,9 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _small_cfg(version="center"):
+def _small_cfg(version="center", shard_field="auto"):
     from remixfusion_amd.config import synthetic_config
     cfg = synthetic_config("office0")
+    cfg["mapping"]["shard_field"] = shard_field
     cfg["volume"]["version"] = version
     if version == "more":      # the layout the reference's 'more' logic is written for: one axis fixed to a range (no shipped config
         cfg["volume"]["z_config"] = {"fix": 1, "len": 3, "range": [-3, 3]}     # selects 'more'; without a fixed axis it leaves z empty)
@@ -87,6 +88,8 @@ def _run(pipe, frames, out):
     poses = pipe.slam.est_c2w_data[0:N_FRAMES:pipe.config["mapping"]["keyframe_every"]].clone()
     losses.append(d.map_gradients(rays, poses).clone().cpu())
     pipe.slam.map_optimizer.step()
+    pipe.mapper.sync_field()                     # (sharded scene, table partitioned by level: whole again on every rank)
+    out["mode"] = type(d).__name__
     out["losses"] = torch.stack(losses)
     out["hash"] = pipe.model.embed_res_fn.params.detach().cpu().clone()
     out["w1"] = pipe.model.decoder_res.fused_weights()[0].detach().cpu().clone()
@@ -114,14 +117,14 @@ def _run(pipe, frames, out):
         out["bnds_more"] = np.array(pipe.mv.vol_bnds)
 
 
-def _worker(rank, world, port, out_dir, version):
+def _worker(rank, world, port, out_dir, version, shard_field="auto"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from remixfusion_amd.dist import ShardedPipeline
-    pipe = ShardedPipeline(_small_cfg(version), dist, rank, world, n_frames=N_FRAMES + 4, seed=5)
+    pipe = ShardedPipeline(_small_cfg(version, shard_field), dist, rank, world, n_frames=N_FRAMES + 4, seed=5)
     frames = pipe.prefetch(list(range(N_FRAMES)))
     out = {}
     _run(pipe, frames, out)
@@ -134,13 +137,13 @@ def _worker(rank, world, port, out_dir, version):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("version", ["center", "more"])
-def test_sharded_scene_world2_equals_single_gpu(tmp_path, version):
+@pytest.mark.parametrize("version,shard_field", [("center", "levels"), ("center", "replicas"), ("more", "levels")])
+def test_sharded_scene_world2_equals_single_gpu(tmp_path, version, shard_field):
     import torch
     import torch.multiprocessing as mp
     from remixfusion_amd.pipeline import MappingPipeline
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), version), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), version, shard_field), nprocs=world, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world))
     # ---- the single-GPU run
     pipe = MappingPipeline(_small_cfg(version), n_frames=N_FRAMES + 4, seed=5)
@@ -158,7 +161,9 @@ def test_sharded_scene_world2_equals_single_gpu(tmp_path, version):
         assert torch.equal(r0["mv"][k], mv[k]), name
         assert torch.equal(r1["mv"][k], mv[k]), name
     assert float((mv[1] > 0).float().mean()) > 0.01
-    # replicas identical to each other (all-reduced gradients, same Adam step): bit for bit
+    assert r0["mode"] == r1["mode"] == ("LevelShardedIterations" if shard_field == "levels" else "ShardedIterations")
+    # the two ranks' fields identical to each other (levels: each level has ONE owner, copies synchronised; replicas:
+    # all-reduced gradients, same Adam step): bit for bit
     for key in ("hash", "w1", "gbv", "poses", "losses"):
         assert torch.equal(r0[key], r1[key]), key
     # ... and equal to the single-GPU run up to the order of floating-point sums (atomics, all-reduce)

@@ -2,12 +2,13 @@
 
 cafeteria (config 4: BS3D sizes -- 1280x720, moving volume 700x700x300 @ 2 cm, hash table 2^21, 63^3 TV lattice) and apartment
 (config 5: uHumans2 sizes at 1 cm -- 720x480, 1600x1600x600 = 1.5e9 voxels, S = 117, 10 map iterations, a marching-cubes mesh
-per keyframe) run through ``ShardedPipeline`` on 4 ranks -- four processes on this one GPU, gloo rendezvous on 127.0.0.1,
+per keyframe) run through ``ShardedPipeline`` on 4 and 6 ranks -- that many processes on this one GPU, gloo rendezvous on 127.0.0.1,
 device tensors staged through the host (the pool hands out 1-GPU boxes; with backend "nccl" the same code runs one rank per
 GPU over RCCL) -- for two mapper steps and a volume move across the slab cuts, then once more in a single process:
 
   * moving volume: every rank's x-slab bit-identical to the same planes of the single-process volume (exact digests),
-  * field / decoder / global volume replicas bit-identical across the ranks,
+  * the hash table partitioned by level (mp_slam/sharded.py: per-point rows exchanged, never the table); after
+    ``Mapper.sync_field()`` every rank holds the same table, decoder and global volume, bit for bit,
   * losses within the noise of float atomics of the single-process run,
   * config 5: the per-keyframe mesh hook of the reference's loop (mp_slam/mapper.py:908-918) produced a mesh on rank 0.
 """
@@ -20,8 +21,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 N_FRAMES = 12
-WORLD = 4
-FAR_POSE_DX = 1.4
+WORLDS = {"cafeteria": 4, "apartment": 6}       # BASELINE asks 4 and 8; a GPU box admits at most 6 processes on its card (gpurun's
+FAR_POSE_DX = 1.4                               # process guard), so config 5 runs on 6: uneven slabs (1600 planes) and level ranges (16)
 
 
 def _cfg(name):
@@ -54,6 +55,9 @@ def _run(pipe, frames, out, tmp):
     rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], -1).reshape(-1, 7).to(pipe.device)
     poses = pipe.slam.est_c2w_data[0:N_FRAMES:pipe.config["mapping"]["keyframe_every"]].clone()
     out["losses"] = d.map_gradients(rays, poses).clone().cpu()
+    out["mode"] = type(d).__name__
+    out["recv_bytes"] = getattr(d, "last_exchange", {}).get("recv_bytes")
+    pipe.mapper.sync_field()                     # collective on a sharded scene: every rank's copy of the table whole again
     out["mapping_idx"] = int(pipe.slam.mapping_idx[0])
     out["hash"] = _digest(pipe.model.embed_res_fn.params.detach())
     out["w1"] = _digest(pipe.model.decoder_res.fused_weights()[0].detach())
@@ -108,10 +112,11 @@ def _worker(rank, world, port, out_dir, name):
 
 @pytest.mark.timeout(2400)
 @pytest.mark.parametrize("name", ["cafeteria", "apartment"])
-def test_config_runs_sharded_over_four_ranks_and_equals_the_single_process_run(name, tmp_path):
+def test_config_runs_sharded_over_several_ranks_and_equals_the_single_process_run(name, tmp_path):
     import torch
     import torch.multiprocessing as mp
     from remixfusion_amd.pipeline import MappingPipeline
+    WORLD = WORLDS[name]
     mp.spawn(_worker, args=(WORLD, _free_port(), str(tmp_path), name), nprocs=WORLD, join=True)
     rs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(WORLD)]
     # ---- the single-process run of the same stream
@@ -129,13 +134,16 @@ def test_config_runs_sharded_over_four_ranks_and_equals_the_single_process_run(n
         for k, (t, nm) in enumerate(zip(pipe.mv._vols(), ("tsdf", "weight", "colour"))):
             assert _digest(t[x0 * plane:x1 * plane]) == tuple(r["mv"][k]), (nm, x0, x1)
     assert sum(r["mv_w_pos"] for r in rs) > 0
-    for key in ("hash", "w1", "gbv"):                                                      # replicas bit-identical
+    assert all(r["mode"] == "LevelShardedIterations" for r in rs)                          # the table partitioned by level
+    for key in ("hash", "w1", "gbv"):                                                      # after sync_field: copies bit-identical
         assert all(tuple(r[key]) == tuple(rs[0][key]) for r in rs), key
+    # what an iteration moves between the ranks: per-point rows, not the table (161 / 166 MB of gradient at T = 2^21)
+    assert all(r["recv_bytes"] is not None and r["recv_bytes"] < 24e6 for r in rs), [r["recv_bytes"] for r in rs]
     assert all(torch.equal(r["losses"], rs[0]["losses"]) for r in rs)
     assert tuple(rs[0]["gbv"]) == ref["gbv"]                                               # deterministic kernel, same keyframes
     dl = (rs[0]["losses"][:4] - ref["losses"][:4]).abs() / ref["losses"][:4].abs().clamp_min(1e-12)
     print(f"{name}: sharded vs single loss rel {float(dl.max()):.2e}; mesh faces {rs[0]['mesh_faces']} / {ref['mesh_faces']}")
-    assert float(dl.max()) < 2e-3
+    assert float(dl.max()) < 1e-5                # (the field's features and the decoder see the same bits; the sums are grouped by rank)
     # halo read: every rank returns the single-process records, bit for bit
     g = torch.Generator().manual_seed(3)
     b = torch.from_numpy(np.array(pipe.mv.vol_bnds)).float()
