@@ -380,6 +380,9 @@ def run_one_scene(args, dist, rank, world, device, timer):
     exchange = {"field": "levels" if levels else "replicas", "rays_per_iteration": n_rays, "points_per_iteration": n_rays * S,
                 "recv_bytes_per_iteration_model": {k: int(model[k]["recv_bytes"]) for k in ("replicas", "points", "levels")},
                 "scatter_share_of_one_gpu_model": {k: round(model[k]["scatter_share"], 3) for k in ("replicas", "points", "levels")}}
+    choice = getattr(pipe.mapper, "field_mode_choice", None)
+    if choice is not None:
+        exchange["auto_choice_estimated_us"] = {k: round(v * 1e6, 1) for k, v in choice["estimated_seconds"].items()}
     if levels:
         exchange["rays_own"], exchange["k_own"], exchange["n_lattice"] = direct.last_exchange.get("rays_own"), direct.k_own, P3
         exchange["recv_bytes_last_iteration_rank0"] = direct.last_exchange.get("recv_bytes")

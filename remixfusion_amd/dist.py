@@ -286,6 +286,40 @@ def field_exchange_model(desc, n_points: int, n_lattice: int, world: int, select
     }
 
 
+# constants of the time model below (one MI355X node): what a rank can receive per second over xGMI under a collective
+# (7 links x ~50 GB/s per direction; ring all-reduce and direct all-to-all both priced at a conservative 60 GB/s), the fixed
+# cost of one small collective, and the single-GPU scatter's cost per (point, unit of level cost) -- 78 us for office0's
+# 1.6e5 points x 16 units, 570 us for cafeteria's 3.8e5 x 47.2 (profiles/r3_notes.md): 31 ps either way.
+XGMI_RECV_BYTES_PER_S = 60e9
+COLLECTIVE_LATENCY_S = 30e-6
+SCATTER_S_PER_POINT_UNIT = 31e-12
+DECODER_S_PER_POINT = 0.93e-9          # forward + backward chain + weight gradients: 47 + 39 + 41 us at 1.36e5 points
+ITERATION_FIXED_S = 50e-6              # the kernel boundaries of one iteration (9-12 launches)
+
+
+def choose_field_mode(desc, n_points: int, n_lattice: int, world: int) -> Dict:
+    """mapping.shard_field = auto: the cheaper of "replicas" and "levels" by estimated time per map iteration spent on what
+    differs between them -- exchange (bytes / link rate + a latency per collective: 2 against 3) + the rank's share of the
+    scatter.  Small tables (office0: 6.6 MB, below the per-point rows of two all-to-alls at N = 2) keep the all-reduce;
+    from T = 2^19 on the level partition wins by an order of magnitude.  "points" (all-gather of point gradients, every rank
+    scattering all of them) is priced for the record: it never beats "levels", whose exchange is smaller and whose scatter
+    is divided."""
+    mdl = field_exchange_model(desc, n_points, n_lattice, world)
+    units = sum(level_costs(desc))
+    t_scatter = (n_points + n_lattice) * units * SCATTER_S_PER_POINT_UNIT
+    est = {}
+    for mode, n_coll in (("replicas", 2), ("points", 2), ("levels", 3)):
+        est[mode] = mdl[mode]["recv_bytes"] / XGMI_RECV_BYTES_PER_S + n_coll * COLLECTIVE_LATENCY_S + mdl[mode]["scatter_share"] * t_scatter
+    ok_levels = 1 < world <= int(desc.n_levels) == 16
+    mode = "levels" if ok_levels and est["levels"] <= est["replicas"] else "replicas"
+    # whole map iteration, one GPU against N: the decoder's share divides by N in every mode; the sharded forms pay half as
+    # many kernel boundaries again (the phases between the collectives)
+    t_one = t_scatter + n_points * DECODER_S_PER_POINT + ITERATION_FIXED_S
+    t_iter = {k: v + n_points * DECODER_S_PER_POINT / world + 1.5 * ITERATION_FIXED_S for k, v in est.items()}
+    return {"mode": mode, "estimated_seconds": est, "single_gpu_scatter_seconds": t_scatter, "model": mdl,
+            "iteration_seconds_one_gpu": t_one, "iteration_seconds": t_iter}
+
+
 def shift_plan(cuts: List[int], need: List) -> List:
     """who sends which old x-planes to whom when the volume moves: need[r] = (a_r, b_r) are the old planes rank r's new
     slab reads; cuts are the (unchanged) slab boundaries of the old volume.  Returns [(src, dst, p0, p1)] with src != dst,

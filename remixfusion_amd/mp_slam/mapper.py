@@ -293,10 +293,16 @@ class Mapper:
                 # mapping.shard_field: "levels" (hash table partitioned by level: per-point rows travel), "replicas" (table
                 # replicated, dense gradient all-reduced), "auto" = levels whenever the table has a level per rank
                 mode = str(self.config["mapping"].get("shard_field", "auto"))
-                levels = int(self.model.embed_res_fn.desc.n_levels)
                 if mode not in ("auto", "levels", "replicas"):
                     raise _lib.RfxError(f"mapping.shard_field: {mode!r}")
-                if mode == "levels" or (mode == "auto" and 1 < sh.world <= levels == 16):
+                if mode == "auto":          # the cheaper of the two by the time model of dist.choose_field_mode
+                    from ..dist import choose_field_mode
+                    m, tr = self.config["mapping"], self.config["training"]
+                    n_rays = int(m["sample"]) + max(int(m["sample"]) // 8, int(m["min_pixels_cur"]))
+                    S, P = int(tr["n_range_d"]) + int(tr["n_samples_d"]), int(tr["smooth_pts"]) - 1
+                    self.field_mode_choice = choose_field_mode(self.model.embed_res_fn.desc, n_rays * S, P ** 3, sh.world)
+                    mode = self.field_mode_choice["mode"]
+                if mode == "levels":
                     self._direct = LevelShardedIterations(self, sh.dist, sh.rank, sh.world)
                 else:
                     self._direct = ShardedIterations(self, sh.dist, sh.rank, sh.world)
