@@ -142,8 +142,16 @@ def test_config_runs_sharded_over_several_ranks_and_equals_the_single_process_ru
     assert all(torch.equal(r["losses"], rs[0]["losses"]) for r in rs)
     assert tuple(rs[0]["gbv"]) == ref["gbv"]                                               # deterministic kernel, same keyframes
     dl = (rs[0]["losses"][:4] - ref["losses"][:4]).abs() / ref["losses"][:4].abs().clamp_min(1e-12)
-    print(f"{name}: sharded vs single loss rel {float(dl.max()):.2e}; mesh faces {rs[0]['mesh_faces']} / {ref['mesh_faces']}")
-    assert float(dl.max()) < 1e-5                # (the field's features and the decoder see the same bits; the sums are grouped by rank)
+    # the yardstick: the single-process run against ITSELF (a second run of the same seed).  The hash gradient is built with
+    # float atomics, so after these 20 Adam steps two single-GPU runs already differ in the last digits of the losses
+    pipe2 = MappingPipeline(_cfg(name), n_frames=N_FRAMES + 4, seed=5)
+    ref2 = {}
+    _run(pipe2, pipe2.prefetch(list(range(N_FRAMES))), ref2, os.path.join(str(tmp_path), "single2"))
+    del pipe2
+    noise = (ref2["losses"][:4] - ref["losses"][:4]).abs() / ref["losses"][:4].abs().clamp_min(1e-12)
+    print(f"{name}: sharded vs single loss rel {float(dl.max()):.2e} (single vs single: {float(noise.max()):.2e}); "
+          f"mesh faces {rs[0]['mesh_faces']} / {ref['mesh_faces']}")
+    assert float(dl.max()) < max(4.0 * float(noise.max()), 2e-5)
     # halo read: every rank returns the single-process records, bit for bit
     g = torch.Generator().manual_seed(3)
     b = torch.from_numpy(np.array(pipe.mv.vol_bnds)).float()
