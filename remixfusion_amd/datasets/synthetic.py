@@ -64,6 +64,20 @@ class SyntheticRoom:
         # two spheres: centre, radius
         self.spheres = [(ctr + ext * torch.tensor([0.22, 0.18, -0.30]), 0.16 * float(ext.min())),
                         (ctr + ext * torch.tensor([-0.25, -0.20, -0.35]), 0.12 * float(ext.min()))]
+        # synthetic.clutter = K: K more spheres (seeded) between the camera's orbit and the walls.  The plain box room is
+        # degenerate for a geometric tracker -- a translation along a flat wall changes no depth (the ROTracker slides there:
+        # tools/tracker_dbg.py) -- so the tracker's sequence tests furnish the room; 0 (every other stream) changes nothing.
+        k_extra = int(syn.get("clutter", 0))
+        if k_extra > 0:
+            rng = np.random.default_rng(self.seed + 7)
+            added = 0
+            while added < k_extra:
+                u = rng.uniform(-0.5, 0.5, 3)
+                if max(abs(u[0]), abs(u[1])) < 0.30:          # keep the orbit (|offset| <= 0.18 ext) and its surroundings free
+                    continue
+                r = float(rng.uniform(0.15, 0.45))
+                self.spheres.append((ctr + ext * torch.tensor(u, dtype=torch.float32), r))
+                added += 1
 
     def __len__(self):
         return self.num_frames

@@ -185,3 +185,52 @@ def test_config3_scene0000_mapping_with_the_tracker_on():
     assert max(errs) < 0.10
     assert bool(torch.isfinite(pipe.model.embed_res_fn.params).all()) and bool(torch.isfinite(pipe.model.GBV.params).all())
     assert float((pipe.mv.weight_vol_gpu > 0).float().mean()) > 0.01
+
+
+@pytest.mark.timeout(900)
+def test_config3_tracker_follows_a_120_frame_sequence():
+    """Sequence-level evidence for the ROTracker (reference model/ROtracker.py:713-866, mp_slam/tracker.py:55-134): 120 frames of
+    the scene0000-sized stream with the tracker on, absolute trajectory error against the synthetic ground truth (no alignment:
+    both start from the same pose).  The room is furnished (synthetic.clutter = 48 spheres): in the bare box room a translation
+    along a flat wall changes no depth and a geometric tracker slides along it (measured: 1.8 cm of every 3 cm step lost,
+    ATE 28 cm after 120 frames; tools/tracker_dbg.py), which says nothing about the tracker.  Generated search templates (the
+    reference's PST files do not travel to the GPU box; tests/test_pst_cpu.py checks the reader against their digest).
+    Measured: ATE rmse 2.2 cm, max 3.3 cm, rotation rmse 0.8 deg at 4 cm voxels."""
+    import random
+    import warnings
+    import numpy as np
+    import torch
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    N = 120
+    random.seed(0)
+    cfg = synthetic_config("scene0000")
+    cfg["synthetic"].update({"tracker": True, "depth_noise": 0.0, "dropout": 0.0, "clutter": 48})
+    cfg["mapping"]["first_iters"] = 50
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = MappingPipeline(cfg, n_frames=N + 8)
+    frames = pipe.prefetch(list(range(N)))
+    pipe.start(frames[0])
+    for i in range(1, N):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize()
+    assert int(pipe.slam.tracking_idx[0]) == N - 1 and int(pipe.slam.mapping_idx[0]) == N - 5
+    ke = cfg["mapping"]["keyframe_every"]
+    err, rot = [], []
+    for i in range(1, N):
+        est = pipe.slam.est_c2w_data[i] if i % ke == 0 else pipe.slam.est_c2w_data_rel[i] @ pipe.slam.est_c2w_data[(i // ke) * ke]
+        est, gt = est.cpu().double(), frames[i]["c2w"].double()
+        assert bool(torch.isfinite(est).all())
+        err.append(float((est[:3, 3] - gt[:3, 3]).norm()))
+        R = est[:3, :3].T @ gt[:3, :3]
+        rot.append(float(torch.rad2deg(torch.acos(((R.trace() - 1) / 2).clamp(-1, 1)))))
+    err, rot = np.array(err), np.array(rot)
+    path = sum(float((frames[i]["c2w"][:3, 3] - frames[i - 1]["c2w"][:3, 3]).norm()) for i in range(1, N))
+    rmse = float(np.sqrt((err ** 2).mean()))
+    print(f"scene0000 + tracker, {N} frames, path {path:.2f} m: ATE rmse {rmse * 100:.2f} cm, max {err.max() * 100:.2f} cm, "
+          f"final {err[-1] * 100:.2f} cm; rotation rmse {float(np.sqrt((rot ** 2).mean())):.2f} deg")
+    assert path > 1.5
+    assert rmse < 0.05 and err.max() < 0.08 and err[-1] < 0.06          # bounded, no drift: the last frame is no worse than the mean
+    assert float(np.sqrt((rot ** 2).mean())) < 2.0
+    assert bool(torch.isfinite(pipe.model.embed_res_fn.params).all())
