@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak
 MLP_FLOP_PER_POINT = 2 * (81 * 32 + 32 * 16 + 66 * 32 + 32 * 3)     # 10 624
+PMC_TRAFFIC_FILE, PMC_V1_FILE = "r4_pmc_traffic.json", "r4_pmc_v1_frame25.json"      # written by tools/r4_measure.sh
 
 
 def parse():
@@ -748,13 +749,22 @@ def main():
                     "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
                     "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # HBM traffic per launch: NOT measured by this run (PMC counters need rocprofv3 passes of their own).  The figure is
-    # taken from the committed summary of those passes, profiles/r3_pmc_traffic.json (tools/summarize_pmc.py), and tagged
-    # with the commit the passes ran at; it stays null when that file does not cover the kernel.
+    # taken from the committed summary of those passes, profiles/r4_pmc_traffic.json (tools/summarize_pmc.py), which
+    # carries the digest of the kernel sources the passes ran on (remixfusion_amd.build.sources_digest): when this tree's
+    # digest differs -- the binary timed here is not the one the counters saw -- traffic stays null and says so.
+    from remixfusion_amd.build import sources_digest
+    digest_now = sources_digest()
     try:
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
         pmc, tag = pmc_all.get("kernels", {}), pmc_all.get("measured_at_commit", "unknown")
+        stale = pmc_all.get("kernel_sources_digest") != digest_now
+        if stale:
+            pmc = {}
+            for r_ in extra_rooflines.values():
+                r_["traffic_source"] = (f"null: profiles/{PMC_TRAFFIC_FILE} was measured on kernel sources {pmc_all.get('kernel_sources_digest')} "
+                                        f"(commit {tag}), this tree is {digest_now}")
         for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
-                        ("field_forward", ("rfx::field_forward_kernel<false, true>",)),
+                        ("field_forward", ("rfx::field_forward_kernel<false, 1>",)),
                         ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false, true>",)),
                         ("field_backward_weights", ("rfx::field_dw_recompute_kernel", "rfx::field_dw_reduce_kernel")),
                         ("render_rays", ("rfx::render_rays_kernel<false, 1>",)),
@@ -762,19 +772,23 @@ def main():
             keys = [k for k in pmc if any(kn in k for kn in kns)]
             if rk in extra_rooflines and keys:
                 extra_rooflines[rk]["traffic"] = int(sum(pmc[k]["hbm_bytes"] for k in keys))
-                extra_rooflines[rk]["traffic_source"] = (f"profiles/r3_pmc_traffic.json, rocprofv3 --pmc passes at commit {tag} (not this run): "
+                extra_rooflines[rk]["traffic_source"] = (f"profiles/{PMC_TRAFFIC_FILE}, rocprofv3 --pmc passes at commit {tag} on these kernel sources ({digest_now}; not this run): "
                                                          "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B) + WRITE_SIZE; " + " + ".join(keys))
     except Exception:
         pass
     # V1: traffic of the SAME frame the algorithmic bytes above were counted on (frame 1 + warmup + steps - 1), when the
-    # committed passes cover it (profiles/r3_pmc_v1_frame25.json: the driver's settings)
+    # committed passes cover it (profiles/r4_pmc_v1_frame25.json: the driver's settings) and ran on these kernel sources
     try:
-        v1p = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_v1_frame25.json")))
-        if "tsdf_integrate" in extra_rooflines and v1p["frame"] == n_frames - 1 and v1p["config"] == args.config:
+        v1p = json.load(open(os.path.join(ROOT, "profiles", PMC_V1_FILE)))
+        if "tsdf_integrate" in extra_rooflines and v1p.get("kernel_sources_digest") != digest_now:
+            extra_rooflines["tsdf_integrate"]["traffic"] = None
+            extra_rooflines["tsdf_integrate"]["traffic_source"] = (f"null: profiles/{PMC_V1_FILE} was measured on kernel sources "
+                                                                   f"{v1p.get('kernel_sources_digest')}, this tree is {digest_now}")
+        elif "tsdf_integrate" in extra_rooflines and v1p["frame"] == n_frames - 1 and v1p["config"] == args.config:
             extra_rooflines["tsdf_integrate"]["traffic"] = int(sum(k["hbm_bytes"] for k in v1p["kernels"].values()))
             extra_rooflines["tsdf_integrate"]["traffic_raw_counters"] = int(sum(k["hbm_bytes_raw"] for k in v1p["kernels"].values()))
             extra_rooflines["tsdf_integrate"]["traffic_source"] = (
-                f"profiles/r3_pmc_v1_frame25.json: rocprofv3 --pmc passes of tools/pmc_v1.py at commit {v1p['measured_at_commit']} on frame "
+                f"profiles/{PMC_V1_FILE}: rocprofv3 --pmc passes of tools/pmc_v1.py at commit {v1p['measured_at_commit']} on frame "
                 f"{v1p['frame']} (this frame; not this run): 2 x FETCH_SIZE + WRITE_SIZE, the factor 2 calibrated on a coalesced "
                 "dword-per-lane read of known size in the same passes; traffic_raw_counters = FETCH_SIZE + WRITE_SIZE")
         elif "tsdf_integrate" in extra_rooflines:

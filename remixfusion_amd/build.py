@@ -40,6 +40,21 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def sources_digest() -> str:
+    """sha256 over the files that define the kernels (csrc/*.hip, csrc/*.h, include/rfx.h, the compiler flags): the identity
+    of the binary for measurements taken in another run -- profiles/*_pmc_*.json carry it, and bench.py refuses a `traffic`
+    figure whose digest is not this tree's (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        path = os.path.join(CSRC, name)
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False, extra: List[str] | None = None, out: str | None = None) -> str:
     """``extra``/``out``: A/B builds (tools/build_variant.py) -- later -D flags override the defaults above; such a
     library is selected at run time with RFX_LIB_PATH (see _lib.py)."""

@@ -104,6 +104,14 @@ __device__ __forceinline__ void corner_indices(const Level& L, const Cell& c, un
     for (int k = 0; k < 8; ++k) idx[k] = corner_index(L, c, k);
 }
 
+// element idx of a table whose byte size is below 4 GiB (every grid here: <= 332 MB), addressed as uniform base + 32-bit byte
+// offset: the load then takes its address as (SGPR base, VGPR offset) -- one shift per gather instead of a 64-bit shift-add
+// and a zeroed high word (128 gathers per point in the fused kernels)
+template <typename T>
+__device__ __forceinline__ T at32(const T* __restrict__ base, unsigned idx) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(idx * (unsigned)sizeof(T)));
+}
+
 // F = 2 lookup (hash grid): returns the two interpolated features of one level.
 __device__ __forceinline__ float2 lookup2(const float* __restrict__ table, const Level& L, const float x[3]) {
     const Cell c = locate(L, x);
@@ -112,7 +120,7 @@ __device__ __forceinline__ float2 lookup2(const float* __restrict__ table, const
     corner_indices(L, c, idx);
     float2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = at32(t, idx[k]);
     float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -131,7 +139,7 @@ __device__ __forceinline__ float4 lookup4(const float* __restrict__ table, const
     corner_indices(L, c, idx);
     float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = at32(t, idx[k]);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -149,7 +157,7 @@ __device__ __forceinline__ float lookup1(const float* __restrict__ table, const 
     corner_indices(L, c, idx);
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = t[idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = at32(t, idx[k]);
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = fmaf(corner_weight(c, k), v[k], acc);
@@ -275,7 +283,22 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#if defined(FIELD_DBG) && (FIELD_DBG == 5 || FIELD_DBG == 6)
+    // timing experiment (results are wrong by construction): every fp32 k-step issued as ONE bf16 32x32x16 MFMA (half the
+    // matrix-pipe passes, and on the pipe that co-executes with the VALU) -- an upper bound for what a split-bf16 MLP, which
+    // needs 3-6 such products per 16 k but 8x fewer k-steps, could gain; FIELD_DBG == 6: no MFMA at all
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 av = {a, a, a, a}, bv = {b, b, b, b};
+#if FIELD_DBG == 5
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+#else
+    c[0] += a * b;
+    return c;
+#endif
+#else
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // row index held by (accumulator register r, lane half h) of a 32x32 D tile

@@ -423,7 +423,7 @@ __device__ __forceinline__ void mlp_forward_123(const FieldK& f, const float x[3
 #pragma unroll
         for (int g = 0; g < HG; ++g)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cv[g][k] = tl[g][idx[g][k]];
+            for (int k = 0; k < 8; ++k) cv[g][k] = at32(tl[g], idx[g][k]);
 #pragma unroll
         for (int g = 0; g < HG; ++g) {
             float2 acc = make_float2(0.f, 0.f);

@@ -33,7 +33,9 @@ for k, v in kern.items():
     f, w = v.get("FETCH_SIZE_KiB_avg", 0.0), v.get("WRITE_SIZE_KiB_avg", 0.0)
     v["hbm_bytes_raw"] = (f + w) * 1024
     v["hbm_bytes"] = (2 * f + w) * 1024
-json.dump({"measured_at_commit": commit, "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- {command} (one pass per counter)",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from remixfusion_amd.build import sources_digest
+json.dump({"measured_at_commit": commit, "kernel_sources_digest": sources_digest(), "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- {command} (one pass per counter)",
            "unit_note": "KiB counters; hbm_bytes = (2*FETCH + WRITE)*1024 (gfx950 FETCH correction), hbm_bytes_raw = (FETCH + WRITE)*1024; per launch averages",
            "kernels": kern}, open(os.path.join(out_dir, prefix + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 lines = [f"# HBM traffic per launch (rocprofv3 --pmc, commit {commit}); MiB", "", "| kernel | launches | FETCH raw | FETCH x2 | WRITE |", "|---|---|---|---|---|"]
