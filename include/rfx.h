@@ -145,6 +145,14 @@ int rfx_tsdf_truncated_pc(const float* tsdf, const float* color, int dx, int dy,
                           const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
                           float* pc7, uint32_t* count, int index_decode, rfx_stream stream);
 
+/* V5 on one x-slab [x0, x1) of the volume (tsdf / color hold the slab's planes; dims and origin describe the whole volume).
+ * Slots are filled from the slab's own voxels only (global indices, so slot = global index % pc_num as on one GPU);
+ * hit dev uint8[pc_num] (may be NULL) = 1 where this slab wrote.  Merging over the slabs -- the slab with the highest
+ * x-planes that hit a slot wins it -- gives the record rfx_tsdf_truncated_pc leaves (remixfusion_amd/dist.py). */
+int rfx_tsdf_truncated_pc_slab(const float* tsdf, const float* color, int dx, int dy, int dz, int x0, int x1,
+                               const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
+                               float* pc7, uint32_t* count, uint8_t* hit, int index_decode, rfx_stream stream);
+
 /* ======================================================================================
  * Global explicit volume (GBV/GBW): trgb dev [R^3,4] interleaved (tsdf,r,g,b), x fastest;
  * w dev [R^3].  Same memory the dense-grid lookup (rfx_field_*) reads.
@@ -456,6 +464,13 @@ int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float or
                        const float* vertex4, const float* normal3, const float R[9], const float T[3],
                        const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
                        int level, int level_index, float* value, float* count, rfx_stream stream);
+
+/* T3 on one x-slab [x0, x1) of the volume (tsdf holds the slab's planes): value / count receive the terms of the pixels
+ * whose nearest voxel lies in the slab; summed over the slabs they are rfx_track_evaluate's (up to the order of the sums). */
+int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, int x1, const float origin[3], float voxel,
+                            const float* vertex4, const float* normal3, const float R[9], const float T[3],
+                            const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
+                            int level, int level_index, float* value, float* count, rfx_stream stream);
 
 /* ---- iso-surface extraction -------------------------------------------------------
  * MC1/MC2 replace the host `skimage.measure.marching_cubes(raw, level=isolevel, mask=mask)` call of

@@ -107,6 +107,8 @@ PROTOTYPES = {
     "rfx_tsdf_trilerp_slab": (_i, [_P, _P, _i, _i, _i, _i, _i, _P, _P, _F3, _f, _P, _l, _P, _P, _P]),
     "rfx_tsdf_filter": (_i, [_P, _P, _P, _l, _f, _P]),
     "rfx_tsdf_truncated_pc": (_i, [_P, _P, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _i, _P]),
+    "rfx_tsdf_truncated_pc_slab": (_i, [_P, _P, _i, _i, _i, _i, _i, _F3, _f, _f, _i, _f, _P, _P, _P, _i, _P]),
+    "rfx_track_evaluate_slab": (_i, [_P, _i, _i, _i, _i, _i, _F3, _f, _P, _P, _F9, _F3, _P, _F6, _i, _F9, _i, _i, _i, _i, _P, _P, _P]),
     "rfx_gbv_integrate": (_i, [_P, _P, _i, _F6, _F9, _P, _P, _P, _i, _i, _f, _f, _P]),
     "rfx_gbv_clear": (_i, [_P, _l, _P]),
     "rfx_grid_encode_forward": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P]),

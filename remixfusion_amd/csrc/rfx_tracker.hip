@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void track_normal_kernel(const float4* __restr
 struct EvalK {
     float R[9], T[3], ss[6], K[9];
     int dx, dy, dz, ox, oy, oz;
+    int x0, x1;            // the x-planes tsdf holds (one slab of the volume; whole volume: 0, dx)
     float voxel;
     int P, H, W, level, level_index, gh, gw, n_slabs;
 };
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const floa
         const int vyi = (int)roundf((y - (float)E.oy) / E.voxel);
         const int vzi = (int)roundf((z - (float)E.oz) / E.voxel);
         if (vxi < 1 || vxi >= E.dx - 1 || vyi < 1 || vyi >= E.dy - 1 || vzi < 1 || vzi >= E.dz - 1) continue;
-        const int64_t idx = (int64_t)vzi + (int64_t)vyi * E.dz + (int64_t)vxi * E.dy * E.dz;
+        if (vxi < E.x0 || vxi >= E.x1) continue;             // another slab's voxel: that rank adds this term
+        const int64_t idx = (int64_t)vzi + (int64_t)vyi * E.dz + (int64_t)(vxi - E.x0) * E.dy * E.dz;
         acc += fabsf(tsdf[idx] - v.w);
         cnt += 1.0f;
     }
@@ -155,9 +157,19 @@ int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float or
                        const float* vertex4, const float* normal3, const float R[9], const float T[3],
                        const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
                        int level, int level_index, float* value, float* count, rfx_stream stream) {
+    return rfx_track_evaluate_slab(tsdf, dx, dy, dz, 0, dx, origin, voxel, vertex4, normal3, R, T, q6, search_size, n_candidates, K, H, W,
+                                   level, level_index, value, count, stream);
+}
+
+int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, int x1, const float origin[3], float voxel,
+                            const float* vertex4, const float* normal3, const float R[9], const float T[3],
+                            const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
+                            int level, int level_index, float* value, float* count, rfx_stream stream) {
     if (!tsdf || !origin || !vertex4 || !normal3 || !R || !T || !q6 || !search_size || !K || !value || !count) return RFX_ERR_ARG;
     if (dx <= 2 || dy <= 2 || dz <= 2 || n_candidates <= 0 || H <= 0 || W <= 0 || level <= 0 || !(voxel > 0.f)) return RFX_ERR_ARG;
+    if (x0 < 0 || x1 > dx || x1 < x0) return RFX_ERR_ARG;
     EvalK E;
+    E.x0 = x0; E.x1 = x1;
     for (int i = 0; i < 9; ++i) { E.R[i] = R[i]; E.K[i] = K[i]; }
     for (int i = 0; i < 3; ++i) E.T[i] = T[i];
     for (int i = 0; i < 6; ++i) E.ss[i] = search_size[i];

@@ -1132,25 +1132,27 @@ __global__ __launch_bounds__(256) void mv_filter_kernel(float* __restrict__ t, f
 
 // V5: one thread per output slot; walks the voxels that map to the slot from the highest index
 // down, so the survivor is deterministic ("last writer in index order").
+// [i0, i1): the global voxel indices held by tsdf / color (one x-slab of the volume; the whole volume: [0, n)); hit (optional):
+// hit[s] = 1 where this slab wrote slot s, for the merge over the slabs (the slab with the highest indices wins a slot).
 __global__ __launch_bounds__(256) void mv_truncated_pc_kernel(VolView V, const float* __restrict__ tsdf,
                                                               const float* __restrict__ color, float trunc,
                                                               int pc_num, float tt, float* __restrict__ pc7,
                                                               unsigned* __restrict__ count, int risky_rows,
-                                                              int literal_all) {
+                                                              int literal_all, int64_t i0, int64_t i1,
+                                                              unsigned char* __restrict__ hit) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)V.dx * V.dy * V.dz;
     unsigned found = 0;
     if (s < pc_num) {
-        int64_t kmax = (n - 1 - s) / pc_num;
+        int64_t kmax = i1 - 1 - s >= 0 ? (i1 - 1 - s) / pc_num : -1;
         bool written = false;
-        for (int64_t k = kmax; k >= 0 && s + k * pc_num < n; --k) {
+        for (int64_t k = kmax; k >= 0 && s + k * pc_num >= i0; --k) {
             const int64_t idx = s + k * pc_num;
-            const float t = tsdf[idx];
+            const float t = tsdf[idx - i0];
             if (t <= -tt || t >= tt) continue;
             ++found;
             if (written) continue;
             written = true;
-            const float oc = color[idx];
+            const float oc = color[idx - i0];
             const float ob = floorf(oc / 65536.0f);
             const float og = floorf((oc - ob * 65536.0f) / 256.0f);
             const float orr = oc - ob * 65536.0f - og * 256.0f;
@@ -1165,6 +1167,7 @@ __global__ __launch_bounds__(256) void mv_truncated_pc_kernel(VolView V, const f
             o[2] = madd(vz + 0.5f, V.voxel, V.origin[2]);
             o[3] = t * trunc; o[4] = orr; o[5] = og; o[6] = ob;
         }
+        if (hit) hit[s] = written ? 1 : 0;
     }
     // one atomic per wave
 #pragma unroll
@@ -1614,20 +1617,28 @@ int rfx_tsdf_filter(float* tsdf, float* weight, float* color, int64_t n, float w
     return RFX_OK;
 }
 
-int rfx_tsdf_truncated_pc(const float* tsdf, const float* color, int dx, int dy, int dz,
-                          const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
-                          float* pc7, uint32_t* count, int index_decode, rfx_stream stream) {
+int rfx_tsdf_truncated_pc_slab(const float* tsdf, const float* color, int dx, int dy, int dz, int x0, int x1,
+                               const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
+                               float* pc7, uint32_t* count, uint8_t* hit, int index_decode, rfx_stream stream) {
     if (!tsdf || !color || !origin || !pc7 || !count || pc_num <= 0) return RFX_ERR_ARG;
-    if (dx <= 0 || dy <= 0 || dz <= 0) return RFX_ERR_ARG;
+    if (dx <= 0 || dy <= 0 || dz <= 0 || x0 < 0 || x1 > dx || x1 < x0) return RFX_ERR_ARG;
     if ((int64_t)dx * dy * dz >= (1LL << 31)) return RFX_ERR_UNSUPPORTED;
     VolView V; V.dx = dx; V.dy = dy; V.dz = dz; V.voxel = voxel;
     for (int i = 0; i < 3; ++i) V.origin[i] = origin[i];
     int rr, la;
     decode_split(dx, dy, dz, index_decode, &rr, &la);
+    const int64_t plane = (int64_t)dy * dz;
     hipLaunchKernelGGL(mv_truncated_pc_kernel, dim3((unsigned)((pc_num + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       V, tsdf, color, trunc, pc_num, trunc_tsdf, pc7, count, rr, la);
+                       V, tsdf, color, trunc, pc_num, trunc_tsdf, pc7, count, rr, la, x0 * plane, x1 * plane, hit);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+int rfx_tsdf_truncated_pc(const float* tsdf, const float* color, int dx, int dy, int dz,
+                          const float origin[3], float voxel, float trunc, int pc_num, float trunc_tsdf,
+                          float* pc7, uint32_t* count, int index_decode, rfx_stream stream) {
+    return rfx_tsdf_truncated_pc_slab(tsdf, color, dx, dy, dz, 0, dx, origin, voxel, trunc, pc_num, trunc_tsdf, pc7, count, nullptr,
+                                      index_decode, stream);
 }
 
 int rfx_gbv_integrate(float* trgb, float* w, int res, const float box[6], const float K[9],

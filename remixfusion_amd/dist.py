@@ -410,11 +410,52 @@ class sharded_volume(moving_volume):
         return result, ~notvalid
 
     def get_truncated_pc(self, pc_num=5000000, trunc_tsdf=0.5):
-        """not available on a sharded volume: the reference's slot scatter (`voxel_idx % pc_num`, model/Volume.py:489-559) keeps
-        the LAST voxel per slot in global index order, which needs a merge over the ranks; no shipped configuration reaches it
-        (training.surface_weight = 0 everywhere)."""
+        """Near-surface voxels as a point cloud (reference model/Volume.py:622-653, kernel :489-559) from a sharded volume.  The
+        reference's slot scatter (`voxel_idx % pc_num`) keeps, in this build deterministically, the voxel with the HIGHEST global
+        index per slot: each rank fills the slots from its slab (rfx_tsdf_truncated_pc_slab: global indices), the rank with the
+        highest x-planes that hit a slot wins it (all-reduce MAX of rank + 1 over the hit flags), and the winners' records are
+        summed (every other rank contributes zeros): every rank returns the single-GPU cloud, bit for bit.  Cold path
+        (training.surface_weight = 0 in every shipped configuration); two all-reduces of 4 and 28 bytes per slot."""
         from . import _lib
-        raise _lib.RfxError("get_truncated_pc is not implemented for sharded_volume (cold path: surface_weight = 0 in every config)")
+        from ._lib import _F3, check, farr, ptr, stream_ptr
+        self._wait_for_producer()
+        pc = torch.zeros((pc_num, 7), dtype=torch.float32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        hit = torch.zeros(pc_num, dtype=torch.uint8, device=self.device)
+        d = self.vol_dim
+        x0, x1 = self._slab()
+        check(_lib.load().rfx_tsdf_truncated_pc_slab(ptr(self.tsdf_vol_gpu), ptr(self.color_vol_gpu), int(d[0]), int(d[1]), int(d[2]), x0, x1,
+                                                     farr(_F3, self.vol_origin), self.voxel_size, float(self.trunc_margin), int(pc_num),
+                                                     float(trunc_tsdf), ptr(pc), cnt.data_ptr(), hit.data_ptr(), self.index_decode,
+                                                     stream_ptr(self.device)), "rfx_tsdf_truncated_pc_slab")
+        if self.dist is not None and self.world > 1:
+            owner = hit.to(torch.float32) * float(self.rank + 1)
+            if _host_staged(self.dist, owner):
+                h = owner.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
+                owner = h.to(self.device)
+            else:
+                self.dist.all_reduce(owner, op=self.dist.ReduceOp.MAX)
+            pc = pc * (owner == float(self.rank + 1)).unsqueeze(1).to(pc.dtype)
+            all_reduce_sum_(self.dist, [pc])
+        truncated_pc = pc.cpu().numpy()
+        valid = (truncated_pc[:, 0] != 0.0) & (truncated_pc[:, 1] != 0.0) & (truncated_pc[:, 2] != 0.0)
+        return truncated_pc[valid, :]
+
+    def track_evaluate(self, vertex4, normal3, R, T, cand, search_size, n_cand, K9, H, W, level, level_index, value, count):
+        """the tracker's nearest-voxel reads (reference model/ROtracker.py:244-259) on a sharded volume: every rank evaluates the
+        pixels whose nearest voxel lies in its slab (rfx_track_evaluate_slab), the sums and hit counts are added over the ranks
+        -- the single-GPU values up to the order of the additions -- and every rank continues with the same numbers."""
+        from . import _lib
+        from ._lib import _F3, _F6, _F9, check, farr, ptr, stream_ptr
+        self._wait_for_producer()
+        d = self.vol_dim
+        x0, x1 = self._slab()
+        check(_lib.load().rfx_track_evaluate_slab(ptr(self.tsdf_vol_gpu), int(d[0]), int(d[1]), int(d[2]), x0, x1, farr(_F3, self.vol_origin),
+                                                  float(self.voxel_size), ptr(vertex4), ptr(normal3), farr(_F9, R), farr(_F3, T), ptr(cand),
+                                                  farr(_F6, search_size), int(n_cand), farr(_F9, K9), int(H), int(W), int(level),
+                                                  int(level_index), ptr(value), ptr(count), stream_ptr(self.device)), "rfx_track_evaluate_slab")
+        all_reduce_sum_(self.dist, [value, count])
 
     def copy_volume(self):
         """front -> back on this slab; remembers the layout of the copy (see update_tsdf_swap_rot_trans)"""

@@ -31,7 +31,7 @@ from .pst import generated_pst, load_pst, make_pst, pst_slot  # noqa: E402,F401 
 
 
 class ROTracker(object):
-    def __init__(self, cfg, data_stream, device=None) -> None:
+    def __init__(self, cfg, data_stream, device=None, volume_factory=None) -> None:
         self.cfg = cfg
         ro = cfg["RO"]
         self.data_stream = data_stream
@@ -56,7 +56,9 @@ class ROTracker(object):
         init_batch = self.data_stream[0]
         init_pose = init_batch["c2w"].squeeze().cpu().numpy()
         self.RO_pose = []
-        self.MV = moving_volume(cfg, self.traj, init_pose.astype(np.float64), start=0, device=self.device)
+        # volume_factory(cfg, traj, pose0): a one-scene-on-N-GPUs run hands in its x-slab volume (dist.sharded_volume)
+        self.MV = (volume_factory(cfg, self.traj, init_pose.astype(np.float64)) if volume_factory is not None else
+                   moving_volume(cfg, self.traj, init_pose.astype(np.float64), start=0, device=self.device))
         self.im_h, self.im_w = self.data_stream.H, self.data_stream.W
         d = self.data_stream
         self.K = np.array([[d.fx, 0.0, d.cx], [0.0, d.fy, d.cy], [0.0, 0.0, 1.0]])
@@ -132,14 +134,9 @@ class ROTracker(object):
         P = int(node_size // 1024) * 1024            # grid = int(node_size/(32*32)) blocks of 1024 candidates
         val = torch.empty(P, dtype=torch.float32, device=self.device)
         cnt = torch.empty(P, dtype=torch.float32, device=self.device)
-        mv = self.MV
-        d = mv.vol_dim
-        check(_lib.load().rfx_track_evaluate(ptr(mv.tsdf_vol_gpu), int(d[0]), int(d[1]), int(d[2]), farr(_F3, mv.vol_origin),
-                                             float(mv.voxel_size), ptr(self.depth_vertex_gpu), ptr(self.normal_vertex_gpu),
-                                             farr(_F9, self.current_global_R.reshape(-1)), farr(_F3, self.current_global_T),
-                                             ptr(self._cand_dev), farr(_F6, self.search_size), P,
-                                             farr(_F9, np.asarray(cam_intr).reshape(-1)), self.im_h, self.im_w, int(level),
-                                             int(level_index), ptr(val), ptr(cnt), stream_ptr(self.device)), "rfx_track_evaluate")
+        self.MV.track_evaluate(self.depth_vertex_gpu, self.normal_vertex_gpu, self.current_global_R.reshape(-1), self.current_global_T,
+                               self._cand_dev, self.search_size, P, np.asarray(cam_intr).reshape(-1), self.im_h, self.im_w, level,
+                               level_index, val, cnt)
         n_all = self.transform_candidate.shape[0]
         sv = np.zeros(n_all, np.float32)
         sc = np.zeros(n_all, np.float32)

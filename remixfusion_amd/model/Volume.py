@@ -243,6 +243,15 @@ class moving_volume:
         valid = (truncated_pc[:, 0] != 0.0) & (truncated_pc[:, 1] != 0.0) & (truncated_pc[:, 2] != 0.0)
         return truncated_pc[valid, :]
 
+    def track_evaluate(self, vertex4, normal3, R, T, cand, search_size, n_cand, K9, H, W, level, level_index, value, count):
+        """nearest-voxel TSDF residuals of the tracker's pose candidates against THIS volume (reference kernel
+        model/ROtracker.py:144-270): value / count dev [n_cand].  A sharded volume overrides it (its slab + a sum over ranks)."""
+        d = self.vol_dim
+        check(_lib.load().rfx_track_evaluate(ptr(self.tsdf_vol_gpu), int(d[0]), int(d[1]), int(d[2]), farr(_F3, self.vol_origin),
+                                             float(self.voxel_size), ptr(vertex4), ptr(normal3), farr(_F9, R), farr(_F3, T), ptr(cand),
+                                             farr(_F6, search_size), int(n_cand), farr(_F9, K9), int(H), int(W), int(level),
+                                             int(level_index), ptr(value), ptr(count), stream_ptr(self.device)), "rfx_track_evaluate")
+
     def get_volume_all(self):
         """D2H copy of the three volumes, flat, z fastest (reference :1265-1277)."""
         self._wait_for_producer()

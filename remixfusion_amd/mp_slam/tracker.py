@@ -21,14 +21,14 @@ def orthogonalize_rotation(R: np.ndarray) -> np.ndarray:
 
 class Tracker:
     def __init__(self, config, SLAM, model, dataset, est_c2w_data, RO_c2w_data, est_c2w_data_rel, tracking_idx, mapping_idx,
-                 tracking_stop_flag, pose_gt, update_local_MV, all_fuse_pose, device) -> None:
+                 tracking_stop_flag, pose_gt, update_local_MV, all_fuse_pose, device, volume_factory=None) -> None:
         self.config, self.slam, self.dataset = config, SLAM, dataset
         self.est_c2w_data, self.RO_c2w_data, self.est_c2w_data_rel = est_c2w_data, RO_c2w_data, est_c2w_data_rel
         self.tracking_idx, self.mapping_idx, self.tracking_stop_flag = tracking_idx, mapping_idx, tracking_stop_flag
         self.update_local_MV, self.all_fuse_pose, self.share_model, self.pose_gt = update_local_MV, all_fuse_pose, model, pose_gt
         self.frames_num = len(dataset)
         self.device = device
-        self.RO_Tracker = ROTracker(config, dataset, device=device)
+        self.RO_Tracker = ROTracker(config, dataset, device=device, volume_factory=volume_factory)
         self.all_poses = []
 
     def predict_current_pose(self, frame_id, constant_speed=True):

@@ -55,7 +55,8 @@ class MappingPipeline:
             del self.mv
             self.tracker = Tracker(config, s, self.model, self.dataset, s.est_c2w_data, s.RO_c2w_data, s.est_c2w_data_rel,
                                    s.tracking_idx, s.mapping_idx, s.tracking_stop_flag, s.pose_gt, s.update_local_MV,
-                                   s.keyframeDatabase.all_fuse_pose, self.device)
+                                   s.keyframeDatabase.all_fuse_pose, self.device,
+                                   volume_factory=(lambda c, t, p0: self._make_volume(c, t, p0)) if shard is None else None)
             self.mv = self.tracker.RO_Tracker.MV
         # The moving volume and the residual field touch disjoint memory (the reference runs them in two processes,
         # run.py:56-60): with ground-truth poses the per-frame V1 (and the volume moves) go on their own HIP stream and

@@ -176,3 +176,76 @@ def test_sharded_scene_world2_equals_single_gpu(tmp_path, version, shard_field):
     # (two single-GPU runs of the same seed differ by ~1e-6 in the losses and up to ~1e-2 of the table's scale in single hash
     #  entries after these 20 Adam steps: float atomics)
     assert float(dl.max()) < 1e-3 and float(dh) < 3e-2 and float(dw) < 2e-3 and float(dp) < 1e-5
+
+
+# ---- the volume's cold readers on a sharded volume: the truncated point cloud (V5) and the tracker's nearest-voxel reads (T3)
+N_COLD = 9
+
+
+def _cold_run(make_pipe):
+    import random
+    import warnings
+    import torch
+    out = {}
+    cfg = _small_cfg()
+    pipe = make_pipe(cfg)
+    frames = pipe.prefetch(list(range(N_COLD)))
+    pipe.start(frames[0])
+    for i in range(1, N_COLD):
+        pipe.step(i, frames[i])
+    out["pc"] = pipe.mv.get_truncated_pc(pc_num=40000, trunc_tsdf=0.5)
+    out["pc_small"] = pipe.mv.get_truncated_pc(pc_num=977, trunc_tsdf=0.9)          # many voxels per slot: the highest index must win
+    del pipe
+    random.seed(0)
+    cfg = _small_cfg()
+    cfg["synthetic"].update({"tracker": True, "clutter": 32})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = make_pipe(cfg)
+    frames = pipe.prefetch(list(range(N_COLD)))
+    pipe.start(frames[0])
+    for i in range(1, N_COLD):
+        pipe.step(i, frames[i])
+    torch.cuda.synchronize()
+    out["poses"] = pipe.slam.RO_c2w_data[:N_COLD].detach().cpu().clone()
+    out["gt"] = torch.stack([frames[i]["c2w"] for i in range(N_COLD)])
+    out["volume_class"] = type(pipe.mv).__name__
+    return out
+
+
+def _worker_cold(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from remixfusion_amd.dist import ShardedPipeline
+    out = _cold_run(lambda cfg: ShardedPipeline(cfg, dist, rank, world, n_frames=N_COLD + 4, seed=5))
+    torch.save(out, os.path.join(out_dir, f"cold{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_volume_cold_readers_world3(tmp_path):
+    """get_truncated_pc (reference model/Volume.py:489-559, :622-653) and the tracker's reads of the volume
+    (model/ROtracker.py:144-270) on a volume cut into 3 x-slabs (uneven: 200 planes) against the single-GPU volume."""
+    import torch
+    import torch.multiprocessing as mp
+    from remixfusion_amd.pipeline import MappingPipeline
+    world = 3
+    mp.spawn(_worker_cold, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"cold{r}.pt"), weights_only=False) for r in range(world)]
+    ref = _cold_run(lambda cfg: MappingPipeline(cfg, n_frames=N_COLD + 4, seed=5))
+    for key in ("pc", "pc_small"):
+        assert ref[key].shape[0] > 500 and ref[key].shape[1] == 7
+        for r in rs:                                       # the merged cloud: the single-GPU cloud, bit for bit, on every rank
+            assert r[key].shape == ref[key].shape and np.array_equal(r[key].view(np.uint32), ref[key].view(np.uint32)), key
+    assert all(r["volume_class"] == "sharded_volume" for r in rs) and ref["volume_class"] == "moving_volume"
+    for r in rs[1:]:
+        assert torch.equal(r["poses"], rs[0]["poses"])     # every rank continues with the same sums: the same poses
+    dp = (rs[0]["poses"][:, :3, 3] - ref["poses"][:, :3, 3]).norm(dim=1)
+    err = (ref["poses"][:, :3, 3] - ref["gt"][:, :3, 3]).norm(dim=1)
+    print(f"tracker on 3 slabs vs one volume: max |dt| {float(dp.max()) * 1e3:.3f} mm; single-GPU error vs ground truth {float(err.max()) * 1e3:.1f} mm")
+    # the sums are the same terms added in another order: the searches agree to far below the tracker's own accuracy
+    assert float(dp.max()) < 2e-3 and float(err.max()) < 0.08
