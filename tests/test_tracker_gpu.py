@@ -64,6 +64,17 @@ def test_vertex_normal_evaluate_match_oracle():
         assert np.array_equal(cnt.cpu().numpy(), ref_cnt)                       # hit counts are exact
         assert np.allclose(val.cpu().numpy(), ref_val, rtol=1e-5, atol=1e-5)    # sums: slab order differs
         assert ref_cnt.max() > 5
+        # the volume in x-slabs (one scene on several GPUs): each slab adds the pixels whose nearest voxel it holds
+        plane = dims[1] * dims[2]
+        sv, sc = np.zeros(1024, np.float32), np.zeros(1024, np.float32)
+        for x0, x1 in ((0, 33), (33, 34), (34, 100)):
+            v2, c2 = torch.empty(1024, device="cuda"), torch.empty(1024, device="cuda")
+            L.check(lib.rfx_track_evaluate_slab(L.ptr(d_t[x0 * plane:x1 * plane]), *dims, x0, x1, L.farr(L._F3, origin), voxel, L.ptr(d_v),
+                                                L.ptr(d_n), L.farr(L._F9, c2w[:3, :3].reshape(-1)), L.farr(L._F3, c2w[:3, 3]), L.ptr(d_q),
+                                                L.farr(L._F6, ss), 1024, L.farr(L._F9, K.reshape(-1)), H, W, level, li, L.ptr(v2), L.ptr(c2),
+                                                L.stream_ptr()), "eval slab")
+            sv += v2.cpu().numpy(); sc += c2.cpu().numpy()
+        assert np.array_equal(sc, ref_cnt) and np.allclose(sv, ref_val, rtol=1e-5, atol=1e-5)
     # the null candidate at the true pose fits better than most perturbed ones
     mean = ref_val / (ref_cnt + 1e-6)
     assert mean[0] <= np.percentile(mean[1:], 30)
