@@ -279,7 +279,8 @@ def test_direct_iterations_equal_autograd_iterations():
     o64 = [fq.hash_table.grad, fq.W1.grad, fq.W2.grad, fq.W3.grad, fq.W4.grad]
     for which, grads in (("direct", got), ("autograd", ref)):
         for g, a, q, nm in zip(grads, o32, o64, ("d_hash", "dW1", "dW2", "dW3", "dW4")):
-            _grad_close(g, a, q, f"{nm} ({which}, map phase)", _level_groups(fp.hash_meta) if nm == "d_hash" else None)
+            _grad_close(g, a, q, f"{nm} ({which}, map phase)", _level_groups(fp.hash_meta) if nm == "d_hash" else None,
+                        relu_ties=0 if nm == "d_hash" else 2 * 81)
     assert float((ref[0] != 0).float().mean()) > 0.001
     # ---- pose phase
     reset()
@@ -317,7 +318,8 @@ def test_direct_iterations_equal_autograd_iterations():
     assert float(ref_r[0].abs().max()) > 0
     for which, grads in (("direct", got_m), ("autograd", ref_m)):
         for g, a, q, nm in zip(grads, p32[8:], p64[8:], ("d_hash", "dW1", "dW2", "dW3", "dW4")):
-            _grad_close(g, a, q, f"{nm} ({which}, pose phase)", _level_groups(fp2.hash_meta) if nm == "d_hash" else None)
+            _grad_close(g, a, q, f"{nm} ({which}, pose phase)", _level_groups(fp2.hash_meta) if nm == "d_hash" else None,
+                        relu_ties=0 if nm == "d_hash" else 2 * 81)
     # ---- the one-call driver (rfx_ba_forward_backward) vs the same iteration issued stage by stage
     direct.stagewise_every = 1
     reset()

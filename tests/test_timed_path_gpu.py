@@ -143,7 +143,7 @@ def test_one_call_ba_iteration_matches_oracle_at_bench_size(name, frames):
     total64.backward()
     _grad_close(got[0], fp.hash_table.grad, fq.hash_table.grad, "d_hash (map iteration)", _level_groups(fp.hash_meta))
     for g, a, q, nm in zip(got[1:], (fp.W1, fp.W2, fp.W3, fp.W4), (fq.W1, fq.W2, fq.W3, fq.W4), ("dW1", "dW2", "dW3", "dW4")):
-        _grad_close(g, a.grad, q.grad, nm + " (map iteration)")
+        _grad_close(g, a.grad, q.grad, nm + " (map iteration)", relu_ties=2 * 81)      # (two rows of the widest matrix)
     assert float((got[0] != 0).float().mean()) > 0.001
     frac_zero = float((f["d_raw"] == 0).all(dim=1).float().mean())
     assert 0.15 < frac_zero < 0.7, frac_zero           # a real batch: a good share of the rows carry no gradient
@@ -228,7 +228,7 @@ def test_backward_with_selection_matches_oracle_above_the_threshold(stashed):
     L.check(lib.rfx_field_backward_dx(C.byref(desc), L.ptr(xx), n, L.ptr(dd), L.ptr(dx), wsp, nbytes, st), "dx")
     torch.cuda.synchronize()
     for got, a, q, nm in zip(dws, (fp.W1, fp.W2, fp.W3, fp.W4), (fq.W1, fq.W2, fq.W3, fq.W4), ("dW1", "dW2", "dW3", "dW4")):
-        _grad_close(got, a.grad, q.grad, nm)
+        _grad_close(got, a.grad, q.grad, nm, relu_ties=2 * 81)
     _grad_close(d_hash, fp.hash_table.grad, fq.hash_table.grad, "d_hash", _level_groups(fp.hash_meta))
     _grad_close(dx, xo.grad, xq.grad, "dx01", k=8.0)
     zero_rows = (draw == 0).all(dim=1)
