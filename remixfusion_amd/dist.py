@@ -207,14 +207,30 @@ def all_to_all_rows_(dist, out: torch.Tensor, out_splits: List[int], inp: torch.
 
 # ---- the residual field over N GPUs: the hash table partitioned by LEVEL (mp_slam/sharded.py) -----------------------------
 _BIN_SEG, _BIN_MIN_SEGMENTS = 8192, 12       # csrc/rfx_field.hip: levels of >= 12 segments of 8 192 entries take the binned scatter
-_BINNED_LEVEL_COST = 3.6                     # measured at cafeteria sizes (profiles/r3_notes.md): 62 us per binned level against
-                                             # 17 us per level of the LDS sweep, per merged scatter
+# What keeping a level costs a rank per map iteration, relative to a small (LDS-swept) level, measured with the ranks of worlds
+# of 2, 4 and 8 played on one GPU at cafeteria and apartment sizes (tools/shard_phase_times.py, profiles/r4_shard_phases.txt):
+# a small level ~30 us (the 250 k-point TV lattice collides on its few cells), a binned DENSE level ~60 us (its segments are
+# slabs of space, a scene fills a few of them), a binned HASHED level of 2^21 entries ~78 us: ~37 us of scatter + its Adam
+# step, 7 arrays streamed over its 2.1e6 entries.  The costs are not exactly additive (grouped launches, bandwidth shared
+# between phases); these three numbers reproduce the best partitions found by measurement at N = 2, 4 and 8.
+_SMALL_LEVEL_COST, _BINNED_DENSE_COST, _BINNED_HASHED_COST = 1.0, 2.0, 2.6
+_SWEEP_UNITS_BINNED = 3.6                    # the TIME model's units (choose_field_mode): a binned level's scatter against a small
+                                             # level's, single GPU (profiles/r3_notes.md: 62 us against 17 us per merged scatter)
+
+
+def _binned(desc, l: int) -> bool:
+    return -(-int(desc.size[l]) // _BIN_SEG) >= _BIN_MIN_SEGMENTS
 
 
 def level_costs(desc) -> List[float]:
-    """relative cost of keeping one hash level (lookups + gradient scatter + TV term): every level sees every point, so the
-    cost is per level, not per entry; levels large enough for the binned scatter cost more."""
-    return [_BINNED_LEVEL_COST if -(-int(desc.size[l]) // _BIN_SEG) >= _BIN_MIN_SEGMENTS else 1.0 for l in range(int(desc.n_levels))]
+    """relative cost of keeping one hash level (lookups + gradient scatter + TV term + Adam step): every level sees every
+    point, so the cost is per level; large levels take the binned scatter and a bandwidth-bound Adam step."""
+    return [(_BINNED_HASHED_COST if int(desc.hashed[l]) else _BINNED_DENSE_COST) if _binned(desc, l) else _SMALL_LEVEL_COST
+            for l in range(int(desc.n_levels))]
+
+
+def _sweep_units(desc) -> float:
+    return sum(_SWEEP_UNITS_BINNED if _binned(desc, l) else 1.0 for l in range(int(desc.n_levels)))
 
 
 def level_partition(desc, world: int) -> List[int]:
@@ -305,8 +321,7 @@ def choose_field_mode(desc, n_points: int, n_lattice: int, world: int) -> Dict:
     scattering all of them) is priced for the record: it never beats "levels", whose exchange is smaller and whose scatter
     is divided."""
     mdl = field_exchange_model(desc, n_points, n_lattice, world)
-    units = sum(level_costs(desc))
-    t_scatter = (n_points + n_lattice) * units * SCATTER_S_PER_POINT_UNIT
+    t_scatter = (n_points + n_lattice) * _sweep_units(desc) * SCATTER_S_PER_POINT_UNIT
     est = {}
     for mode, n_coll in (("replicas", 2), ("points", 2), ("levels", 3)):
         est[mode] = mdl[mode]["recv_bytes"] / XGMI_RECV_BYTES_PER_S + n_coll * COLLECTIVE_LATENCY_S + mdl[mode]["scatter_share"] * t_scatter
