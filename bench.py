@@ -309,6 +309,7 @@ def run_same_scene_alone(args, world, device):
     t0 = time.perf_counter()
     for i in range(1 + args.warmup, n_frames):
         pipe.step(i, frames[i])
+    pipe.mapper.wait_meshes()               # in-loop mesh exports run on a worker thread: they belong to the timed region
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     del pipe, frames
@@ -345,6 +346,7 @@ def run_one_scene(args, dist, rank, world, device, timer):
         for k in ("depth", "rgb255"):
             broadcast_(dist, frames[i][k], 0)
         pipe.step(i, frames[i])
+    pipe.mapper.wait_meshes()               # (rank 0's exports of the timed frames finish inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
@@ -621,6 +623,8 @@ def main():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             frame_marks.append((i, time.perf_counter() - t0, ev))
+    if pipe.mapper is not None:
+        pipe.mapper.wait_meshes()           # in-loop mesh exports run on a worker thread: they belong to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False

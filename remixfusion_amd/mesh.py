@@ -161,6 +161,9 @@ _TABLES: Dict[str, Tuple[torch.Tensor, torch.Tensor, int]] = {}
 EDGE_CORNERS = np.array(_EDGES, np.int32)        # [12,2]
 
 
+_LATTICE_CACHE: Dict = {}
+
+
 def device_tables(device) -> Tuple[torch.Tensor, torch.Tensor, int]:
     key = str(device)
     if key not in _TABLES:
@@ -222,12 +225,21 @@ def extract_mesh(query_fn: Callable, query_w_fn: Callable, config: Dict, boundin
     colors [nv,3] uint8 or None).  Everything stays on the device; only the vertex count is synced."""
     dev = bounding_box.device
     mcb = bounding_box if marching_cube_bound is None else marching_cube_bound
-    tx, ty, tz = get_voxels(mcb[0, 1], mcb[0, 0], mcb[1, 1], mcb[1, 0], mcb[2, 1], mcb[2, 0], voxel_size, resolution)
-    pts = torch.stack(torch.meshgrid(tx, ty, tz, indexing="ij"), -1).to(torch.float32).to(dev)
-    sh = pts.shape
-    flat = pts.reshape(-1, 3)
-    if config["grid"]["tcnn_encoding"]:
-        flat = (flat - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])
+    # the sample lattice is a function of the bounds and the voxel size only: built once per (bounds, size, device) -- the
+    # reference rebuilds it on the host for every export (utils.py:79-103, :137-150), 28 MB and an upload at config 5's sizes
+    key = (tuple(float(v) for v in mcb.reshape(-1)), tuple(float(v) for v in bounding_box.reshape(-1)), voxel_size, resolution,
+           str(dev), bool(config["grid"]["tcnn_encoding"]))
+    hit = _LATTICE_CACHE.get(key)
+    if hit is None:
+        tx, ty, tz = get_voxels(mcb[0, 1], mcb[0, 0], mcb[1, 1], mcb[1, 0], mcb[2, 1], mcb[2, 0], voxel_size, resolution)
+        pts = torch.stack(torch.meshgrid(tx, ty, tz, indexing="ij"), -1).to(torch.float32).to(dev)
+        flat = pts.reshape(-1, 3)
+        if config["grid"]["tcnn_encoding"]:
+            flat = (flat - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])
+        if len(_LATTICE_CACHE) >= 4:
+            _LATTICE_CACHE.clear()
+        hit = _LATTICE_CACHE[key] = (tx, ty, tz, tuple(pts.shape), flat.contiguous())
+    tx, ty, tz, sh, flat = hit
     sdf = query_fn(flat[:, None, :]).reshape(sh[:-1]).to(torch.float32)
     weight = query_w_fn(flat[:, None, :]).reshape(sh[:-1])
     verts, faces = marching_cubes(sdf, isolevel, mask=weight > 0)
@@ -266,3 +278,127 @@ def write_ply(path: str, mesh: Dict) -> None:
         frec = np.zeros(f.shape[0], dtype=[("n", "u1"), ("i", "<i4", 3)])
         frec["n"], frec["i"] = 3, f
         fh.write(frec.tobytes())
+
+
+# ---- in-loop exports off the mapper's critical path ------------------------------------------------------------------
+class FieldSnapshot:
+    """A frozen copy of what a mesh export reads -- hash table, global volume (GBV / GBW), decoder weights -- with the three
+    point queries of ``JointEncoding`` on it (``query_sdf_res`` / ``query_w_res`` / ``query_color_residual``, reference
+    model/scene_rep.py:212-298): same kernels, same arithmetic, other buffers.  The reference meshes inside the mapper's loop
+    and blocks it (mp_slam/mapper.py:908-918); here the loop only takes the copy (D2D, ~0.1 ms for 320 MB) and a worker thread
+    sweeps the copy on a stream of its own while the next frames are mapped (``AsyncMeshExporter``)."""
+
+    def __init__(self, model):
+        self.model = model
+        enc = model.embed_res_fn
+        self.table = torch.empty_like(enc.params.detach())
+        self.gbv = torch.empty_like(model.GBV.params.detach())
+        self.gbw = torch.empty_like(model.GBW.params.detach())
+        self.weights = [torch.empty_like(w.detach()) for w in model.decoder_res.fused_weights()]
+        self.staged = torch.empty(int(_lib.load().rfx_field_staged_floats()), dtype=torch.float32, device=self.table.device)
+
+    def capture(self):
+        """on the caller's current stream: after it, the model may go on changing"""
+        m = self.model
+        with torch.no_grad():
+            self.table.copy_(m.embed_res_fn.params.detach())
+            self.gbv.copy_(m.GBV.params.detach())
+            self.gbw.copy_(m.GBW.params.detach())
+            for dst, src in zip(self.weights, m.decoder_res.fused_weights()):
+                dst.copy_(src.detach())
+
+    def _desc(self):
+        import ctypes as C
+        m = self.model
+        tr = m.config["training"]
+        d = _lib.FieldDesc()
+        d.hash = m.embed_res_fn.desc
+        d.hash_table, d.gbv = ptr(self.table), ptr(self.gbv)
+        d.gbv_res = int(m.config["globalV"]["base_resolution"])
+        d.w1, d.w2, d.w3, d.w4 = (ptr(w) for w in self.weights)
+        d.c_trunc, d.trunc = float(tr["c_trunc"]), float(tr["trunc"])
+        d.tsdf_scale = d.c_trunc / d.trunc
+        d.clamp_mode, d.clamp_hi = 0, 1.0
+        d.pos_fp16 = 1 if getattr(m.embedpos_fn, "fp16", False) else 0
+        d.staged = None
+        check(_lib.load().rfx_field_stage_weights(C.byref(d), ptr(self.staged), stream_ptr(self.staged.device)), "rfx_field_stage_weights")
+        d.staged = self.staged.data_ptr()
+        return d
+
+    @staticmethod
+    def _flat(q):
+        return torch.reshape(q, [-1, q.shape[-1]]).to(torch.float32).contiguous()
+
+    def query_sdf_res(self, query_points):
+        import ctypes as C
+        x = self._flat(query_points)
+        out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        d = self._desc()
+        check(_lib.load().rfx_field_query_sdf(C.byref(d), ptr(x), x.shape[0], ptr(out), stream_ptr(x.device)), "rfx_field_query_sdf")
+        return torch.reshape(out, list(query_points.shape[:-1]))
+
+    def query_w_res(self, query_points):
+        x = self._flat(query_points)
+        out = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+        check(_lib.load().rfx_grid_encode_forward(self.model.GBW.desc, ptr(self.gbw), ptr(x), x.shape[0], ptr(out), stream_ptr(x.device)),
+              "rfx_grid_encode_forward")
+        return torch.reshape(out, list(query_points.shape[:-1]))
+
+    def query_color_residual(self, query_points):
+        import ctypes as C
+        x = self._flat(query_points)
+        out = torch.empty((x.shape[0], 3), dtype=torch.float32, device=x.device)
+        d = self._desc()
+        check(_lib.load().rfx_field_query_color(C.byref(d), ptr(x), x.shape[0], ptr(out), stream_ptr(x.device)), "rfx_field_query_color")
+        return out
+
+
+class AsyncMeshExporter:
+    """at most ONE export in flight: ``submit`` first waits for the previous one (its snapshot buffers are re-used), copies the
+    field on the caller's stream, and hands the sweep + marching cubes + PLY write to a worker thread that runs them on a
+    side stream behind an event; ``result()`` joins and returns the last finished mesh (or re-raises the worker's exception)."""
+
+    def __init__(self, model, config, bounding_box, marching_cube_bound):
+        import threading
+        self._threading = threading
+        self.model, self.config, self.bb, self.mcb = model, config, bounding_box, marching_cube_bound
+        self.snapshot = None
+        self.stream = torch.cuda.Stream(device=bounding_box.device)
+        self._thread, self._mesh, self._error = None, None, None
+
+    def _work(self, path, voxel_size, ev):
+        try:
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                s = self.snapshot
+                mesh = extract_mesh(s.query_sdf_res, s.query_w_res, self.config, self.bb, color_func=s.query_color_residual,
+                                    marching_cube_bound=self.mcb, voxel_size=voxel_size)
+                import os
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                write_ply(path, mesh)
+                self.stream.synchronize()
+            self._mesh = mesh
+        except BaseException as e:          # noqa: BLE001 -- handed to the thread that asks for the result
+            self._error = e
+
+    def submit(self, path, voxel_size):
+        self.wait()
+        if self.snapshot is None:
+            self.snapshot = FieldSnapshot(self.model)
+        self.snapshot.capture()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._thread = self._threading.Thread(target=self._work, args=(path, voxel_size, ev), daemon=True)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+
+    def result(self):
+        self.wait()
+        return self._mesh

@@ -349,6 +349,18 @@ class Mapper:
             self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
         self._meshes_in_loop(current_map_id, batch)
 
+    @property
+    def last_mesh(self):
+        """the latest in-loop mesh (joins an export that is still running)"""
+        m = getattr(self, "_last_mesh", None)
+        return m.result() if hasattr(m, "result") else m
+
+    def wait_meshes(self):
+        """block until the in-loop exports issued so far are on disk"""
+        m = getattr(self, "_last_mesh", None)
+        if hasattr(m, "wait"):
+            m.wait()
+
     def sync_field(self):
         """collective on a sharded scene (every rank calls it): make this rank's copy of the hash table whole again before
         something reads all of it -- meshing, rendering, a checkpoint.  A no-op elsewhere."""
@@ -368,11 +380,15 @@ class Mapper:
                 self.sync_field()           # every rank: rank 0 is about to read the whole table
             if sh.rank != 0:
                 return
+        # mesh.async_export (default on): the loop copies the field and goes on; a worker thread sweeps the copy and writes the
+        # file (SLAM.save_mesh_async).  Off: the reference's blocking export.
+        asyn = bool(cfg["mesh"].get("async_export", True))
+        save = self.slam.save_mesh_async if asyn else self.slam.save_mesh
         if cfg["video"]["save"] and idx % cfg["video"]["save_freq"] == 0:
-            self.last_mesh = self.slam.save_mesh(idx, voxel_size=0.075)
+            self._last_mesh = save(idx, voxel_size=0.075)
         if idx % cfg["mesh"]["vis"] == 0:
             if not cfg["mesh"]["only_final"]:
-                self.last_mesh = self.slam.save_mesh(idx, voxel_size=0.1)
+                self._last_mesh = save(idx, voxel_size=0.1)
             # (mesh.render_img / pose_eval_func at this point of the reference are evaluation I/O: out of scope)
 
     def run(self):

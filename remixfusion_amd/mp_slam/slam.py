@@ -228,6 +228,17 @@ class SLAM:
         write_ply(path, mesh)
         return mesh
 
+    def save_mesh_async(self, i, voxel_size=0.05):
+        """save_mesh without blocking the caller: the field is copied now, swept and written by a worker thread on its own
+        stream (mesh.AsyncMeshExporter); the mesh is that of the field at the moment of the call.  Returns the exporter
+        (``.result()`` joins)."""
+        from ..mesh import AsyncMeshExporter
+        ex = getattr(self, "_mesh_exporter", None)
+        if ex is None:
+            ex = self._mesh_exporter = AsyncMeshExporter(self.model, self.config, self.bounding_box, self.marching_cube_bound)
+        ex.submit(self._mesh_path("mesh_track{}.ply".format(int(i))), voxel_size)
+        return ex
+
     def save_mesh(self, i, voxel_size=0.05):
         return self._save_mesh(self._mesh_path("mesh_track{}.ply".format(int(i))), self.model.query_sdf_res,
                                self.model.query_color_residual, voxel_size)

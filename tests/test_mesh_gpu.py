@@ -116,7 +116,20 @@ def test_mesh_of_a_mapped_scene(tmp_path):
         d = surface_distance(v.float())
         assert float(d.median()) < 0.03 and float((d < 0.1).float().mean()) > 0.9, (float(d.median()), float((d < 0.1).float().mean()))
         assert float(c.float().std()) > 5.0                    # colours vary over the checkerboard
+    # the export the mapper's loop uses (SLAM.save_mesh_async): the field is copied at the call, swept by a worker thread on a
+    # side stream -- the same mesh as the blocking export of the same state, even though the field moves on meanwhile
+    ref = pipe.slam.save_mesh(10)
+    ex = pipe.slam.save_mesh_async(11)
+    with torch.no_grad():
+        saved = pipe.model.embed_res_fn.params.detach().clone()
+        pipe.model.embed_res_fn.params.mul_(0.5)                # the mapper's next step, as far as the export is concerned
+    got = ex.result()
+    with torch.no_grad():
+        pipe.model.embed_res_fn.params.copy_(saved)
+    for k in ("vertices", "faces", "colors"):
+        assert torch.equal(got[k], ref[k]), k
     import os
+    assert os.path.getsize(os.path.join(str(tmp_path), "t", "mesh_track11.ply")) == os.path.getsize(os.path.join(str(tmp_path), "t", "mesh_track10.ply"))
     assert os.path.getsize(os.path.join(str(tmp_path), "t", "mesh_track10.ply")) > 10000
     with open(os.path.join(str(tmp_path), "t", "mesh_track10_ex.ply"), "rb") as fh:
         assert fh.readline().strip() == b"ply"
