@@ -68,6 +68,16 @@ class MappingPipeline:
             self.mv_stream = torch.cuda.Stream(device=self.device)
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))      # the volume was initialised there
             self.mv.producer_stream = self.mv_stream     # readers on other streams (get_volume_all, ...) wait for it
+        # With the tracker on, the reference runs tracker (+ moving volume) and mapper as two processes (run.py:56-60,
+        # mp_slam/tracker.py:173-197): the tracker's pose search reads its results back every iteration (20 host
+        # synchronisations per frame), and on ONE stream each of them also waits for whatever the mapper has queued (a 7 ms
+        # mapper step at scene0000 sizes), which serialises the two.  The tracker and its volume therefore get a stream of their
+        # own; the mapper's stream waits for it (an event, not the host) before it reads the poses the tracker wrote.
+        self.track_stream = None
+        if self.tracker is not None and self.device.type == "cuda" and config.get("pipeline", {}).get("track_stream", True):
+            self.track_stream = torch.cuda.Stream(device=self.device)
+            self.track_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self.mv.producer_stream = self.track_stream
         self.frames_done = 0
 
     def _make_volume(self, config, traj, pose0):
@@ -84,6 +94,8 @@ class MappingPipeline:
             out[i] = b
         if self.mv_stream is not None:                  # the frames above were produced on the current stream
             self.mv_stream.wait_stream(torch.cuda.current_stream(self.device))
+        if self.track_stream is not None:
+            self.track_stream.wait_stream(torch.cuda.current_stream(self.device))
         return out
 
     def start(self, batch0: Dict, first_iters: Optional[int] = None):
@@ -101,7 +113,12 @@ class MappingPipeline:
                 self.slam.est_c2w_data[0] = batch["c2w"].to(self.device)
                 self.slam.RO_c2w_data[0] = batch["c2w"].to(self.device)
             else:
-                self.tracker.tracking({k: v for k, v in batch.items() if k not in ("rgb255", "c2w_dev")}, i)
+                b = {k: v for k, v in batch.items() if k not in ("rgb255", "c2w_dev")}
+                if self.track_stream is None:
+                    self.tracker.tracking(b, i)
+                else:
+                    with torch.cuda.stream(self.track_stream):
+                        self.tracker.tracking(b, i)
                 self.slam.tracking_idx[0] = i
             return
         c2w = batch["c2w"]
@@ -151,6 +168,8 @@ class MappingPipeline:
         """make the current stream wait for the moving volume's stream (before reading the volume from it)"""
         if self.mv_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.mv_stream)
+        if self.track_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.track_stream)
 
     def step(self, i: int, batch: Dict):
         """one frame of the stream: V1 always; mapper step when the reference's loop would fire."""
@@ -160,5 +179,7 @@ class MappingPipeline:
             cur = int(self.slam.mapping_idx[0] + m["keyframe_every"])
             # the reference's mapper wakes when tracking_idx > mapping_idx + map_every (mapper.py:879)
             if i > int(self.slam.mapping_idx[0]) + m["map_every"] and cur < len(self.dataset):
+                if self.track_stream is not None:       # the poses up to frame i are written on the tracker's stream
+                    torch.cuda.current_stream(self.device).wait_stream(self.track_stream)
                 self.mapper.step(cur)
         self.frames_done += 1

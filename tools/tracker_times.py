@@ -1,0 +1,28 @@
+"""dev helper: wall time of the tracker's per-frame search and of the mapper step on the scene0000-sized stream (tracker on)"""
+import os, sys, time, random, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from remixfusion_amd.config import synthetic_config
+from remixfusion_amd.pipeline import MappingPipeline
+N = 61
+random.seed(0)
+cfg = synthetic_config("scene0000"); cfg["synthetic"].update({"tracker": True, "depth_noise": 0.0, "dropout": 0.0, "clutter": 48})
+cfg["mapping"]["first_iters"] = 50
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    pipe = MappingPipeline(cfg, n_frames=N + 8)
+frames = pipe.prefetch(list(range(N)))
+pipe.start(frames[0])
+tt, tm = [], []
+trk, mp = pipe.tracker.tracking, pipe.mapper.step
+def trk2(*a):
+    t0 = time.perf_counter(); r = trk(*a); tt.append(time.perf_counter() - t0); return r
+def mp2(*a):
+    t0 = time.perf_counter(); r = mp(*a); tm.append(time.perf_counter() - t0); return r
+pipe.tracker.tracking, pipe.mapper.step = trk2, mp2
+for i in range(1, 11): pipe.step(i, frames[i])
+torch.cuda.synchronize(); tt.clear(); tm.clear(); t0 = time.perf_counter()
+for i in range(11, N): pipe.step(i, frames[i])
+torch.cuda.synchronize(); el = time.perf_counter() - t0
+print(f"{(N - 11) / el:.1f} frames/s; tracking() per frame {np.mean(tt) * 1e3:.2f} ms (host wall, incl. its syncs); mapper.step per call {np.mean(tm) * 1e3:.2f} ms host wall, {len(tm)} calls; "
+      f"sum per frame {(sum(tt) + sum(tm)) / (N - 11) * 1e3:.2f} ms of {el / (N - 11) * 1e3:.2f}")
