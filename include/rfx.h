@@ -416,6 +416,13 @@ int rfx_tv_lattice(const float* u6, int P, float voxel, float margin, const doub
 int rfx_uniform_draws(uint64_t seed, int stream_id, int64_t n, float* out, rfx_stream stream);
 
 int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out, rfx_stream stream);
+/* The same with the population on the DEVICE: *population_dev (dev int64, <= fallback_population) if it exceeds k, else
+ * fallback_population, in which case *used_fallback_dev (dev int32, may be NULL) is set to 1 (else 0).  Replaces the
+ * `num_valid > num_rays_to_save ? sample(range(num_valid)) : sample(range(H*W))` of KeyFrameDatabase.sample_single_keyframe_rays
+ * (model/keyframe.py:37-47) without bringing num_valid to the host -- a synchronisation that would drain the mapper's queue
+ * once per keyframe.  Same permutation as rfx_random_subset(seed, N, k) for the N it ends up with. */
+int rfx_random_subset_dev(uint64_t seed, const int64_t* population_dev, int64_t fallback_population, int64_t k, int64_t* out,
+                          int32_t* used_fallback_dev, rfx_stream stream);
 
 /* M1 ray batch of one optimisation iteration: replaces the host glue of mp_slam/mapper.py:394-409
  * (KeyFrameDatabase.sample_global_rays + random.sample over the current frame + torch.cat + poses_all[ids]

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
     "rfx_random_subset": (_i, [C.c_uint64, _l, _l, _P, _P]),
     "rfx_uniform_draws": (_i, [C.c_uint64, _i, _l, _P, _P]),
+    "rfx_random_subset_dev": (_i, [C.c_uint64, _P, _l, _l, _P, _P, _P]),
     "rfx_grid_encode_backward_workspace_bytes_for": (C.c_size_t, [_P, _l]),
     "rfx_ba_workspace_bytes_for": (C.c_size_t, [_l, _i, _i, _P]),
     "rfx_track_vertex": (_i, [_P, _P, _F9, _i, _i, _f, _f, _f, C.c_uint32, _P, _P]),

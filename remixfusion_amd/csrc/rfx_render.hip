@@ -776,6 +776,23 @@ __global__ __launch_bounds__(256) void random_subset_kernel(uint64_t seed, int64
     out[i] = feistel_index(seed, i, N, half_bits);
 }
 
+// the same with the population read on the device: N = *population_dev if that exceeds k, else fallback_population (and
+// *used_fallback = 1).  For a caller that must not wait for a count it has just computed on the device: the keyframe store's
+// "k rays among those with a valid depth, or among all rays when too few are valid" (model/keyframe.py:37-47).
+__global__ __launch_bounds__(256) void random_subset_dev_kernel(uint64_t seed, const int64_t* __restrict__ population_dev,
+                                                                int64_t fallback, int64_t k, int64_t* __restrict__ out,
+                                                                int32_t* __restrict__ used_fallback) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cnt = *population_dev;
+    const bool fb = !(cnt > k);
+    const int64_t N = fb ? fallback : cnt;
+    if (i == 0 && used_fallback) *used_fallback = fb ? 1 : 0;
+    if (i >= k) return;
+    int bits = 1;
+    while (bits < 63 && (1LL << bits) < N) ++bits;
+    out[i] = feistel_index(seed, i, N, (bits + 1) / 2);
+}
+
 // ------------------------------------------------------------------ M1: ray batch of one BA iteration
 // Replaces the per-iteration host glue of mp_slam/mapper.py:394-409 (sample_global_rays + random.sample of
 // current-frame pixels + cat + poses_all[ids] + rays_o / rays_d): one launch draws both index sets,
@@ -1207,6 +1224,17 @@ int rfx_random_subset(uint64_t seed, int64_t population, int64_t k, int64_t* out
     if (half_bits > 31) return RFX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(random_subset_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
                        population, k, half_bits, out);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_random_subset_dev(uint64_t seed, const int64_t* population_dev, int64_t fallback_population, int64_t k, int64_t* out,
+                          int32_t* used_fallback_dev, rfx_stream stream) {
+    if (k == 0) return RFX_OK;
+    if (!out || !population_dev || fallback_population <= 0 || k < 0 || k > fallback_population) return RFX_ERR_ARG;
+    if (feistel_half_bits(fallback_population) > 31) return RFX_ERR_UNSUPPORTED;       // (*population_dev <= fallback is the caller's contract)
+    hipLaunchKernelGGL(random_subset_dev_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
+                       population_dev, fallback_population, k, out, used_fallback_dev);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

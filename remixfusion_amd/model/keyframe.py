@@ -51,6 +51,8 @@ class KeyFrameDatabase(object):
         rays_valid = None
         if option == "random":
             idx_t = self._choose(self.H * self.W, self.num_rays_to_save, rays.device)
+        elif option == "filter_depth" and self.device_sampling and rays.is_cuda:
+            return self._filter_depth_on_device(rays, first)
         elif option == "filter_depth":
             valid = (rays[..., -1] > 0.0) & (rays[..., -1] <= self.config["cam"]["depth_trunc"])
             rays_valid = rays[valid, :]
@@ -67,6 +69,27 @@ class KeyFrameDatabase(object):
         if option == "random" or first:
             return rays[:, idx_t]
         return rays_valid[idx_t, :]
+
+    def _filter_depth_on_device(self, rays, first):
+        """option 'filter_depth' (reference :37-52) without bringing the number of valid rays to the host: the boolean-mask
+        gather `rays[valid]` and `len(rays_valid)` of the reference wait for the device, i.e. for everything the mapper has
+        queued (5.6 ms per keyframe at scene0000 sizes, the frame loop's only synchronisation).  The k indices are drawn
+        among the valid rays by rfx_random_subset_dev (or among all rays when k or fewer are valid), and the j-th valid ray
+        is found by a search in the running count of valid rays.  Same distribution; the reference's quirk for the first
+        frame (indices drawn among the valid rays but applied to ALL rays) is kept."""
+        import random as _random
+        r = rays.reshape(-1, rays.shape[-1])
+        valid = (r[:, -1] > 0.0) & (r[:, -1] <= self.config["cam"]["depth_trunc"])
+        running = valid.to(torch.int64).cumsum(0)
+        k = self.num_rays_to_save
+        j = torch.empty(k, dtype=torch.int64, device=r.device)
+        fb = torch.empty(1, dtype=torch.int32, device=r.device)
+        _lib.check(_lib.load().rfx_random_subset_dev(_random.getrandbits(64), running[-1:].data_ptr(), r.shape[0], k, j.data_ptr(),
+                                                     fb.data_ptr(), _lib.stream_ptr(r.device)), "rfx_random_subset_dev")
+        if first:
+            return rays[:, j] if rays.dim() == 3 else r[j]
+        idx = torch.where(fb.bool(), j, torch.searchsorted(running, j + 1))
+        return r[idx]
 
     def attach_ids(self, frame_ids):
         n0 = 0 if self.frame_ids is None else len(self.frame_ids)

@@ -507,3 +507,49 @@ def test_one_call_iteration_equals_stagewise_on_both_sides_of_its_switches(sampl
                 assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
             assert float(r1[0].abs().max()) > 0
     direct.stagewise_every = 0
+
+
+def test_filter_depth_keyframe_rays_are_drawn_on_the_device_without_a_host_round_trip():
+    """KeyFrameDatabase.sample_single_keyframe_rays(option='filter_depth') (reference model/keyframe.py:37-52) with device
+    sampling: k distinct rays, all with a valid depth when more than k are valid, any rays when not; the first-frame quirk
+    (indices drawn among the valid rays, applied to all rays); and no synchronising call (torch's sync debug mode)."""
+    import random
+    import warnings
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.model.keyframe import KeyFrameDatabase
+    cfg = synthetic_config("scene0000")
+    H, W, k = 48, 64, 500
+    kf = KeyFrameDatabase(cfg, H, W, 4, k, torch.device("cuda"))
+    assert kf.device_sampling
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rays = torch.rand((1, H * W, 7), device="cuda", generator=g)
+    rays[..., :6] += torch.arange(H * W, device="cuda")[None, :, None]          # every ray recognisable
+    depth = torch.rand(H * W, device="cuda", generator=g) * 8.0                 # depth_trunc = 5: ~ 3/8 invalid
+    depth[::7] = 0.0
+    rays[0, :, 6] = depth
+    valid = (depth > 0) & (depth <= cfg["cam"]["depth_trunc"])
+    random.seed(1)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = kf.sample_single_keyframe_rays(rays, "filter_depth")
+            out_first = kf.sample_single_keyframe_rays(rays, "filter_depth", first=True)
+            few = rays.clone()
+            few[0, 300:, 6] = 0.0                                               # < k valid rays left: uniform over the frame
+            out_few = kf.sample_single_keyframe_rays(few, "filter_depth")
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert out.shape == (k, 7)
+    src = out[:, 0].floor().long()                                             # which ray each row is
+    assert torch.equal(out, rays[0, src]) and src.unique().numel() == k
+    assert bool(valid[src].all())
+    # uniform over the valid rays: the picks spread over the whole frame
+    assert int(src.min()) < H * W // 10 and int(src.max()) > H * W * 9 // 10
+    assert out_first.shape == (1, k, 7)
+    src1 = out_first[0, :, 0].floor().long()
+    assert src1.unique().numel() == k and int(src1.max()) < int(valid.sum())    # indices among the VALID count, applied to all rays
+    assert not bool(valid[src1].all())
+    srcf = out_few.reshape(-1, 7)[:, 0].floor().long()
+    assert srcf.unique().numel() == k and int((few[0, srcf, 6] == 0).sum()) > 0 and int(srcf.max()) > 300
