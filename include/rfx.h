@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 6
+#define RFX_ABI_VERSION 7
 
 typedef void* rfx_stream;
 
@@ -478,6 +478,44 @@ int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, i
                             const float* vertex4, const float* normal3, const float R[9], const float T[3],
                             const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
                             int level, int level_index, float* value, float* count, rfx_stream stream);
+
+/* ---- the whole pose search of one frame on the device (round 4) ------------------------------------------------------
+ * `random_optimization` (model/ROtracker.py:713-831) drives T3 from the host: 20 x (launch, copy 2 x P floats back, pick the
+ * candidates that beat candidate 0 in Python -- cal_transform :606-709 --, move the pose, rescale the search box :493-534).
+ * Here the pose, the search box and the loop's flags live in `state` on the device, T3 reads them from there and a one-block
+ * kernel does cal_transform + the bookkeeping, so a frame's search is 2 launches per iteration and the host reads `state`
+ * once, at the end.  Arithmetic follows the host loop (float32 state, float64 weighted sums in candidate order).
+ *
+ * templates[k] / template_rows[k] / n_eval[k] / level[k], k = `count_particle` 0..19: the template
+ * `ALL_PST[...]` of tiff_index[k] (dev [rows,6]), the number of its candidates T3 evaluates (`int(PST_size/1024)*1024`; the rest
+ * count as sum 0, as on the host) and depth_level[k].  x0, x1: the x-planes `tsdf` holds (whole volume: 0, dx).
+ * state words (float unless noted): 0..8 R, 9..11 T, 12..17 search_size, 18..23 previous_search_size, 24 min_tsdf of the last
+ * iteration; int32: 32 count_particle, 33 level_index, 34 success, 35 previous_success, 36 success of iteration 0,
+ * 37 error (1 = a selected candidate had 1 - |q|^2 < 0: the reference exits there, :662-669), 38 successful iterations,
+ * 39 iterations done.  value / count: dev [max template_rows] scratch, owned by the search between begin and the last update. */
+#define RFX_TRACK_STEPS 20
+#define RFX_TRACK_STATE_WORDS 64
+#define RFX_TRACK_MAX_COUNT_SEARCH 512
+typedef struct rfx_track_search {
+    const float* tsdf; int32_t dx, dy, dz, x0, x1; float origin[3]; float voxel;
+    const float* vertex4; const float* normal3;
+    const float* templates[RFX_TRACK_STEPS];
+    int32_t template_rows[RFX_TRACK_STEPS], n_eval[RFX_TRACK_STEPS], level[RFX_TRACK_STEPS];
+    float K[9]; int32_t H, W;
+    int32_t count_search, fix_level_index, iterative_scale, reserved;
+    double scaling_coefficient, beta;            /* RO.scaling_coefficient; the smoothing of the box (0.9 in the reference) */
+    float* state; float* value; float* count;
+} rfx_track_search;
+/* begin: state <- (R, T, search_size), flags cleared, level_index 5, value/count zeroed.  evaluate: T3 of the current state
+ * (adds this volume's -- or slab's -- sums into value/count).  update: cal_transform + bookkeeping of iteration `iteration`,
+ * then zeroes value/count.  Between evaluate and update a rank of a sharded volume adds value/count over the ranks.
+ * run = begin + iterations x (evaluate, update). */
+size_t rfx_track_search_bytes(void);           /* sizeof(rfx_track_search), for bindings to check their mirror */
+int rfx_track_search_begin(const rfx_track_search* s, const float R[9], const float T[3], const float search_size[6], rfx_stream stream);
+int rfx_track_search_evaluate(const rfx_track_search* s, rfx_stream stream);
+int rfx_track_search_update(const rfx_track_search* s, int iteration, rfx_stream stream);
+int rfx_track_search_run(const rfx_track_search* s, const float R[9], const float T[3], const float search_size[6], int iterations,
+                         rfx_stream stream);
 
 /* ---- iso-surface extraction -------------------------------------------------------
  * MC1/MC2 replace the host `skimage.measure.marching_cubes(raw, level=isolevel, mask=mask)` call of

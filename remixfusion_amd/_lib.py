@@ -70,6 +70,21 @@ class BaShard(C.Structure):
                 ("dx_recv", C.c_void_p)]
 
 
+RFX_TRACK_STEPS = 20
+RFX_TRACK_STATE_WORDS = 64
+RFX_TRACK_MAX_COUNT_SEARCH = 512
+
+
+class TrackSearch(C.Structure):
+    _fields_ = [("tsdf", C.c_void_p), ("dx", C.c_int32), ("dy", C.c_int32), ("dz", C.c_int32), ("x0", C.c_int32), ("x1", C.c_int32),
+                ("origin", C.c_float * 3), ("voxel", C.c_float), ("vertex4", C.c_void_p), ("normal3", C.c_void_p),
+                ("templates", C.c_void_p * RFX_TRACK_STEPS), ("template_rows", C.c_int32 * RFX_TRACK_STEPS),
+                ("n_eval", C.c_int32 * RFX_TRACK_STEPS), ("level", C.c_int32 * RFX_TRACK_STEPS), ("K", C.c_float * 9),
+                ("H", C.c_int32), ("W", C.c_int32), ("count_search", C.c_int32), ("fix_level_index", C.c_int32),
+                ("iterative_scale", C.c_int32), ("reserved", C.c_int32), ("scaling_coefficient", C.c_double), ("beta", C.c_double),
+                ("state", C.c_void_p), ("value", C.c_void_p), ("count", C.c_void_p)]
+
+
 class RbaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("hidden", C.c_int32)]
 
@@ -142,6 +157,11 @@ PROTOTYPES = {
     "rfx_tv_backward": (_i, [_P, _i, _i, _f, _P, _P, _P]),
     "rfx_random_subset": (_i, [C.c_uint64, _l, _l, _P, _P]),
     "rfx_uniform_draws": (_i, [C.c_uint64, _i, _l, _P, _P]),
+    "rfx_track_search_bytes": (_sz, []),
+    "rfx_track_search_begin": (_i, [_P, _F9, _F3, _F6, _P]),
+    "rfx_track_search_evaluate": (_i, [_P, _P]),
+    "rfx_track_search_update": (_i, [_P, _i, _P]),
+    "rfx_track_search_run": (_i, [_P, _F9, _F3, _F6, _i, _P]),
     "rfx_random_subset_dev": (_i, [C.c_uint64, _P, _l, _l, _P, _P, _P]),
     "rfx_grid_encode_backward_workspace_bytes_for": (C.c_size_t, [_P, _l]),
     "rfx_ba_workspace_bytes_for": (C.c_size_t, [_l, _i, _i, _P]),
@@ -197,7 +217,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 6:
+    if lib.rfx_abi_version() != 7:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")
@@ -205,6 +225,8 @@ def load() -> C.CDLL:
         raise RfxError("rfx_ba_desc layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
     if lib.rfx_ba_shard_bytes() != C.sizeof(BaShard):
         raise RfxError("rfx_ba_shard layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
+    if lib.rfx_track_search_bytes() != C.sizeof(TrackSearch):
+        raise RfxError("rfx_track_search layout mismatch between include/rfx.h and remixfusion_amd/_lib.py")
     _lib = lib
     return lib
 

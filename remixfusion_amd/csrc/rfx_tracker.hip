@@ -72,11 +72,10 @@ struct EvalK {
     int P, H, W, level, level_index, gh, gw, n_slabs;
 };
 
-__global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const float* __restrict__ tsdf,
-                                                             const float4* __restrict__ vertex, const float* __restrict__ n3,
-                                                             const float* __restrict__ q6, float* __restrict__ value,
-                                                             float* __restrict__ count) {
-    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+// one (candidate, pixel-slab) pair's share of compute_tsdf_value: thread = candidate `node`, walks pixel slab `slab`
+__device__ __forceinline__ void evaluate_share(const EvalK& E, int node, int slab, const float* __restrict__ tsdf,
+                                               const float4* __restrict__ vertex, const float* __restrict__ n3,
+                                               const float* __restrict__ q6, float* __restrict__ value, float* __restrict__ count) {
     const bool live = node < E.P;
     float tx = 0.f, ty = 0.f, tz = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
     if (live) {
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const floa
     const float q0 = sqrtf(madd(-q3, q3, madd(-q2, q2, madd(-q1, q1, 1.0f))));
     const int n_pix = E.gh * E.gw;
     const int per = (n_pix + E.n_slabs - 1) / E.n_slabs;
-    const int p0 = blockIdx.y * per, p1 = min(n_pix, p0 + per);
+    const int p0 = slab * per, p1 = min(n_pix, p0 + per);
     const int im_h = E.gh * E.level, im_w = E.gw * E.level;
     float acc = 0.f, cnt = 0.f;
     for (int p = p0; p < p1; ++p) {                      // wave-uniform pixel walk
@@ -127,6 +126,181 @@ __global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const floa
         if (E.n_slabs == 1) { value[node] = acc; count[node] = cnt; }
         else { atomicAdd(value + node, acc); atomicAdd(count + node, cnt); }
     }
+}
+
+__global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const float* __restrict__ tsdf,
+                                                             const float4* __restrict__ vertex, const float* __restrict__ n3,
+                                                             const float* __restrict__ q6, float* __restrict__ value,
+                                                             float* __restrict__ count) {
+    evaluate_share(E, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, tsdf, vertex, n3, q6, value, count);
+}
+
+// candidate blocks x pixel slabs of one evaluation: enough pairs to fill 256 CUs several times over
+__host__ __device__ inline int eval_slabs(int blocks_x, int n_pix) {
+    const int want = (256 * 8 + blocks_x - 1) / blocks_x;
+    const int s = want < n_pix ? want : n_pix;
+    return s > 1 ? s : 1;
+}
+
+// ---- the whole 20-iteration search on the device (rfx_track_search_*): the pose, the search box and the loop's flags live in
+// `state` (RFX_TRACK_STATE_WORDS words), every launch reads them from there, the host reads them once per frame.
+enum { ST_R = 0, ST_T = 9, ST_SS = 12, ST_PSS = 18, ST_MIN_TSDF = 24, ST_COUNT_PARTICLE = 32, ST_LEVEL_INDEX = 33, ST_SUCCESS = 34,
+       ST_PREVIOUS_SUCCESS = 35, ST_FIRST_SUCCESS = 36, ST_ERROR = 37, ST_N_SUCCESS = 38, ST_ITERATION = 39 };
+static_assert(RFX_TRACK_STATE_WORDS >= 40, "state words");
+
+struct SearchK {
+    const float* tsdf; const float4* vertex; const float* n3;
+    const float* templates[RFX_TRACK_STEPS];
+    int rows[RFX_TRACK_STEPS], n_eval[RFX_TRACK_STEPS], level[RFX_TRACK_STEPS];
+    float K[9];
+    int dx, dy, dz, x0, x1, ox, oy, oz, H, W;
+    float voxel;
+    int count_search, fix_level_index, iterative_scale, max_rows;
+    double scale_d;                                            // RO.scaling_coefficient as the host's Python float
+    float scale_f, beta, one_minus_beta;
+    float* state; float* value; float* count;
+};
+
+__global__ __launch_bounds__(64) void track_search_begin_kernel(float* __restrict__ state, float* __restrict__ value,
+                                                                float* __restrict__ count, int max_rows, EvalK init) {
+    int* si = reinterpret_cast<int*>(state);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (t < 9) state[ST_R + t] = init.R[t];
+        if (t < 3) state[ST_T + t] = init.T[t];
+        if (t < 6) { state[ST_SS + t] = init.ss[t]; state[ST_PSS + t] = 0.f; }
+        if (t >= 24 && t < RFX_TRACK_STATE_WORDS) si[t] = 0;
+        if (t == 0) si[ST_LEVEL_INDEX] = 5;                        // reference :737 `level_index = 5`
+    }
+    for (int i = t; i < max_rows; i += gridDim.x * blockDim.x) { value[i] = 0.f; count[i] = 0.f; }
+}
+
+__global__ __launch_bounds__(256) void track_search_evaluate_kernel(SearchK S) {
+    const int* si = reinterpret_cast<const int*>(S.state);
+    const int cp = si[ST_COUNT_PARTICLE];
+    EvalK E;
+    for (int i = 0; i < 9; ++i) { E.R[i] = S.state[ST_R + i]; E.K[i] = S.K[i]; }
+    for (int i = 0; i < 3; ++i) E.T[i] = S.state[ST_T + i];
+    for (int i = 0; i < 6; ++i) E.ss[i] = S.state[ST_SS + i];
+    E.dx = S.dx; E.dy = S.dy; E.dz = S.dz; E.ox = S.ox; E.oy = S.oy; E.oz = S.oz; E.x0 = S.x0; E.x1 = S.x1; E.voxel = S.voxel;
+    E.P = S.n_eval[cp]; E.H = S.H; E.W = S.W; E.level = S.level[cp]; E.level_index = si[ST_LEVEL_INDEX];
+    E.gh = S.H / E.level; E.gw = S.W / E.level;
+    const int blocks_x = (E.P + 255) / 256;
+    E.n_slabs = eval_slabs(blocks_x, E.gh * E.gw);
+    const int bx = blockIdx.x % blocks_x, slab = blockIdx.x / blocks_x;      // the grid is sized for the largest template
+    if (slab >= E.n_slabs) return;
+    evaluate_share(E, bx * 256 + threadIdx.x, slab, S.tsdf, S.vertex, S.n3, S.templates[cp], S.value, S.count);
+}
+
+// cal_transform + the bookkeeping of one iteration of random_optimization (model/ROtracker.py:606-709, :745-826), one block.
+// Arithmetic types follow the host loop of remixfusion_amd/model/ROtracker.py (float32 state, float64 weighted sums).
+__global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, int iteration) {
+    __shared__ int wave_total[16], wave_base[16];
+    __shared__ int sel_idx[RFX_TRACK_MAX_COUNT_SEARCH];
+    __shared__ float sel_fit[RFX_TRACK_MAX_COUNT_SEARCH];
+    __shared__ double col[9][RFX_TRACK_MAX_COUNT_SEARCH];
+    __shared__ double sums[9];
+    __shared__ int bad, n_better;
+    int* si = reinterpret_cast<int*>(S.state);
+    const int cp = si[ST_COUNT_PARTICLE];
+    const int n_all = S.rows[cp], P = S.n_eval[cp];
+    const float* __restrict__ cand = S.templates[cp];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float origin = S.value[0] / (S.count[0] + 1e-6f);
+    const int ipt = (n_all + 1023) / 1024;                         // <= 16 (checked on the host)
+    const int i0 = t * ipt, i1 = min(n_all, i0 + ipt);
+    if (t == 0) bad = 0;
+    // ---- rank of every candidate that beats candidate 0, in index order
+    int mine = 0;
+    for (int i = max(i0, 1); i < i1; ++i) {
+        const float m = i < P ? S.value[i] / (S.count[i] + 1e-6f) : 0.f;     // rows past P are never evaluated: sums 0 (host: zeros)
+        mine += m < origin ? 1 : 0;
+    }
+    int scan = mine;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(scan, d, 64); if (lane >= d) scan += o; }
+    if (lane == 63) wave_total[wave] = scan;
+    __syncthreads();
+    if (t == 0) { int a = 0; for (int w = 0; w < 16; ++w) { wave_base[w] = a; a += wave_total[w]; } n_better = a; }
+    __syncthreads();
+    int rank = wave_base[wave] + scan - mine;
+    for (int i = max(i0, 1); i < i1 && rank < S.count_search; ++i) {
+        const float m = i < P ? S.value[i] / (S.count[i] + 1e-6f) : 0.f;
+        if (m < origin) { sel_idx[rank] = i; sel_fit[rank] = m; ++rank; }
+    }
+    __syncthreads();
+    const int m_sel = min(n_better, S.count_search);
+    const float* ss = S.state + ST_SS;
+    if (t < m_sel) {
+        const int i = sel_idx[t];
+        const double fit = (double)sel_fit[t], w = (double)origin - fit;
+        const double c0 = cand[i * 6 + 0], c1 = cand[i * 6 + 1], c2 = cand[i * 6 + 2], c3 = cand[i * 6 + 3], c4 = cand[i * 6 + 4], c5 = cand[i * 6 + 5];
+        const double qx = c3 * (double)ss[3], qy = c4 * (double)ss[4], qz = c5 * (double)ss[5];
+        const double rad = 1.0 - ((qx * qx + qy * qy) + qz * qz);
+        if (rad < 0.0) atomicOr(&bad, 1);
+        col[0][t] = w; col[1][t] = fit * w; col[2][t] = c0 * w; col[3][t] = c1 * w; col[4][t] = c2 * w;
+        col[5][t] = sqrt(rad < 0.0 ? 0.0 : rad) * w; col[6][t] = c3 * w; col[7][t] = c4 * w; col[8][t] = c5 * w;
+    }
+    __syncthreads();
+    if (t < 9) { double a = 0.0; for (int k = 0; k < m_sel; ++k) a += col[t][k]; sums[t] = a; }   // in candidate order, like the reference's loop
+    __syncthreads();
+    // ---- zero the sums for the next evaluation
+    for (int i = t; i < S.max_rows; i += 1024) { S.value[i] = 0.f; S.count[i] = 0.f; }
+    if (t != 0) return;
+    float* st = S.state;
+    const bool success = m_sel > 0;
+    float mt[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    double tsdf_scale;                                             // `scale * tsdf` of update_PST
+    if (success) {
+        if (bad) si[ST_ERROR] = 1;                                 // invalid quaternion in the template (reference exits, :662-669)
+        const double sw = sums[0];
+        const double mean_tsdf = sums[1] / sw;
+        mt[0] = (float)(sums[2] / sw * (double)ss[0]); mt[1] = (float)(sums[3] / sw * (double)ss[1]); mt[2] = (float)(sums[4] / sw * (double)ss[2]);
+        const double q0 = sums[5] / sw, q1 = sums[6] / sw * (double)ss[3], q2 = sums[7] / sw * (double)ss[4], q3 = sums[8] / sw * (double)ss[5];
+        const double len = sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+        mt[3] = (float)(q0 / len); mt[4] = (float)(q1 / len); mt[5] = (float)(q2 / len); mt[6] = (float)(q3 / len);
+        tsdf_scale = S.scale_d * mean_tsdf;
+        st[ST_MIN_TSDF] = (float)mean_tsdf;
+    } else {
+        tsdf_scale = (double)(S.scale_f * origin);    // python float * np.float32 -> float32
+        st[ST_MIN_TSDF] = origin;
+    }
+    int count_particle = cp;
+    if (success) {
+        if (count_particle < RFX_TRACK_STEPS - 1) ++count_particle;
+        const float qw = mt[3], qx = mt[4], qy = mt[5], qz = mt[6];
+        const float Ri[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qz * qw), 2.f * (qx * qz + qy * qw),
+                             2.f * (qx * qy + qz * qw), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qx * qw),
+                             2.f * (qx * qz - qy * qw), 2.f * (qy * qz + qx * qw), 1.f - 2.f * (qx * qx + qy * qy)};
+        float Rn[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (Ri[r * 3] * st[ST_R + c] + Ri[r * 3 + 1] * st[ST_R + 3 + c]) + Ri[r * 3 + 2] * st[ST_R + 6 + c];
+        for (int k = 0; k < 9; ++k) st[ST_R + k] = Rn[k];
+        for (int k = 0; k < 3; ++k) st[ST_T + k] += mt[k];
+        si[ST_N_SUCCESS] += 1;
+    }
+    int level_index = S.fix_level_index ? 1 : si[ST_LEVEL_INDEX] + 5;
+    si[ST_LEVEL_INDEX] = level_index % S.level[count_particle];
+    si[ST_COUNT_PARTICLE] = success ? count_particle : 0;          // `if not success: count_particle = 0` at the top of the next iteration
+    {   // update_PST (reference :493-534)
+        const double min_scale = 1e-3;
+        double s[6] = {fabs((double)mt[0]) + min_scale, fabs((double)mt[1]) + min_scale, fabs((double)mt[2]) + min_scale,
+                       fabs((double)mt[4]) + min_scale, fabs((double)mt[5]) + min_scale, fabs((double)mt[6]) + min_scale};
+        double n2 = 0.0;
+        for (int k = 0; k < 6; ++k) n2 += s[k] * s[k];
+        const double nrm = sqrt(n2);
+        for (int k = 0; k < 6; ++k) st[ST_SS + k] = (float)(tsdf_scale * (s[k] / nrm) + min_scale);
+    }
+    const bool previous_success = si[ST_PREVIOUS_SUCCESS] != 0;
+    if (previous_success && success) {
+        for (int k = 0; k < 6; ++k) st[ST_SS + k] = S.beta * st[ST_SS + k] + S.one_minus_beta * st[ST_PSS + k];
+    } else if (success) {
+        if (S.iterative_scale) si[ST_PREVIOUS_SUCCESS] = 1;
+        for (int k = 0; k < 6; ++k) st[ST_PSS + k] = st[ST_SS + k];
+    }
+    if (!success) si[ST_PREVIOUS_SUCCESS] = 0;
+    if (iteration == 0) si[ST_FIRST_SUCCESS] = success ? 1 : 0;
+    si[ST_SUCCESS] = success ? 1 : 0;
+    si[ST_ITERATION] = iteration + 1;
 }
 
 }  // namespace rfx
@@ -180,13 +354,91 @@ int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, i
     const int n_pix = E.gh * E.gw;
     if (n_pix <= 0) return RFX_ERR_ARG;
     const int blocks_x = (n_candidates + 255) / 256;
-    // enough (candidate-block, pixel-slab) pairs to fill 256 CUs several times over
-    E.n_slabs = std::max(1, std::min(n_pix, (256 * 8 + blocks_x - 1) / blocks_x));
+    E.n_slabs = eval_slabs(blocks_x, n_pix);
     hipStream_t st = as_stream(stream);
     RFX_HIP_TRY(hipMemsetAsync(value, 0, sizeof(float) * n_candidates, st));
     RFX_HIP_TRY(hipMemsetAsync(count, 0, sizeof(float) * n_candidates, st));
     hipLaunchKernelGGL(track_evaluate_kernel, dim3(blocks_x, E.n_slabs), dim3(256), 0, st, E, tsdf,
                        reinterpret_cast<const float4*>(vertex4), normal3, q6, value, count);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+static int search_kernel_args(const rfx_track_search* s, SearchK* S, int* eval_blocks) {
+    if (!s || !s->tsdf || !s->vertex4 || !s->normal3 || !s->state || !s->value || !s->count) return RFX_ERR_ARG;
+    if (s->dx <= 2 || s->dy <= 2 || s->dz <= 2 || s->H <= 0 || s->W <= 0 || !(s->voxel > 0.f)) return RFX_ERR_ARG;
+    if (s->x0 < 0 || s->x1 > s->dx || s->x1 < s->x0) return RFX_ERR_ARG;
+    if (s->count_search <= 0 || s->count_search > RFX_TRACK_MAX_COUNT_SEARCH) return RFX_ERR_ARG;
+    if (((uintptr_t)s->vertex4 & 15) || ((uintptr_t)s->state & 15)) return RFX_ERR_ARG;
+    S->tsdf = s->tsdf; S->vertex = reinterpret_cast<const float4*>(s->vertex4); S->n3 = s->normal3;
+    int max_rows = 0, blocks = 0;
+    for (int k = 0; k < RFX_TRACK_STEPS; ++k) {
+        if (!s->templates[k] || s->template_rows[k] <= 0 || s->n_eval[k] <= 0 || s->n_eval[k] > s->template_rows[k] || s->level[k] <= 0)
+            return RFX_ERR_ARG;
+        if (s->template_rows[k] > 16 * 1024) return RFX_ERR_ARG;              // the update's block holds 16 candidates per thread
+        const int n_pix = (s->H / s->level[k]) * (s->W / s->level[k]);
+        if (n_pix <= 0) return RFX_ERR_ARG;
+        S->templates[k] = s->templates[k]; S->rows[k] = s->template_rows[k]; S->n_eval[k] = s->n_eval[k]; S->level[k] = s->level[k];
+        max_rows = std::max(max_rows, s->template_rows[k]);
+        const int bx = (s->n_eval[k] + 255) / 256;
+        blocks = std::max(blocks, bx * eval_slabs(bx, n_pix));
+    }
+    for (int i = 0; i < 9; ++i) S->K[i] = s->K[i];
+    S->dx = s->dx; S->dy = s->dy; S->dz = s->dz; S->x0 = s->x0; S->x1 = s->x1;
+    S->ox = (int)s->origin[0]; S->oy = (int)s->origin[1]; S->oz = (int)s->origin[2];
+    S->H = s->H; S->W = s->W; S->voxel = s->voxel;
+    S->count_search = s->count_search; S->fix_level_index = s->fix_level_index; S->iterative_scale = s->iterative_scale;
+    S->max_rows = max_rows;
+    S->scale_d = s->scaling_coefficient; S->scale_f = (float)s->scaling_coefficient;
+    S->beta = (float)s->beta; S->one_minus_beta = (float)(1.0 - s->beta);
+    S->state = s->state; S->value = s->value; S->count = s->count;
+    *eval_blocks = blocks;
+    return RFX_OK;
+}
+
+size_t rfx_track_search_bytes(void) { return sizeof(rfx_track_search); }
+
+int rfx_track_search_begin(const rfx_track_search* s, const float R[9], const float T[3], const float search_size[6], rfx_stream stream) {
+    SearchK S; int blocks;
+    if (int rc = search_kernel_args(s, &S, &blocks)) return rc;
+    if (!R || !T || !search_size) return RFX_ERR_ARG;
+    EvalK init = {};
+    for (int i = 0; i < 9; ++i) init.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) init.T[i] = T[i];
+    for (int i = 0; i < 6; ++i) init.ss[i] = search_size[i];
+    hipLaunchKernelGGL(track_search_begin_kernel, dim3((S.max_rows + 63) / 64), dim3(64), 0, as_stream(stream), S.state, S.value, S.count,
+                       S.max_rows, init);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_track_search_evaluate(const rfx_track_search* s, rfx_stream stream) {
+    SearchK S; int blocks;
+    if (int rc = search_kernel_args(s, &S, &blocks)) return rc;
+    hipLaunchKernelGGL(track_search_evaluate_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), S);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_track_search_update(const rfx_track_search* s, int iteration, rfx_stream stream) {
+    SearchK S; int blocks;
+    if (int rc = search_kernel_args(s, &S, &blocks)) return rc;
+    if (iteration < 0) return RFX_ERR_ARG;
+    hipLaunchKernelGGL(track_search_update_kernel, dim3(1), dim3(1024), 0, as_stream(stream), S, iteration);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+int rfx_track_search_run(const rfx_track_search* s, const float R[9], const float T[3], const float search_size[6], int iterations,
+                         rfx_stream stream) {
+    SearchK S; int blocks;
+    if (int rc = search_kernel_args(s, &S, &blocks)) return rc;
+    if (iterations < 0) return RFX_ERR_ARG;
+    if (int rc = rfx_track_search_begin(s, R, T, search_size, stream)) return rc;
+    for (int i = 0; i < iterations; ++i) {
+        hipLaunchKernelGGL(track_search_evaluate_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), S);
+        hipLaunchKernelGGL(track_search_update_kernel, dim3(1), dim3(1024), 0, as_stream(stream), S, i);
+    }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -472,6 +472,16 @@ class sharded_volume(moving_volume):
                                                   int(level_index), ptr(value), ptr(count), stream_ptr(self.device)), "rfx_track_evaluate_slab")
         all_reduce_sum_(self.dist, [value, count])
 
+    def track_search_volume(self):
+        self._wait_for_producer()
+        d = self.vol_dim
+        return {"tsdf": self.tsdf_vol_gpu, "dim": (int(d[0]), int(d[1]), int(d[2])), "slab": self._slab(),
+                "origin": self.vol_origin, "voxel": float(self.voxel_size)}
+
+    def track_search_reduce(self, sums):
+        """value / count of one evaluation of the device-side search (rfx_track_search_evaluate), added over the slabs"""
+        all_reduce_sum_(self.dist, [sums])
+
     def copy_volume(self):
         """front -> back on this slab; remembers the layout of the copy (see update_tsdf_swap_rot_trans)"""
         super().copy_volume()

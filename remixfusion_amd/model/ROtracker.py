@@ -11,7 +11,11 @@ Differences, on purpose:
     selection: the first ``count_search`` candidates that beat candidate 0, same weights);
   * compute_vertex's cuRAND jitter is replaced by a counter-based hash (exactly zero anyway for
     RO.sample_range = 0, which every reference config uses);
-  * mesh dumps (RO.save_volume) are CPU debug I/O and not built.
+  * mesh dumps (RO.save_volume) are CPU debug I/O and not built;
+  * the 20 iterations of ``random_optimization`` run on the device by default (``RO.device_search``, librfx
+    ``rfx_track_search_*``): the pose, the search box and the loop's flags stay in device memory and the host reads them
+    once per frame instead of copying 2 x P sums back and selecting candidates in numpy 20 times.  The host loop below is the
+    restatement of the reference's and stays (``RO.device_search: False``); tests compare the two.
 """
 from __future__ import annotations
 
@@ -49,6 +53,7 @@ class ROTracker(object):
         self.truncation = cfg["volume"]["trunc"]
         self.sample_range = ro["sample_range"]
         self.iterative_scale = ro["iterative_scale"]
+        self.device_search = bool(ro.get("device_search", True))
         self.get_pc = cfg["training"]["surface_weight"] > 0
         self.traj = Trajectory("./results/")
         self.start_frame, self.end_frame = 0, len(self.data_stream)
@@ -144,6 +149,81 @@ class ROTracker(object):
         sv[:P], sc[:P] = both[0], both[1]
         return sv / (sc + 1e-6), sv, sc
 
+    # ------------------------------------------------------------------ the search on the device
+    def _search_desc(self, cam_intr):
+        """rfx_track_search for the volume as it is NOW (it moves and re-grids between frames) + the scratch it owns"""
+        if getattr(self, "_search_state", None) is None:
+            rows = max(int(a.shape[1]) for a in self.ALL_PST_dev.values())
+            self._search_state = torch.zeros(_lib.RFX_TRACK_STATE_WORDS, dtype=torch.float32, device=self.device)
+            self._search_sums = torch.zeros((2, rows), dtype=torch.float32, device=self.device)
+        s = _lib.TrackSearch()
+        vol = self.MV.track_search_volume()
+        s.tsdf = ptr(vol["tsdf"])
+        s.dx, s.dy, s.dz = (int(v) for v in vol["dim"])
+        s.x0, s.x1 = (int(v) for v in vol["slab"])
+        for i in range(3):
+            s.origin[i] = float(np.float32(vol["origin"][i]))
+        s.voxel = float(vol["voxel"])
+        s.vertex4, s.normal3 = ptr(self.depth_vertex_gpu), ptr(self.normal_vertex_gpu)
+        for k in range(_lib.RFX_TRACK_STEPS):
+            t = self._get_PST_dev(self.tiff_index[k])
+            s.templates[k] = t.data_ptr()
+            s.template_rows[k] = int(t.shape[0])
+            s.n_eval[k] = int(self.PST_size[k % 3] // 1024) * 1024
+            s.level[k] = int(self.depth_level[k])
+        for i, v in enumerate(np.asarray(cam_intr, np.float32).reshape(-1)):
+            s.K[i] = float(v)
+        s.H, s.W = int(self.im_h), int(self.im_w)
+        s.count_search, s.fix_level_index = int(self.count_search), int(bool(self.fix_level_index))
+        s.iterative_scale = int(bool(self.iterative_scale))
+        s.scaling_coefficient = float(self.scaling_coefficient)
+        s.state, s.value, s.count = ptr(self._search_state), ptr(self._search_sums[0]), ptr(self._search_sums[1])
+        return s
+
+    def random_optimization_device(self, cur_id, cam_pose, rgb_im, depth_im, cam_intr, beta=0.9, inherit=False):
+        """``random_optimization`` with the loop on the device: 2 launches per iteration, ONE device->host copy per frame
+        (the 64-word state: pose, search box, flags).  Same arithmetic as the host loop below."""
+        import ctypes as C
+        lib = _lib.load()
+        R0 = np.asarray(cam_pose[:3, :3], np.float32).copy()
+        T0 = np.asarray(cam_pose[:3, 3], np.float32).copy()
+        if inherit is True and self.previous_frame_success:
+            self.search_size = self.initialize_search_size
+        else:
+            self.init_searchsize()
+        self.init_depth_vertex(depth_im, cam_intr)
+        self.init_normal()
+        s = self._search_desc(cam_intr)
+        s.beta = float(beta)
+        st = stream_ptr(self.device)
+        args = (farr(_F9, R0.reshape(-1)), farr(_F3, T0), farr(_F6, self.search_size))
+        if self.MV.track_search_reduce is None:
+            check(lib.rfx_track_search_run(C.byref(s), *args, int(self.particle_iter_lens), st), "rfx_track_search_run")
+        else:                                        # a slab of a sharded volume: the sums are added over the ranks in between
+            check(lib.rfx_track_search_begin(C.byref(s), *args, st), "rfx_track_search_begin")
+            for i in range(self.particle_iter_lens):
+                check(lib.rfx_track_search_evaluate(C.byref(s), st), "rfx_track_search_evaluate")
+                self.MV.track_search_reduce(self._search_sums)
+                check(lib.rfx_track_search_update(C.byref(s), i, st), "rfx_track_search_update")
+        state = self._search_state.cpu().numpy()                 # the frame's one synchronisation
+        flags = state.view(np.int32)
+        if flags[37]:
+            raise ValueError("invalid quaternion in the particle template (reference exits here, :662-669)")
+        self.current_global_R = state[0:9].reshape(3, 3).copy()
+        self.current_global_T = state[9:12].copy()
+        self.search_size = state[12:18].copy()
+        self.previous_search_size = state[18:24].copy()
+        self.search_successes = int(flags[38])
+        if flags[36]:                                            # iteration 0 succeeded (reference :816-821)
+            self.initialize_search_size = self.search_size
+            self.previous_frame_success = True
+        else:
+            self.previous_frame_success = False
+        cam_pose_iter = np.eye(4, dtype=np.float32)
+        cam_pose_iter[:3, :3] = self.current_global_R
+        cam_pose_iter[:3, 3] = self.current_global_T
+        return cam_pose_iter
+
     # ------------------------------------------------------------------ host logic
     def update_PST(self, tsdf, mean_transform, min_scale=1e-3, scale=0.09):
         """anisotropic search-size update (reference :493-534)."""
@@ -178,6 +258,42 @@ class ROTracker(object):
         mean_transform[3:7] = qm / np.sqrt((qm ** 2).sum())
         return True, mean_tsdf, mean_transform
 
+    def _search_step(self, i, st, search_value, beta):
+        """what one iteration does with the candidates' fitness (reference :745-826): move to the weighted mean, pick the next
+        template and pixel offset, rescale and smooth the search box.  ``st``: the loop's success / previous_success /
+        count_particle / level_index.  (The device-side search does the same in rfx_track_search_update.)"""
+        success, min_tsdf, mean_transform = self.cal_transform(search_value)
+        st["success"] = success
+        count_particle = st["count_particle"]
+        qw, qx, qy, qz = mean_transform[3:7]
+        if success:
+            if count_particle < 19:
+                count_particle += 1
+            Rinc = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                             [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                             [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]], dtype=np.float32)
+            self.current_global_T += mean_transform[:3]
+            self.current_global_R = np.matmul(Rinc, self.current_global_R)
+        st["count_particle"] = count_particle
+        level_index = 1 if self.fix_level_index else st["level_index"] + 5
+        st["level_index"] = level_index % (self.depth_level[count_particle])
+        st["min_tsdf"] = min_tsdf
+        self.update_PST(min_tsdf, mean_transform, scale=self.scaling_coefficient)
+        if st["previous_success"] and success:
+            self.search_size[:] = beta * self.search_size + (1 - beta) * self.previous_search_size
+        elif success:
+            if self.iterative_scale:
+                st["previous_success"] = True
+            self.previous_search_size[:] = self.search_size
+        if not success:
+            st["previous_success"] = False
+        if i == 0:
+            if success:
+                self.initialize_search_size = self.search_size
+                self.previous_frame_success = True
+            else:
+                self.previous_frame_success = False
+
     def random_optimization(self, cur_id, cam_pose, rgb_im, depth_im, cam_intr, beta=0.9, inherit=False):
         """20 iterations of: evaluate the particle set around the current pose, move to the fitness-weighted
         mean, rescale the search box (reference :713-831)."""
@@ -189,42 +305,17 @@ class ROTracker(object):
             self.init_searchsize()
         self.init_depth_vertex(depth_im, cam_intr)
         self.init_normal()
-        previous_success, success, count_particle, level_index = False, False, 0, 5
+        st = {"previous_success": False, "success": False, "count_particle": 0, "level_index": 5}
         for i in range(self.particle_iter_lens):
-            if not success:
-                count_particle = 0
+            if not st["success"]:
+                st["count_particle"] = 0
+            count_particle = st["count_particle"]
             PST_class = count_particle % 3
             self.transform_candidate = self.get_PST(self.tiff_index[count_particle])
             self._cand_dev = self._get_PST_dev(self.tiff_index[count_particle])
             level = self.depth_level[count_particle]
-            search_value, sv, sc = self.evaluate_tsdf(cur_id, level, self.PST_size[PST_class], cam_intr, level_index)
-            success, min_tsdf, mean_transform = self.cal_transform(search_value)
-            qw, qx, qy, qz = mean_transform[3:7]
-            if success:
-                if count_particle < 19:
-                    count_particle += 1
-                Rinc = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
-                                 [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
-                                 [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]], dtype=np.float32)
-                self.current_global_T += mean_transform[:3]
-                self.current_global_R = np.matmul(Rinc, self.current_global_R)
-            level_index = 1 if self.fix_level_index else level_index + 5
-            level_index = level_index % (self.depth_level[count_particle])
-            self.update_PST(min_tsdf, mean_transform, scale=self.scaling_coefficient)
-            if previous_success and success:
-                self.search_size[:] = beta * self.search_size + (1 - beta) * self.previous_search_size
-            elif success:
-                if self.iterative_scale:
-                    previous_success = True
-                self.previous_search_size[:] = self.search_size
-            if not success:
-                previous_success = False
-            if i == 0:
-                if success:
-                    self.initialize_search_size = self.search_size
-                    self.previous_frame_success = True
-                else:
-                    self.previous_frame_success = False
+            search_value, sv, sc = self.evaluate_tsdf(cur_id, level, self.PST_size[PST_class], cam_intr, st["level_index"])
+            self._search_step(i, st, search_value, beta)
         cam_pose_iter = np.eye(4, dtype=np.float32)
         cam_pose_iter[:3, :3] = self.current_global_R
         cam_pose_iter[:3, 3] = self.current_global_T
@@ -237,7 +328,8 @@ class ROTracker(object):
         depth = batch["depth"].squeeze()
         rgb = torch.floor(batch["rgb"].squeeze() * 255.0)
         self.gt_pose = batch["c2w"].squeeze().cpu().numpy()
-        cam_pose_iter = self.random_optimization(batch["frame_id"], init_pose, rgb, depth, self.K)
+        search = self.random_optimization_device if self.device_search else self.random_optimization
+        cam_pose_iter = search(batch["frame_id"], init_pose, rgb, depth, self.K)
         return cam_pose_iter, rgb, depth
 
     def post_processing(self, cur_id, cam_pose_iter, rgb, depth, est_c2w_data):

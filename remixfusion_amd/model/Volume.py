@@ -252,6 +252,14 @@ class moving_volume:
                                              farr(_F6, search_size), int(n_cand), farr(_F9, K9), int(H), int(W), int(level),
                                              int(level_index), ptr(value), ptr(count), stream_ptr(self.device)), "rfx_track_evaluate")
 
+    # the device-side search (rfx_track_search_*): what it reads of this volume; a sharded volume overrides both
+    track_search_reduce = None                         # callable(sums [2, rows]) adding the evaluation's sums over ranks, or None
+
+    def track_search_volume(self):
+        d = self.vol_dim
+        return {"tsdf": self.tsdf_vol_gpu, "dim": (int(d[0]), int(d[1]), int(d[2])), "slab": (0, int(d[0])),
+                "origin": self.vol_origin, "voxel": float(self.voxel_size)}
+
     def get_volume_all(self):
         """D2H copy of the three volumes, flat, z fastest (reference :1265-1277)."""
         self._wait_for_producer()

@@ -120,3 +120,118 @@ def test_rotracker_recovers_a_perturbed_pose():
     tr.current_global_R, tr.current_global_T = est[:3, :3].copy(), est[:3, 3].copy()
     f_est = tr.evaluate_tsdf(6, 16, 10240, tr.K, 3)[0][0]
     assert f_est < f_init
+
+
+def _tracker_with_a_map(device_search):
+    import random
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.datasets import get_dataset
+    from remixfusion_amd.model.ROtracker import ROTracker
+    random.seed(0)
+    cfg = synthetic_config("office0")
+    cfg["cam"].update({"H": 240, "W": 320, "fx": 288.0, "fy": 288.0, "cx": 159.5, "cy": 119.5})
+    cfg["volume"].update({"voxel_size": 0.02, "trunc": 0.06})
+    cfg["synthetic"].update({"depth_noise": 0.0, "dropout": 0.0, "clutter": 24})
+    cfg["RO"]["device_search"] = device_search
+    ds = get_dataset(cfg, device="cuda", n_frames=12)
+    tr = ROTracker(cfg, ds)
+    for i in range(1, 6):
+        b = ds[i]
+        tr.post_processing(i, b["c2w"].numpy(), torch.floor(b["rgb"] * 255.0), b["depth"], None)
+    b = ds[6]
+    gt = b["c2w"].numpy()
+    init = gt.copy()
+    init[:3, 3] += 0.03 * gt[:3, 2]
+    ang = 0.02
+    init[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32) @ init[:3, :3]
+    return tr, b, gt, init
+
+
+def test_device_search_iterations_follow_the_host_loop_step_by_step():
+    """rfx_track_search_* (the 20 iterations of random_optimization on the device) against the host loop, ONE ITERATION AT A
+    TIME on the same inputs: T3 from the device state gives the sums rfx_track_evaluate gives for the same pose and box (hit
+    counts exactly); fed those very sums, the host's cal_transform + bookkeeping (model/ROtracker.py `_search_step`,
+    reference :606-709, :745-826, :493-534) and rfx_track_search_update leave the same pose, search box, template index,
+    pixel offset and flags -- every iteration of a 20-iteration search, including failed ones (a second search starts 50 m away,
+    where no vertex meets the volume and no candidate beats the null candidate)."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    tr, b, gt, init = _tracker_with_a_map(True)
+    st_ptr = L.stream_ptr(tr.device)
+    n_failed = n_succeeded = 0
+    far = init.copy()
+    far[:3, 3] += 50.0
+    for start, box in ((init, None), (far, None)):
+        tr.current_global_R = np.asarray(start[:3, :3], np.float32).copy()
+        tr.current_global_T = np.asarray(start[:3, 3], np.float32).copy()
+        tr.init_searchsize()
+        tr.init_depth_vertex(b["depth"].squeeze(), tr.K)
+        tr.init_normal()
+        s = tr._search_desc(tr.K)
+        s.beta = 0.9
+        L.check(lib.rfx_track_search_begin(C.byref(s), L.farr(L._F9, tr.current_global_R.reshape(-1)), L.farr(L._F3, tr.current_global_T),
+                                           L.farr(L._F6, tr.search_size), st_ptr), "begin")
+        host = {"previous_success": False, "success": False, "count_particle": 0, "level_index": 5}
+        for i in range(20):
+            if not host["success"]:
+                host["count_particle"] = 0
+            cp = host["count_particle"]
+            state = tr._search_state.cpu().numpy()
+            flags = state.view(np.int32)
+            assert flags[32] == cp and flags[33] == host["level_index"] and flags[39] == i
+            # ---- the evaluation: from the device state == from host arguments
+            L.check(lib.rfx_track_search_evaluate(C.byref(s), st_ptr), "evaluate")
+            sums = tr._search_sums.cpu().numpy().copy()
+            tr.transform_candidate = tr.get_PST(tr.tiff_index[cp])
+            tr._cand_dev = tr._get_PST_dev(tr.tiff_index[cp])
+            P = int(tr.PST_size[cp % 3] // 1024) * 1024
+            _, sv, sc = tr.evaluate_tsdf(6, tr.depth_level[cp], tr.PST_size[cp % 3], tr.K, host["level_index"])
+            assert np.array_equal(sums[1, :P], sc[:P]) and (sc[:P].max() > 50) == (start is init)
+            assert np.abs(sums[0, :P] - sv[:P]).max() <= 2e-5 * np.abs(sv[:P]).max()
+            assert not sums[:, P:].any()
+            # ---- the update: host step on the device's sums
+            n_all = tr.transform_candidate.shape[0]
+            dv, dc = np.zeros(n_all, np.float32), np.zeros(n_all, np.float32)
+            dv[:P], dc[:P] = sums[0, :P], sums[1, :P]
+            tr._search_step(i, host, dv / (dc + 1e-6), 0.9)
+            L.check(lib.rfx_track_search_update(C.byref(s), i, st_ptr), "update")
+            state = tr._search_state.cpu().numpy()
+            flags = state.view(np.int32)
+            tag = (start is init, i, host)
+            assert bool(flags[34]) == host["success"] and bool(flags[35]) == host["previous_success"], tag
+            assert flags[32] == (host["count_particle"] if host["success"] else 0) and flags[33] == host["level_index"], tag
+            assert flags[37] == 0
+            n_failed += not host["success"]
+            n_succeeded += bool(host["success"])
+            assert np.abs(state[0:9].reshape(3, 3) - tr.current_global_R).max() <= 3e-7, tag       # float32 3x3 product: BLAS may fuse
+            assert np.abs(state[9:12] - tr.current_global_T).max() <= 1.5e-7 * max(1.0, np.abs(tr.current_global_T).max()), tag
+            assert np.allclose(state[12:18], tr.search_size, rtol=2e-6, atol=0), tag
+            assert np.allclose(state[18:24], tr.previous_search_size, rtol=2e-6, atol=0), tag
+            assert np.isclose(state[24], np.float32(host["min_tsdf"]), rtol=2e-6), tag
+            assert not tr._search_sums.any()                                                  # zeroed for the next evaluation
+            # continue from the device's numbers, so that every iteration is compared on identical inputs
+            tr.current_global_R, tr.current_global_T = state[0:9].reshape(3, 3).copy(), state[9:12].copy()
+            tr.search_size[:] = state[12:18]
+            tr.previous_search_size[:] = state[18:24]
+    assert n_succeeded >= 10 and n_failed >= 10, (n_succeeded, n_failed)
+
+
+def test_device_search_finds_the_pose_the_host_loop_finds():
+    """a whole frame: rfx_track_search_run (one device->host copy) against the host loop from the same perturbed pose -- both
+    recover it, to the same accuracy (the two differ only through the float atomics' order in the evaluation sums, which the
+    search amplifies like any perturbation of its fitness values)."""
+    est = {}
+    for dev in (True, False):
+        tr, b, gt, init = _tracker_with_a_map(dev)
+        est[dev], _, _ = tr.do_tracking(init, None, b, "cuda")
+        if dev:
+            assert tr.search_successes >= 5
+    fwd = gt[:3, 2]
+    e0 = abs(float((init[:3, 3] - gt[:3, 3]) @ fwd))
+    for dev in (True, False):
+        e1 = abs(float((est[dev][:3, 3] - gt[:3, 3]) @ fwd))
+        r1 = np.arccos(np.clip((np.trace(est[dev][:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1))
+        assert e1 < 0.5 * e0 and r1 < 0.012, (dev, e0, e1, r1)
+    assert np.abs(est[True][:3, 3] - est[False][:3, 3]).max() < 2e-3
+    assert np.abs(est[True][:3, :3] - est[False][:3, :3]).max() < 2e-3
