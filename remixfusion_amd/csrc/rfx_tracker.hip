@@ -156,8 +156,7 @@ struct SearchK {
     int dx, dy, dz, x0, x1, ox, oy, oz, H, W;
     float voxel;
     int count_search, fix_level_index, iterative_scale, max_rows;
-    double scale_d;                                            // RO.scaling_coefficient as the host's Python float
-    float scale_f, beta, one_minus_beta;
+    double scale_d, beta_d;                                    // RO.scaling_coefficient, beta as the host's Python floats
     float* state; float* value; float* count;
 };
 
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256) void track_search_evaluate_kernel(SearchK S) {
 }
 
 // cal_transform + the bookkeeping of one iteration of random_optimization (model/ROtracker.py:606-709, :745-826), one block.
-// Arithmetic types follow the host loop of remixfusion_amd/model/ROtracker.py (float32 state, float64 weighted sums).
+// Arithmetic types follow the host loop of remixfusion_amd/model/ROtracker.py = the reference under its numpy 1.21.6.
 __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, int iteration) {
     __shared__ int wave_total[16], wave_base[16];
     __shared__ int sel_idx[RFX_TRACK_MAX_COUNT_SEARCH];
@@ -231,14 +230,17 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
     const int m_sel = min(n_better, S.count_search);
     const float* ss = S.state + ST_SS;
     if (t < m_sel) {
+        // types as the reference's numpy (1.21.6) gives them (oracle/tracker_host_oracle.py): float32 weights and products,
+        // float64 sums; -ffp-contract=off keeps every product a rounded float32
         const int i = sel_idx[t];
-        const double fit = (double)sel_fit[t], w = (double)origin - fit;
-        const double c0 = cand[i * 6 + 0], c1 = cand[i * 6 + 1], c2 = cand[i * 6 + 2], c3 = cand[i * 6 + 3], c4 = cand[i * 6 + 4], c5 = cand[i * 6 + 5];
-        const double qx = c3 * (double)ss[3], qy = c4 * (double)ss[4], qz = c5 * (double)ss[5];
-        const double rad = 1.0 - ((qx * qx + qy * qy) + qz * qz);
+        const float fit = sel_fit[t], w = origin - fit;
+        const float c0 = cand[i * 6 + 0], c1 = cand[i * 6 + 1], c2 = cand[i * 6 + 2], c3 = cand[i * 6 + 3], c4 = cand[i * 6 + 4], c5 = cand[i * 6 + 5];
+        const float qx = c3 * ss[3], qy = c4 * ss[4], qz = c5 * ss[5];
+        const double rad = ((1.0 - (double)(qx * qx)) - (double)(qy * qy)) - (double)(qz * qz);
         if (rad < 0.0) atomicOr(&bad, 1);
-        col[0][t] = w; col[1][t] = fit * w; col[2][t] = c0 * w; col[3][t] = c1 * w; col[4][t] = c2 * w;
-        col[5][t] = sqrt(rad < 0.0 ? 0.0 : rad) * w; col[6][t] = c3 * w; col[7][t] = c4 * w; col[8][t] = c5 * w;
+        col[0][t] = (double)w; col[1][t] = (double)(fit * w); col[2][t] = (double)(c0 * w); col[3][t] = (double)(c1 * w);
+        col[4][t] = (double)(c2 * w); col[5][t] = sqrt(rad < 0.0 ? 0.0 : rad) * (double)w; col[6][t] = (double)(c3 * w);
+        col[7][t] = (double)(c4 * w); col[8][t] = (double)(c5 * w);
     }
     __syncthreads();
     if (t < 9) { double a = 0.0; for (int k = 0; k < m_sel; ++k) a += col[t][k]; sums[t] = a; }   // in candidate order, like the reference's loop
@@ -256,12 +258,12 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
         const double mean_tsdf = sums[1] / sw;
         mt[0] = (float)(sums[2] / sw * (double)ss[0]); mt[1] = (float)(sums[3] / sw * (double)ss[1]); mt[2] = (float)(sums[4] / sw * (double)ss[2]);
         const double q0 = sums[5] / sw, q1 = sums[6] / sw * (double)ss[3], q2 = sums[7] / sw * (double)ss[4], q3 = sums[8] / sw * (double)ss[5];
-        const double len = sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
-        mt[3] = (float)(q0 / len); mt[4] = (float)(q1 / len); mt[5] = (float)(q2 / len); mt[6] = (float)(q3 / len);
+        const double lens = 1.0 / sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+        mt[3] = (float)(q0 * lens); mt[4] = (float)(q1 * lens); mt[5] = (float)(q2 * lens); mt[6] = (float)(q3 * lens);
         tsdf_scale = S.scale_d * mean_tsdf;
         st[ST_MIN_TSDF] = (float)mean_tsdf;
     } else {
-        tsdf_scale = (double)(S.scale_f * origin);    // python float * np.float32 -> float32
+        tsdf_scale = S.scale_d * (double)origin;
         st[ST_MIN_TSDF] = origin;
     }
     int count_particle = cp;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
     }
     const bool previous_success = si[ST_PREVIOUS_SUCCESS] != 0;
     if (previous_success && success) {
-        for (int k = 0; k < 6; ++k) st[ST_SS + k] = S.beta * st[ST_SS + k] + S.one_minus_beta * st[ST_PSS + k];
+        for (int k = 0; k < 6; ++k) st[ST_SS + k] = (float)(S.beta_d * (double)st[ST_SS + k] + (1.0 - S.beta_d) * (double)st[ST_PSS + k]);
     } else if (success) {
         if (S.iterative_scale) si[ST_PREVIOUS_SUCCESS] = 1;
         for (int k = 0; k < 6; ++k) st[ST_PSS + k] = st[ST_SS + k];
@@ -389,8 +391,7 @@ static int search_kernel_args(const rfx_track_search* s, SearchK* S, int* eval_b
     S->H = s->H; S->W = s->W; S->voxel = s->voxel;
     S->count_search = s->count_search; S->fix_level_index = s->fix_level_index; S->iterative_scale = s->iterative_scale;
     S->max_rows = max_rows;
-    S->scale_d = s->scaling_coefficient; S->scale_f = (float)s->scaling_coefficient;
-    S->beta = (float)s->beta; S->one_minus_beta = (float)(1.0 - s->beta);
+    S->scale_d = s->scaling_coefficient; S->beta_d = s->beta;
     S->state = s->state; S->value = s->value; S->count = s->count;
     *eval_blocks = blocks;
     return RFX_OK;

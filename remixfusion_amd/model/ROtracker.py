@@ -19,6 +19,7 @@ Differences, on purpose:
 """
 from __future__ import annotations
 
+import math
 import random
 from typing import Dict, Tuple
 
@@ -226,36 +227,49 @@ class ROTracker(object):
 
     # ------------------------------------------------------------------ host logic
     def update_PST(self, tsdf, mean_transform, min_scale=1e-3, scale=0.09):
-        """anisotropic search-size update (reference :493-534)."""
-        s = np.abs(np.array([mean_transform[0], mean_transform[1], mean_transform[2], mean_transform[4], mean_transform[5],
-                             mean_transform[6]], dtype=np.float64)) + min_scale
-        s = s / np.sqrt((s ** 2).sum())
-        self.search_size[0:3] = scale * tsdf * s[0:3] + min_scale
-        self.search_size[3:6] = scale * tsdf * s[3:6] + min_scale
+        """anisotropic search-size update (reference :493-534): float64 throughout (numpy 1.21 promotes the reference's
+        float32-scalar (op) Python-float expressions to float64), stored as float32."""
+        s = [abs(float(mean_transform[k])) + min_scale for k in (0, 1, 2, 4, 5, 6)]
+        norm = math.sqrt(s[0] ** 2 + s[1] ** 2 + s[2] ** 2 + s[3] ** 2 + s[4] ** 2 + s[5] ** 2)
+        t = float(tsdf)
+        for k in range(6):
+            self.search_size[k] = scale * t * (s[k] / norm) + min_scale
 
     def cal_transform(self, search_value):
         """fitness-weighted mean of the first ``count_search`` candidates that beat the null candidate
-        (reference :606-709).  Returns (success, min_tsdf, [tx,ty,tz,qw,qx,qy,qz])."""
+        (reference :606-709).  Returns (success, min_tsdf, [tx,ty,tz,qw,qx,qy,qz]).  The reference's scalar loop, vectorised:
+        float32 weights and products, float64 running sums in candidate order, as the reference's numpy (1.21.6) computes them
+        (oracle/tracker_host_oracle.py spells the types out; tests/test_oracle_tracker_host.py compares bit for bit)."""
         mean_transform = np.zeros((7), dtype=np.float32)
-        origin_tsdf = search_value[0]
-        better = np.flatnonzero(search_value[1:] < origin_tsdf) + 1
+        sv = np.asarray(search_value, np.float32)
+        origin_tsdf = sv[0]
+        better = np.flatnonzero(sv[1:] < origin_tsdf) + 1
         if better.size == 0:
             return False, origin_tsdf, mean_transform
         sel = better[:self.count_search]
-        cand = self.transform_candidate[sel].astype(np.float64)
-        fit = search_value[sel].astype(np.float64)
-        w = float(origin_tsdf) - fit
-        ss = self.search_size.astype(np.float64)
-        q = cand[:, 3:6] * ss[3:6]
-        rad = 1.0 - (q ** 2).sum(1)
+        cand = np.asarray(self.transform_candidate, np.float32)[sel]
+        fit = sv[sel]
+        w = origin_tsdf - fit                                            # float32
+        ss = np.asarray(self.search_size, np.float32)
+        q = cand[:, 3:6] * ss[3:6]                                       # float32
+        q2 = (q * q).astype(np.float64)
+        rad = ((1.0 - q2[:, 0]) - q2[:, 1]) - q2[:, 2]
         if (rad < 0).any():
             raise ValueError("invalid quaternion in the particle template (reference exits here, :662-669)")
-        qw = np.sqrt(rad)
-        sw = w.sum()
-        mean_tsdf = (fit * w).sum() / sw
-        mean_transform[0:3] = (cand[:, 0:3] * w[:, None]).sum(0) / sw * ss[0:3]
-        qm = np.concatenate([[(qw * w).sum() / sw], (cand[:, 3:6] * w[:, None]).sum(0) / sw * ss[3:6]])
-        mean_transform[3:7] = qm / np.sqrt((qm ** 2).sum())
+        cols = np.empty((sel.size, 9), np.float64)
+        cols[:, 0:6] = cand * w[:, None]                                 # float32 products
+        cols[:, 6] = np.sqrt(rad) * w.astype(np.float64)
+        cols[:, 7] = w
+        cols[:, 8] = fit * w                                             # float32 product
+        sums = np.cumsum(cols, axis=0)[-1]                               # sequential, like the loop's `+=`
+        sw = float(sums[7])
+        mean_tsdf = float(sums[8]) / sw
+        for k in range(3):
+            mean_transform[k] = (float(sums[k]) / sw) * float(ss[k])
+        qww = float(sums[6]) / sw
+        qxx, qyy, qzz = ((float(sums[3 + k]) / sw) * float(ss[3 + k]) for k in range(3))
+        lens = 1 / math.sqrt(qww * qww + qxx * qxx + qyy * qyy + qzz * qzz)
+        mean_transform[3:7] = (qww * lens, qxx * lens, qyy * lens, qzz * lens)
         return True, mean_tsdf, mean_transform
 
     def _search_step(self, i, st, search_value, beta):
@@ -280,7 +294,8 @@ class ROTracker(object):
         st["min_tsdf"] = min_tsdf
         self.update_PST(min_tsdf, mean_transform, scale=self.scaling_coefficient)
         if st["previous_success"] and success:
-            self.search_size[:] = beta * self.search_size + (1 - beta) * self.previous_search_size
+            for k in range(6):                                       # float64 (Python float * float32 scalar), stored as float32
+                self.search_size[k] = beta * float(self.search_size[k]) + (1 - beta) * float(self.previous_search_size[k])
         elif success:
             if self.iterative_scale:
                 st["previous_success"] = True
