@@ -520,9 +520,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    # RFX_FORCE_SHARDED=1 (with RFX_DIST_FORCE_COLLECTIVES=1): the N > 1 code path with ONE rank -- a one-rank RCCL communicator
+    # executes every collective of the one-scene run on a 1-GPU box (a rehearsal of the calls, not a measurement of anything)
+    force_sharded = world == 1 and os.environ.get("RFX_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
         backend = os.environ.get("RFX_DIST_BACKEND", "nccl")     # nccl == RCCL on ROCm; gloo only for rehearsals
         if backend == "nccl":
             dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
@@ -530,7 +534,7 @@ def main():
             dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
-    if world > 1:
+    if world > 1 or force_sharded:
         return main_sharded(args, dist, rank, world, device)
 
     from remixfusion_amd import _lib

@@ -19,6 +19,7 @@ That is 2 x (R*R*(4+1) floats) = 1.6 MB per neighbour per keyframe -- far below 
 from __future__ import annotations
 
 import copy
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -102,8 +103,9 @@ def exchange_planes(dist, rank: int, left: Optional[int], right: Optional[int], 
         recv_l = torch.empty_like(send_l)
         ops += [dist.P2POp(dist.isend, send_l, left), dist.P2POp(dist.irecv, recv_l, left)]
         recvs.append((recv_l, 0))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     for buf, ix in recvs:
         unpack(buf.to(gbv.device) if host_staged else buf, ix)
 
@@ -133,13 +135,24 @@ def slab_bounds(dx: int, world: int) -> List[int]:
     return [(dx * r) // world for r in range(world + 1)]
 
 
+# RFX_DIST_FORCE_COLLECTIVES=1: issue every collective even in a world of one rank.  A 1-GPU box cannot hold two RCCL ranks
+# (one communicator rank per device), but a one-rank RCCL communicator executes the same calls on the same device tensors
+# (views, split sizes, dtypes, stream ordering): tests/test_rccl_one_rank_gpu.py and `RFX_FORCE_SHARDED=1 bench.py` use it.
+_FORCE_COLLECTIVES = os.environ.get("RFX_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def _alone(dist) -> bool:
+    """no collective needed: no process group, or a world of one (unless forced, above)"""
+    return dist is None or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES)
+
+
 def _host_staged(dist, t: torch.Tensor) -> bool:
     return dist is not None and t.is_cuda and dist.get_backend() == "gloo"
 
 
 def broadcast_(dist, t: torch.Tensor, src: int = 0) -> torch.Tensor:
     """in-place broadcast of a device tensor (gloo: via the host)."""
-    if dist is None or dist.get_world_size() == 1:
+    if _alone(dist):
         return t
     if _host_staged(dist, t):
         h = t.cpu()
@@ -167,7 +180,7 @@ def all_reduce_sum_(dist, tensors) -> None:
     """in-place sum over ranks of a list of tensors.  The big ones (the hash gradient: 6.6 ... 166 MB) are all-reduced where
     they lie -- no concatenation, no copy back; only the small ones (decoder weight gradients, loss sums, pose gradients)
     share one flattened bucket per dtype, so that they cost one collective instead of one each."""
-    if dist is None or dist.get_world_size() == 1:
+    if _alone(dist):
         return
     small = {}
     for t in tensors:
@@ -193,7 +206,7 @@ def all_reduce_sum_(dist, tensors) -> None:
 def all_to_all_rows_(dist, out: torch.Tensor, out_splits: List[int], inp: torch.Tensor, in_splits: List[int]) -> None:
     """all-to-all of flat fp32 buffers with per-rank element counts: inp is cut into in_splits (piece q goes to rank q), out
     receives the pieces of ranks 0..world-1 in turn (out_splits).  nccl (RCCL): on the device; gloo: through the host."""
-    if dist is None or dist.get_world_size() == 1:
+    if _alone(dist):
         out[:sum(out_splits)].copy_(inp[:sum(in_splits)])
         return
     o, i = out[:sum(out_splits)], inp[:sum(in_splits)]
@@ -381,7 +394,7 @@ class sharded_volume(moving_volume):
         """plane x1 of tsdf and colour from the right neighbour (None on the last rank); every rank sends its first plane left"""
         plane = int(self.vol_dim[1]) * int(self.vol_dim[2])
         halo = None
-        if self.dist is None or self.world == 1:
+        if self.dist is None or self.world == 1:             # no neighbour
             return halo
         ops = []
         host = _host_staged(self.dist, self.tsdf_vol_gpu)
@@ -443,7 +456,7 @@ class sharded_volume(moving_volume):
                                                      farr(_F3, self.vol_origin), self.voxel_size, float(self.trunc_margin), int(pc_num),
                                                      float(trunc_tsdf), ptr(pc), cnt.data_ptr(), hit.data_ptr(), self.index_decode,
                                                      stream_ptr(self.device)), "rfx_tsdf_truncated_pc_slab")
-        if self.dist is not None and self.world > 1:
+        if not _alone(self.dist):
             owner = hit.to(torch.float32) * float(self.rank + 1)
             if _host_staged(self.dist, owner):
                 h = owner.cpu()
@@ -563,18 +576,19 @@ class sharded_volume(moving_volume):
     def gather_whole(self):
         """the whole volume as three host arrays on every rank (tests / meshing): all_gather of the slabs"""
         parts = self.get_volume_all()
-        if self.dist is None or self.world == 1:
+        if _alone(self.dist):
             return parts
         out = []
         cuts = self._cuts()
         plane = int(self.vol_dim[1]) * int(self.vol_dim[2])
         width = max(cuts[r + 1] - cuts[r] for r in range(self.world)) * plane
+        where = self.device if self.dist.get_backend() == "nccl" else "cpu"      # RCCL moves device tensors only, gloo host ones
         for p in parts:
-            mine = torch.zeros(width, dtype=torch.float32)
-            mine[:p.size] = torch.from_numpy(p)
-            bufs = [torch.empty(width, dtype=torch.float32) for _ in range(self.world)]
+            mine = torch.zeros(width, dtype=torch.float32, device=where)
+            mine[:p.size] = torch.from_numpy(p).to(where)
+            bufs = [torch.empty(width, dtype=torch.float32, device=where) for _ in range(self.world)]
             self.dist.all_gather(bufs, mine)
-            out.append(np.concatenate([bufs[r][:(cuts[r + 1] - cuts[r]) * plane].numpy() for r in range(self.world)]))
+            out.append(np.concatenate([bufs[r][:(cuts[r + 1] - cuts[r]) * plane].cpu().numpy() for r in range(self.world)]))
         return tuple(out)
 
 
