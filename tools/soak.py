@@ -7,6 +7,8 @@ from remixfusion_amd.pipeline import MappingPipeline
 name = sys.argv[1] if len(sys.argv) > 1 else "office0"
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 501
 cfg = synthetic_config(name)
+if len(sys.argv) > 3 and sys.argv[3] == "tracker":           # config 3: the tracker (device-side search) drives the poses
+    cfg["synthetic"].update({"tracker": True, "clutter": 48})
 pipe = MappingPipeline(cfg, n_frames=nf + 10)
 frames = pipe.prefetch(list(range(nf)))
 pipe.start(frames[0])

@@ -9,6 +9,8 @@ random.seed(0)
 cfg = synthetic_config("scene0000"); cfg["synthetic"]["tracker"] = True
 cfg["synthetic"].update({"depth_noise": float(os.environ.get("NOISE", 0.0)), "dropout": 0.0, "clutter": int(os.environ.get("CLUTTER", 0))})
 cfg["mapping"]["first_iters"] = 50
+cfg["RO"]["device_search"] = os.environ.get("DEVICE_SEARCH", "1") == "1"
+if os.environ.get("NO_POSE_OPT"): cfg["synthetic"]["pose_opt"] = False
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     pipe = MappingPipeline(cfg, n_frames=N + 8)
@@ -32,4 +34,6 @@ err, along, rot = np.array(err), np.array(along), np.array(rot)
 step = np.array([float((frames[i]["c2w"][:3, 3] - frames[i - 1]["c2w"][:3, 3]).norm()) for i in range(1, N)])
 print(f"path length {step.sum():.2f} m; ATE rmse {np.sqrt((err ** 2).mean()) * 100:.2f} cm, max {err.max() * 100:.2f} cm, final {err[-1] * 100:.2f} cm; "
       f"along view axis rmse {np.sqrt((along ** 2).mean()) * 100:.2f} cm; rotation rmse {np.sqrt((rot ** 2).mean()):.3f} deg max {rot.max():.3f}")
-print("every 10th frame (cm):", [round(e * 100, 1) for e in err[9::10]])
+print("every 10th frame (cm):", [round(float(e) * 100, 1) for e in err[9::10]])
+mv = pipe.tracker.RO_Tracker.MV
+print("volume moves:", getattr(mv, "move_count", "?"), "origin", mv.vol_origin, "dim", mv.vol_dim)
