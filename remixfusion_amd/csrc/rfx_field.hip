@@ -479,37 +479,6 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
             // cheap enough that merging runs in registers no longer pays): nearly every corner falls into another
             // segment, so test segment membership first and add only the corners that land here
             // (measured: 1.25-1.6x faster at 128 segments, neutral at 32, slower at 4)
-#if defined(SCATTER_HITLOOP) && SCATTER_HITLOOP
-            // Every corner's atomic pair is issued by the whole wave if ANY lane's corner lands here -- with 8 segments that is
-            // nearly always, at 1/8 of the lanes: 16 LDS instructions per visit.  Instead each lane walks only ITS hits (a bit
-            // mask of the 8 corners): the wave iterates max-over-lanes of the hit count (~5: the two x-neighbours of a corner
-            // pair share a segment) and every atomic carries several times the lanes.
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const float2 gv = gvb[j];
-                if (gv.x == 0.f && gv.y == 0.f) continue;
-                const Cell c = locate(lv, xb[j]);
-                const unsigned m = lv.size - 1u;
-                const unsigned x0 = c.g[0], y0 = c.g[1] * 2654435761u, z0 = c.g[2] * 805459861u;
-                unsigned hits = 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned idx = ((x0 + (unsigned)(k & 1)) ^ (y0 + ((k & 2) ? 2654435761u : 0u)) ^ (z0 + ((k & 4) ? 805459861u : 0u))) & m;
-                    hits |= (idx - base < cnt ? 1u : 0u) << k;
-                }
-                const float g0 = 1.0f - c.f[0], g1 = 1.0f - c.f[1], g2 = 1.0f - c.f[2];
-                while (hits) {
-                    const unsigned k = (unsigned)__builtin_ctz(hits);
-                    hits &= hits - 1u;
-                    const unsigned idx = ((x0 + (k & 1u)) ^ (y0 + ((k & 2u) ? 2654435761u : 0u)) ^ (z0 + ((k & 4u) ? 805459861u : 0u))) & m;
-                    const float w = (((k & 1u) ? c.f[0] : g0) * ((k & 2u) ? c.f[1] : g1)) * ((k & 4u) ? c.f[2] : g2);   // corner_weight's order
-                    const unsigned r = idx - base;
-                    atomicAdd(&acc[2 * r], (ACC)(w * gv.x));
-                    atomicAdd(&acc[2 * r + 1], (ACC)(w * gv.y));
-                }
-            }
-            continue;
-#endif
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const float2 gv = gvb[j];
