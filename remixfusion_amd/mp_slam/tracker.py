@@ -30,17 +30,21 @@ class Tracker:
         self.device = device
         self.RO_Tracker = ROTracker(config, dataset, device=device, volume_factory=volume_factory)
         self.all_poses = []
+        self._ro_host = {}              # frame id -> the tracker's own result as it left the search (numpy, host): what the
+                                        # constant-velocity prediction reads, without a device->host copy (and its wait) per frame
 
     def predict_current_pose(self, frame_id, constant_speed=True):
         """reference :55-72."""
         if frame_id == 1 or (not constant_speed):
             self.est_c2w_data[frame_id] = self.est_c2w_data[frame_id - 1]
         else:
-            pp = self.RO_c2w_data[frame_id - 2].cpu().numpy().astype(np.float64)
-            p = self.RO_c2w_data[frame_id - 1].cpu().numpy().astype(np.float64)
+            pp, p = (self._ro_host[f].astype(np.float64) if f in self._ro_host else self.RO_c2w_data[f].cpu().numpy().astype(np.float64)
+                     for f in (frame_id - 2, frame_id - 1))
             pred = (p @ np.linalg.inv(pp)) @ p
             pred[:3, :3] = orthogonalize_rotation(pred[:3, :3])
-            self.est_c2w_data[frame_id] = torch.from_numpy(pred.astype(np.float32)).to(self.device)
+            self._pred_host = pred.astype(np.float32)
+            self.est_c2w_data[frame_id] = torch.from_numpy(self._pred_host).to(self.device)
+            return self._pred_host                    # (the search starts from a host array: no read-back of what was just sent)
         return self.est_c2w_data[frame_id]
 
     def tracking(self, batch, frame_id):
@@ -51,7 +55,9 @@ class Tracker:
         cur = torch.from_numpy(RO_pose_np).float().to(self.device)
         self.est_c2w_data[frame_id] = cur
         self.RO_c2w_data[frame_id] = cur
-        self.all_poses.append(cur.cpu())
+        self._ro_host[frame_id] = np.asarray(RO_pose_np, np.float32)
+        self._ro_host.pop(frame_id - 3, None)
+        self.all_poses.append(torch.from_numpy(RO_pose_np).float())
         ke = self.config["mapping"]["keyframe_every"]
         if frame_id % ke != 0:
             key = self.RO_c2w_data[(frame_id // ke) * ke]
