@@ -238,8 +238,15 @@ def extract_mesh(query_fn: Callable, query_w_fn: Callable, config: Dict, boundin
             flat = (flat - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])
         if len(_LATTICE_CACHE) >= 4:
             _LATTICE_CACHE.clear()
-        hit = _LATTICE_CACHE[key] = (tx, ty, tz, tuple(pts.shape), flat.contiguous())
-    tx, ty, tz, sh, flat = hit
+        flat = flat.contiguous()
+        ready = None
+        if flat.is_cuda:                       # exports run on several streams (AsyncMeshExporter): readers wait for the producer once
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(flat.device))
+        hit = _LATTICE_CACHE[key] = (tx, ty, tz, tuple(pts.shape), flat, ready)
+    tx, ty, tz, sh, flat, ready = hit
+    if ready is not None:
+        torch.cuda.current_stream(flat.device).wait_event(ready)
     sdf = query_fn(flat[:, None, :]).reshape(sh[:-1]).to(torch.float32)
     weight = query_w_fn(flat[:, None, :]).reshape(sh[:-1])
     verts, faces = marching_cubes(sdf, isolevel, mask=weight > 0)
@@ -354,50 +361,79 @@ class FieldSnapshot:
 
 
 class AsyncMeshExporter:
-    """at most ONE export in flight: ``submit`` first waits for the previous one (its snapshot buffers are re-used), copies the
-    field on the caller's stream, and hands the sweep + marching cubes + PLY write to a worker thread that runs them on a
-    side stream behind an event; ``result()`` joins and returns the last finished mesh (or re-raises the worker's exception)."""
+    """``submit`` copies the field on the caller's stream into a snapshot slot and hands the sweep + marching cubes + PLY write
+    to a worker thread that runs them on the slot's side stream behind an event; a slot is re-used only after its export has
+    finished (``submit`` waits for it).  An export can only start once the GPU has reached its snapshot, i.e. after the whole
+    keyframe's iterations queued before it, so with ONE slot the next ``submit`` usually finds the previous export still waiting
+    for the GPU and blocks: that is back-pressure, not a loss -- at config 5's sizes the GPU is busy throughout (15 iterations
+    = 20 ms per keyframe), and two slots (DEPTH = 2, measured) give the same 221 frames/s while holding a second 320 MB copy.
+    ``result()`` joins everything and returns the mesh of the LATEST submit (or re-raises a worker's exception).  An exporter
+    still working when the interpreter exits is drained first (a worker inside a HIP call at exit aborts the process)."""
+
+    DEPTH = 1
 
     def __init__(self, model, config, bounding_box, marching_cube_bound):
         import threading
         self._threading = threading
         self.model, self.config, self.bb, self.mcb = model, config, bounding_box, marching_cube_bound
-        self.snapshot = None
-        self.stream = torch.cuda.Stream(device=bounding_box.device)
-        self._thread, self._mesh, self._error = None, None, None
+        self._slots = [{"snapshot": None, "stream": torch.cuda.Stream(device=bounding_box.device), "thread": None}
+                       for _ in range(self.DEPTH)]
+        self._seq, self._mesh, self._mesh_seq, self._error = 0, None, -1, None
+        self._lock = threading.Lock()
+        import atexit
+        import weakref
+        me = weakref.ref(self)
 
-    def _work(self, path, voxel_size, ev):
+        def _drain():                       # an interpreter that exits under a running export aborts (worker inside a HIP call)
+            obj = me()
+            if obj is not None:
+                try:
+                    obj.wait()
+                except BaseException:       # noqa: BLE001 -- nothing can be done with it at exit
+                    pass
+        atexit.register(_drain)
+
+    def _work(self, slot, seq, path, voxel_size, ev):
         try:
-            with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
-                s = self.snapshot
+            with torch.cuda.stream(slot["stream"]):
+                slot["stream"].wait_event(ev)
+                s = slot["snapshot"]
                 mesh = extract_mesh(s.query_sdf_res, s.query_w_res, self.config, self.bb, color_func=s.query_color_residual,
                                     marching_cube_bound=self.mcb, voxel_size=voxel_size)
                 import os
                 os.makedirs(os.path.dirname(path), exist_ok=True)
                 write_ply(path, mesh)
-                self.stream.synchronize()
-            self._mesh = mesh
+                slot["stream"].synchronize()
+            with self._lock:
+                if seq > self._mesh_seq:
+                    self._mesh, self._mesh_seq = mesh, seq
         except BaseException as e:          # noqa: BLE001 -- handed to the thread that asks for the result
-            self._error = e
+            with self._lock:
+                self._error = e
 
-    def submit(self, path, voxel_size):
-        self.wait()
-        if self.snapshot is None:
-            self.snapshot = FieldSnapshot(self.model)
-        self.snapshot.capture()
-        ev = torch.cuda.Event()
-        ev.record()
-        self._thread = self._threading.Thread(target=self._work, args=(path, voxel_size, ev), daemon=True)
-        self._thread.start()
-
-    def wait(self):
-        if self._thread is not None:
-            self._thread.join()
-            self._thread = None
+    def _join(self, slot):
+        if slot["thread"] is not None:
+            slot["thread"].join()
+            slot["thread"] = None
         if self._error is not None:
             e, self._error = self._error, None
             raise e
+
+    def submit(self, path, voxel_size):
+        slot = self._slots[self._seq % self.DEPTH]
+        self._join(slot)                                # the export that used this slot's buffers, two submits ago
+        if slot["snapshot"] is None:
+            slot["snapshot"] = FieldSnapshot(self.model)
+        slot["snapshot"].capture()
+        ev = torch.cuda.Event()
+        ev.record()
+        slot["thread"] = self._threading.Thread(target=self._work, args=(slot, self._seq, path, voxel_size, ev), daemon=True)
+        slot["thread"].start()
+        self._seq += 1
+
+    def wait(self):
+        for k in range(self.DEPTH):                     # oldest first
+            self._join(self._slots[(self._seq + k) % self.DEPTH])
 
     def result(self):
         self.wait()
