@@ -235,3 +235,38 @@ def test_device_search_finds_the_pose_the_host_loop_finds():
         assert e1 < 0.5 * e0 and r1 < 0.012, (dev, e0, e1, r1)
     assert np.abs(est[True][:3, 3] - est[False][:3, 3]).max() < 2e-3
     assert np.abs(est[True][:3, :3] - est[False][:3, :3]).max() < 2e-3
+
+
+def test_device_search_reports_an_invalid_template_and_refuses_bad_descriptors():
+    """a selected candidate whose scaled quaternion vector part is longer than 1: the reference prints and exits
+    (model/ROtracker.py:662-669); the host loop raises, the device search raises after its one read of the state (flag 37).
+    Descriptors the kernels are not built for are refused before any launch."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    for dev in (True, False):
+        tr, b, gt, init = _tracker_with_a_map(dev)
+        for cls, t in tr.ALL_PST_dev.items():                   # vector parts of +-60: |q| > 1 at any search size >= 0.02
+            t[..., 3:6] = torch.where(t[..., 3:6] >= 0, 60.0, -60.0)
+            t[:, 0, :] = 0
+            tr.ALL_PST[cls] = t.cpu().numpy()
+        with pytest.raises(ValueError, match="invalid quaternion"):
+            tr.do_tracking(init, None, b, "cuda")
+    tr, b, gt, init = _tracker_with_a_map(True)
+    tr.init_depth_vertex(b["depth"].squeeze(), tr.K)
+    tr.init_normal()
+    st = L.stream_ptr(tr.device)
+    args = (L.farr(L._F9, np.eye(3).reshape(-1)), L.farr(L._F3, np.zeros(3)), L.farr(L._F6, np.full(6, 0.02)))
+    s = tr._search_desc(tr.K)
+    assert lib.rfx_track_search_run(C.byref(s), *args, 1, st) == 0
+    for field, value in (("count_search", 0), ("count_search", L.RFX_TRACK_MAX_COUNT_SEARCH + 1), ("x1", 10 ** 6), ("voxel", 0.0), ("state", None)):
+        s = tr._search_desc(tr.K)
+        setattr(s, field, value)
+        assert lib.rfx_track_search_run(C.byref(s), *args, 1, st) == -1, field          # RFX_ERR_ARG
+    s = tr._search_desc(tr.K)
+    s.template_rows[3] = 16 * 1024 + 1
+    assert lib.rfx_track_search_evaluate(C.byref(s), st) == -1
+    s = tr._search_desc(tr.K)
+    s.n_eval[0] = s.template_rows[0] + 1
+    assert lib.rfx_track_search_update(C.byref(s), 0, st) == -1
+    torch.cuda.synchronize()
