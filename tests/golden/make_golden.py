@@ -16,6 +16,9 @@ imports; no reference source is copied.  What gets pinned:
   host.npz       datasets/utils.get_camera_rays, model/utils.batchify, config.load_config,
                  KeyFrameDatabase.sample_global_rays under random.seed                      (callers)
   volume_bounds.npz  moving_volume bound logic + a scripted check_move_volume_new walk      (V-bnd)
+  tracker_host.npz   model/ROtracker.py cal_transform, update_PST and whole random_optimization loops (host logic of the pose
+                 search) on injected fitness arrays: PyCUDA / cv2 stubbed, the CUDA evaluation replaced by the injected arrays.
+                 Arithmetic is this container's numpy (recorded in the file): oracle/tracker_host_oracle.py mode="numpy2"  (f1)
 """
 import os
 import random
@@ -318,9 +321,109 @@ def make_pst_fixture():
          sqs=np.array(sqs), sha256=np.array(shas))
 
 
+def make_tracker_host():
+    """the reference's OWN host logic of the pose search (model/ROtracker.py:606-709 cal_transform, :493-534 update_PST, :713-831
+    random_optimization) on synthetic fitness values.  The tracker object is made without its __init__ (which allocates through
+    PyCUDA and reads the TIFF templates); `evaluate_tsdf` -- the CUDA launch -- hands out the injected arrays instead, the two
+    image-preparation launches are no-ops.  Nothing of the logic under test is replaced."""
+    import model.Volume  # noqa: F401  (imported while pycuda.driver is absent: its CUDA_GPU_MODE stays 0)
+    _stub("pycuda.driver", PointerHolderBase=object)
+    _stub("pycuda.compiler", SourceModule=_Any)
+    # /root/reference/datasets has no __init__.py and an installed package of the same name would win: point the name at the directory
+    ns = types.ModuleType("datasets")
+    ns.__path__ = [os.path.join(REF, "datasets")]
+    sys.modules["datasets"] = ns
+    from model.ROtracker import ROTracker
+    rng = np.random.default_rng(20251205)
+    depth_level = [32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16]
+    tiff_index = [0, 1 + 20, 2 + 40, 3, 4 + 20, 5 + 40, 6 + 0, 7 + 20, 8 + 40, 9 + 0, 10 + 20, 11 + 40, 12 + 0, 13 + 20, 14 + 40,
+                  15 + 0, 16 + 20, 17 + 40, 18 + 0, 19 + 20]
+    sizes = (640, 384, 256)                                   # candidates per template class (the logic does not depend on them)
+    templates = {c: rng.uniform(-1, 1, (7, sizes[c], 6)).astype(np.float32) for c in range(3)}
+    for c in templates:
+        templates[c][:, 0, :] = 0
+
+    def tracker(count_search, fix_level_index, iterative_scale, scaling):
+        tr = ROTracker.__new__(ROTracker)
+        tr.count_search, tr.fix_level_index, tr.iterative_scale, tr.scaling_coefficient = count_search, fix_level_index, iterative_scale, scaling
+        tr.init_size, tr.particle_iter_lens, tr.PST_size = 0.02, 20, list(sizes)
+        tr.depth_level, tr.tiff_index, tr.ALL_PST = depth_level, tiff_index, templates
+        tr.initialize_search_size, tr.previous_frame_success = np.zeros(6), False
+        tr.init_depth_vertex = lambda *a, **k: None
+        tr.init_normal = lambda *a, **k: None
+        return tr
+
+    out = {"numpy_version": np.array(np.__version__), "sizes": np.array(sizes), "depth_level": np.array(depth_level),
+           "tiff_index": np.array(tiff_index)}
+    for c in templates:
+        out[f"template_{c}"] = templates[c]
+    # ---- cal_transform / update_PST alone
+    n_cases = 10
+    for k in range(n_cases):
+        count_search = (200, 200, 5, 64)[k % 4]
+        tr = tracker(count_search, 0, True, 0.09)
+        cls, slot = k % 3, k % 7
+        tr.transform_candidate = templates[cls][slot]
+        tr.search_size = rng.uniform(0.002, 0.03, 6).astype(np.float32)
+        n = sizes[cls]
+        sv = rng.uniform(0.2, 0.6, n).astype(np.float32)
+        sv[0] = (0.1, 0.21, 0.4, 0.7)[k % 4]                 # none / a handful / about half / all better
+        if k == 7:
+            sv[3], sv[9] = sv[0], 0.0                         # a tie does not count; an unevaluated candidate (0) does
+        ss_in = tr.search_size.copy()
+        ok, min_tsdf, mt = tr.cal_transform(sv)
+        out[f"ct{k}_search_value"], out[f"ct{k}_search_size"], out[f"ct{k}_template"] = sv, ss_in, np.array([cls, slot, count_search])
+        out[f"ct{k}_success"], out[f"ct{k}_min_tsdf"], out[f"ct{k}_mean_transform"] = np.array(bool(ok)), np.asarray(min_tsdf), np.asarray(mt)
+        out[f"ct{k}_min_tsdf_is_f64"] = np.array(np.asarray(min_tsdf).dtype == np.float64)
+        tr.update_PST(min_tsdf, mt, scale=0.09 if k % 2 else 0.12)
+        out[f"ct{k}_search_size_after"] = tr.search_size.copy()
+    out["n_cal_transform"] = np.array(n_cases)
+    # ---- whole loops: 20 iterations each
+    n_loops = 6
+    for k in range(n_loops):
+        count_search = (200, 7, 200)[k % 3]
+        tr = tracker(count_search, k % 2, k != 3, (0.09, 0.12)[k % 2])
+        R0 = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3], pose[:3, 3] = R0, rng.normal(size=3).astype(np.float32)
+        fed, log = [], []
+
+        def evaluate(cur_id, level, node_size, cam_intr, level_index, tr=tr, fed=fed, log=log, k=k):
+            n = tr.transform_candidate.shape[0]
+            assert n == node_size
+            sv = rng.uniform(0.2, 0.6, n).astype(np.float32)
+            mode = rng.integers(0, 4) if k else 1
+            if mode == 0:
+                sv[0] = 0.1
+            elif mode == 1:
+                sv[0] = 0.22
+            if mode == 3:
+                sv[rng.integers(1, n, 3)] = 0.0
+            fed.append(sv.copy())
+            log.append((level, level_index))
+            return sv, sv, sv
+        tr.evaluate_tsdf = evaluate
+        est = tr.random_optimization(0, pose, None, None, None)
+        width = max(sizes)
+        fedm = np.zeros((20, width), np.float32)
+        for i, sv in enumerate(fed):
+            fedm[i, :sv.shape[0]] = sv
+        out[f"loop{k}_pose_in"], out[f"loop{k}_pose_out"] = pose, np.asarray(est)
+        out[f"loop{k}_fed"], out[f"loop{k}_fed_n"], out[f"loop{k}_levels"] = fedm, np.array([sv.shape[0] for sv in fed]), np.array(log)
+        out[f"loop{k}_config"] = np.array([count_search, k % 2, int(k != 3)])
+        out[f"loop{k}_scaling"] = np.array((0.09, 0.12)[k % 2])
+        out[f"loop{k}_search_size"], out[f"loop{k}_previous_search_size"] = tr.search_size.copy(), tr.previous_search_size.copy()
+        out[f"loop{k}_previous_frame_success"] = np.array(bool(tr.previous_frame_success))
+    out["n_loops"] = np.array(n_loops)
+    save("tracker_host.npz", **out)
+
+
 if __name__ == "__main__":
     if "--pst-only" in sys.argv:
         make_pst_fixture()
+        sys.exit(0)
+    if "--tracker-host-only" in sys.argv:
+        make_tracker_host()
         sys.exit(0)
     make_pst_fixture()
     make_decoder()
@@ -329,3 +432,4 @@ if __name__ == "__main__":
     make_host()
     make_volume_bounds()
     make_mapping()
+    make_tracker_host()

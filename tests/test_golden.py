@@ -196,3 +196,55 @@ def test_moving_volume_bound_logic_matches_reference():
         assert np.array_equal(old, g["walk_old"][i]) and np.array_equal(mv.vol_bnds, g["walk_new"][i])
         assert np.array_equal([tr.kfx, tr.kfy, tr.kfz], g["walk_anchor"][i])
     assert log.count("copy") == int(g["walk_n_copy"]) and log.count("swap") == int(g["walk_n_swap"])
+
+
+def test_tracker_host_logic_matches_reference():
+    """tests/golden/tracker_host.npz: the reference's own cal_transform / update_PST / random_optimization (model/ROtracker.py
+    :606-709, :493-534, :713-831) run in the authoring container on injected fitness arrays (numpy 2.x arithmetic: a Python scalar
+    does not promote a float32).  oracle/tracker_host_oracle.py in mode="numpy2" reproduces every output BIT FOR BIT (R of the
+    whole loops to one float32 ulp: np.matmul may fuse): candidate selection in index order with the count_search cut, ties,
+    unevaluated candidates, weights, the mean and its normalisation, failure returns, the box update, template / pixel-offset
+    schedule, smoothing and flags are the reference's.  (mode="numpy1", which the product follows, differs in the documented
+    casts only; tests/test_oracle_tracker_host.py.)"""
+    from oracle import tracker_host_oracle as O
+    g = np.load(os.path.join(G, "tracker_host.npz"))
+    assert str(g["numpy_version"]).startswith("2.")
+    templates = {c: g[f"template_{c}"] for c in range(3)}
+    depth_level, tiff_index = [int(v) for v in g["depth_level"]], [int(v) for v in g["tiff_index"]]
+    n_fail = n_ok = 0
+    for k in range(int(g["n_cal_transform"])):
+        cls, slot, count_search = (int(v) for v in g[f"ct{k}_template"])
+        sv, ss = g[f"ct{k}_search_value"], g[f"ct{k}_search_size"].copy()
+        ok, m, mt, bad = O.cal_transform(sv, templates[cls][slot], ss, count_search, mode="numpy2")
+        assert not bad and ok == bool(g[f"ct{k}_success"]), k
+        assert not bool(g[f"ct{k}_min_tsdf_is_f64"]) and np.float32(m) == np.float32(g[f"ct{k}_min_tsdf"]), k
+        assert np.array_equal(mt, g[f"ct{k}_mean_transform"]), (k, mt, g[f"ct{k}_mean_transform"])
+        O.update_PST(ss, m, mt, scale=0.09 if k % 2 else 0.12, mode="numpy2")
+        assert np.array_equal(ss, g[f"ct{k}_search_size_after"]), (k, ss, g[f"ct{k}_search_size_after"])
+        n_ok += ok
+        n_fail += not ok
+    assert n_ok >= 6 and n_fail >= 2
+    n_loop_fail = 0
+    for k in range(int(g["n_loops"])):
+        count_search, fix, it_scale = (int(v) for v in g[f"loop{k}_config"])
+        scaling = float(g[f"loop{k}_scaling"])
+        pose = g[f"loop{k}_pose_in"]
+        st = O.SearchState(pose[:3, :3], pose[:3, 3], np.full(6, 0.02, np.float32))
+        for i in range(20):
+            cp = st.template()
+            tiff = tiff_index[cp]
+            cand = templates[tiff // 20][(tiff % 20) // 3]
+            n = int(g[f"loop{k}_fed_n"][i])
+            assert cand.shape[0] == n, (k, i)
+            assert (depth_level[cp], st.level_index) == tuple(int(v) for v in g[f"loop{k}_levels"][i]), (k, i)   # what evaluate_tsdf was asked for
+            bad = O.search_step(st, i, g[f"loop{k}_fed"][i, :n], cand, depth_level, count_search, scaling, bool(fix), bool(it_scale), 0.9,
+                                mode="numpy2")
+            assert not bad
+            n_loop_fail += not st.success
+        out = g[f"loop{k}_pose_out"]
+        assert np.array_equal(st.T, out[:3, 3]), (k, st.T, out[:3, 3])
+        assert np.abs(st.R - out[:3, :3]).max() <= 2.4e-7, k                # 20 float32 3x3 products: BLAS may fuse
+        assert np.array_equal(st.search_size, g[f"loop{k}_search_size"]), (k, st.search_size, g[f"loop{k}_search_size"])
+        assert np.array_equal(st.previous_search_size, g[f"loop{k}_previous_search_size"]), k
+        assert st.first_success == bool(g[f"loop{k}_previous_frame_success"]), k
+    assert n_loop_fail >= 10
