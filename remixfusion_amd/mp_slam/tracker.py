@@ -11,12 +11,23 @@ import torch
 from ..model.ROtracker import ROTracker
 
 
-def orthogonalize_rotation(R: np.ndarray) -> np.ndarray:
-    """nearest rotation (SVD), as the reference's orthogonalize_rotation_matrix_tolerate does."""
-    U, _, Vt = np.linalg.svd(R.astype(np.float64))
-    if np.linalg.det(U @ Vt) < 0:
-        U[:, -1] *= -1
-    return (U @ Vt).astype(np.float32)
+def orthogonalize_rotation(R: np.ndarray, epsilon: float = 1e-10) -> np.ndarray:
+    """nearest orthogonal matrix by SVD, in the matrix's own precision, entries within epsilon of +-1 snapped: the reference's
+    ``orthogonalize_rotation_matrix_tolerate`` (model/utils.py:63-70)."""
+    U, _, V = np.linalg.svd(R)
+    out = np.dot(U, V)
+    out[np.abs(out - 1) < epsilon] = 1
+    out[np.abs(out + 1) < epsilon] = -1
+    return out
+
+
+def constant_velocity(pp: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """pose after ``p`` when the motion pp -> p repeats (reference mp_slam/tracker.py:62-70): float32 on the host throughout,
+    ``p @ inverse(pp)`` then ``@ p``, rotation re-orthogonalised.  pp, p: [4,4] float32 CPU tensors."""
+    delta = p @ torch.inverse(pp).float()
+    pred = delta @ p
+    pred[:3, :3] = torch.from_numpy(orthogonalize_rotation(pred[:3, :3].numpy()))
+    return pred
 
 
 class Tracker:
@@ -38,11 +49,9 @@ class Tracker:
         if frame_id == 1 or (not constant_speed):
             self.est_c2w_data[frame_id] = self.est_c2w_data[frame_id - 1]
         else:
-            pp, p = (self._ro_host[f].astype(np.float64) if f in self._ro_host else self.RO_c2w_data[f].cpu().numpy().astype(np.float64)
+            pp, p = (torch.from_numpy(self._ro_host[f]) if f in self._ro_host else self.RO_c2w_data[f].cpu().float()
                      for f in (frame_id - 2, frame_id - 1))
-            pred = (p @ np.linalg.inv(pp)) @ p
-            pred[:3, :3] = orthogonalize_rotation(pred[:3, :3])
-            self._pred_host = pred.astype(np.float32)
+            self._pred_host = constant_velocity(pp, p).numpy()
             self.est_c2w_data[frame_id] = torch.from_numpy(self._pred_host).to(self.device)
             return self._pred_host                    # (the search starts from a host array: no read-back of what was just sent)
         return self.est_c2w_data[frame_id]

@@ -415,6 +415,25 @@ def make_tracker_host():
         out[f"loop{k}_search_size"], out[f"loop{k}_previous_search_size"] = tr.search_size.copy(), tr.previous_search_size.copy()
         out[f"loop{k}_previous_frame_success"] = np.array(bool(tr.previous_frame_success))
     out["n_loops"] = np.array(n_loops)
+    # ---- the constant-velocity prediction of the per-frame loop (mp_slam/tracker.py:55-72), float32 on the host
+    from mp_slam.tracker import Tracker
+    tk = Tracker.__new__(Tracker)
+    tk.device = "cpu"
+    n_pred = 8
+    ro = torch.zeros((n_pred + 2, 4, 4))
+    ang = np.cumsum(rng.normal(0, 0.02, (n_pred + 2, 3)), 0)
+    for i in range(n_pred + 2):
+        cx, cy, cz = np.cos(ang[i]); sx, sy, sz = np.sin(ang[i])
+        Rm = np.array([[cy * cz, -cy * sz, sy], [sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy],
+                       [-cx * sy * cz + sx * sz, cx * sy * sz + sx * cz, cx * cy]])
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = Rm, [0.03 * i + rng.normal(0, 0.002), rng.normal(0, 0.002), 1.0 + 0.01 * i]
+        ro[i] = torch.from_numpy(m.astype(np.float32))
+    tk.RO_c2w_data = ro.clone()
+    tk.est_c2w_data = torch.zeros((n_pred + 2, 4, 4))
+    tk.est_c2w_data[0] = ro[0]
+    preds = [tk.predict_current_pose(f, True).clone() for f in range(1, n_pred + 2)]
+    out["pred_ro"], out["pred_out"] = ro, torch.stack(preds)
     save("tracker_host.npz", **out)
 
 

@@ -248,3 +248,18 @@ def test_tracker_host_logic_matches_reference():
         assert np.array_equal(st.previous_search_size, g[f"loop{k}_previous_search_size"]), k
         assert st.first_success == bool(g[f"loop{k}_previous_frame_success"]), k
     assert n_loop_fail >= 10
+
+
+def test_constant_velocity_prediction_matches_reference():
+    """mp_slam/tracker.py:55-72 (`predict_current_pose`): frame 1 starts from the previous estimate; from frame 2 on the motion
+    between the tracker's last two results repeats -- float32 inverse and products on the host, rotation re-orthogonalised by a
+    float32 SVD (model/utils.py:63-70).  The product's `constant_velocity` gives the reference's own output bit for bit."""
+    from remixfusion_amd.mp_slam.tracker import constant_velocity
+    g = np.load(os.path.join(G, "tracker_host.npz"))
+    ro, out = torch.from_numpy(g["pred_ro"]), g["pred_out"]
+    assert np.array_equal(out[0], ro[0].numpy())
+    for f in range(2, out.shape[0] + 1):
+        mine = constant_velocity(ro[f - 2].clone(), ro[f - 1].clone())
+        assert mine.dtype == torch.float32 and np.array_equal(mine.numpy(), out[f - 1]), f
+        R = mine[:3, :3].double()
+        assert float((R @ R.T - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-6

@@ -7,7 +7,7 @@ import numpy as np, torch
 from remixfusion_amd.config import synthetic_config
 from remixfusion_amd.datasets import get_dataset
 from remixfusion_amd.model.ROtracker import ROTracker
-from remixfusion_amd.mp_slam.tracker import orthogonalize_rotation
+from remixfusion_amd.mp_slam.tracker import constant_velocity
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 mode = os.environ.get("MODE", "own")
 random.seed(0)
@@ -25,10 +25,7 @@ for i in range(1, N):
     if i == 1:
         pred = est[0].copy()
     else:
-        pp, p = est[-2].astype(np.float64), est[-1].astype(np.float64)
-        pred = (p @ np.linalg.inv(pp)) @ p
-        pred[:3, :3] = orthogonalize_rotation(pred[:3, :3])
-        pred = pred.astype(np.float32)
+        pred = constant_velocity(torch.from_numpy(est[-2]), torch.from_numpy(est[-1])).numpy()
     pose, rgb, depth = tr.do_tracking(pred, None, b, "cuda")
     est.append(pose.copy())
     origin_before = np.array(tr.MV.vol_origin).copy()
