@@ -104,6 +104,16 @@ class MappingPipeline:
         if self.mapper is not None:
             n = self.config["mapping"]["first_iters"] if first_iters is None else first_iters
             self.mapper.first_frame_mapping({k: v for k, v in batch0.items() if k not in ("rgb255", "c2w_dev")}, n)
+        # A full (generation-2) pass of Python's cyclic collector over a torch process's ~1e6 long-lived objects takes 60-110 ms
+        # (measured: tools/tracker_times.py) -- a hundred frames' worth whenever it fires inside the frame loop.  Everything alive
+        # now (modules, the model, the dataset, the buffers) stays for the run: `pipeline.gc_freeze: True` collects once and moves
+        # it all to the permanent generation, so that later passes only walk what the loop itself creates.  Opt-in, because it is
+        # process-wide and for the life of the process: a frozen pipeline that is dropped later is never collected (its cycles
+        # hold its GPU buffers) -- right for a process that runs ONE stream, wrong for one that builds pipelines in a loop (tests).
+        if self.config.get("pipeline", {}).get("gc_freeze", False):
+            import gc
+            gc.collect()
+            gc.freeze()
 
     def track_frame(self, i: int, batch: Dict):
         """tracker side with GT pose: follow the camera with the volume, then integrate
