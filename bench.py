@@ -305,6 +305,8 @@ def run_same_scene_alone(args, world, device):
     pipe.start(frames[0])
     for i in range(1, 1 + args.warmup):
         pipe.step(i, frames[i])
+    import gc
+    gc.collect()                            # (a full pass costs 60-110 ms in a torch process: not inside the timed frames)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(1 + args.warmup, n_frames):
@@ -337,6 +339,8 @@ def run_one_scene(args, dist, rank, world, device, timer):
         dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()                            # (a full pass costs 60-110 ms in a torch process: not inside the timed frames)
     barrier()
     timer.enabled = True
     it0 = dict(direct.iterations)
