@@ -16,6 +16,8 @@ imports; no reference source is copied.  What gets pinned:
   host.npz       datasets/utils.get_camera_rays, model/utils.batchify, config.load_config,
                  KeyFrameDatabase.sample_global_rays under random.seed                      (callers)
   volume_bounds.npz  moving_volume bound logic + a scripted check_move_volume_new walk      (V-bnd)
+  smoothness.npz     mp_slam/slam.py SLAM.smoothness (lattice of the TV term + the TV sum) with the oracle's hash encoder
+                 attached as `model.query_sdf_res`, under torch.manual_seed                                          (TV1)
   tracker_host.npz   model/ROtracker.py cal_transform, update_PST and whole random_optimization loops (host logic of the pose
                  search) on injected fitness arrays: PyCUDA / cv2 stubbed, the CUDA evaluation replaced by the injected arrays.
                  Arithmetic is this container's numpy (recorded in the file): oracle/tracker_host_oracle.py mode="numpy2"  (f1)
@@ -321,18 +323,67 @@ def make_pst_fixture():
          sqs=np.array(sqs), sha256=np.array(shas))
 
 
+def _reference_host_modules():
+    """make the reference's mp_slam / model.ROtracker importable: absent third-party names stubbed, `datasets` pointed at the
+    reference's directory (it has no __init__.py and an installed package of the same name would win)"""
+    import model.Volume  # noqa: F401  (imported while pycuda.driver is absent: its CUDA_GPU_MODE stays 0)
+    _stub("pycuda.driver", PointerHolderBase=object)
+    _stub("pycuda.compiler", SourceModule=_Any)
+    _stub("imageio", imwrite=_Any())
+    _stub("torchmetrics.image.lpip", LearnedPerceptualImagePatchSimilarity=_Any)
+    _stub("pytorch3d.transforms", matrix_to_quaternion=_Any, quaternion_to_matrix=_Any, rotation_6d_to_matrix=_Any,
+          quaternion_to_axis_angle=_Any)
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        _stub("matplotlib.pyplot")
+    if "datasets" not in sys.modules or not str(getattr(sys.modules["datasets"], "__path__", [""])[0]).startswith(REF):
+        ns = types.ModuleType("datasets")
+        ns.__path__ = [os.path.join(REF, "datasets")]
+        sys.modules["datasets"] = ns
+
+
+def make_smoothness():
+    """SLAM.smoothness (mp_slam/slam.py:193-217): the reference's own lattice construction (two torch.rand draws, `coordinates`,
+    normalisation) and TV sum, with the oracle's hash encoder standing where tinycudann's would (model.query_sdf_res(.., embed=True)
+    returns the raw hash features)."""
+    _reference_host_modules()
+    from mp_slam.slam import SLAM
+    out = {}
+    cases = [("int_bounds", [[-3.0, 3.0], [-4.0, 3.0], [-2.0, 2.0]], 16, 0.1, 0.05, 3),
+             ("frac_bounds", [[-2.7, 3.1], [-3.3, 2.4], [-1.4, 1.9]], 32, 0.05, 0.05, 4)]
+    meta = FO.hashgrid_meta_from_config(12, 64)
+    g = torch.Generator().manual_seed(17)
+    table = (torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.3
+    out["table"], out["hash_T"], out["hash_R"] = table, 12, 64
+    for name, bb, sp, vox, margin, seed in cases:
+        slam = SLAM.__new__(SLAM)
+        slam.bounding_box = torch.tensor(bb, dtype=torch.float32)
+        slam.config = {"grid": {"tcnn_encoding": True}}
+        seen = {}
+
+        class _M:
+            @staticmethod
+            def query_sdf_res(pts, embed=False):
+                assert embed
+                seen["pts"] = pts.clone()
+                return FO.grid_encode(pts.reshape(-1, 3), table, meta).reshape(*pts.shape[:-1], -1)
+        slam.model = _M()
+        torch.manual_seed(seed)
+        loss = slam.smoothness(sp, vox, margin)
+        out[f"{name}_bbox"], out[f"{name}_args"], out[f"{name}_seed"] = slam.bounding_box, np.array([sp, vox, margin]), seed
+        out[f"{name}_pts"] = seen["pts"][::3, ::3, ::3].contiguous()
+        out[f"{name}_pts_sum"] = seen["pts"].double().sum(dim=(0, 1, 2))
+        out[f"{name}_loss"] = loss
+    save("smoothness.npz", **out)
+
+
 def make_tracker_host():
     """the reference's OWN host logic of the pose search (model/ROtracker.py:606-709 cal_transform, :493-534 update_PST, :713-831
     random_optimization) on synthetic fitness values.  The tracker object is made without its __init__ (which allocates through
     PyCUDA and reads the TIFF templates); `evaluate_tsdf` -- the CUDA launch -- hands out the injected arrays instead, the two
     image-preparation launches are no-ops.  Nothing of the logic under test is replaced."""
-    import model.Volume  # noqa: F401  (imported while pycuda.driver is absent: its CUDA_GPU_MODE stays 0)
-    _stub("pycuda.driver", PointerHolderBase=object)
-    _stub("pycuda.compiler", SourceModule=_Any)
-    # /root/reference/datasets has no __init__.py and an installed package of the same name would win: point the name at the directory
-    ns = types.ModuleType("datasets")
-    ns.__path__ = [os.path.join(REF, "datasets")]
-    sys.modules["datasets"] = ns
+    _reference_host_modules()
     from model.ROtracker import ROTracker
     rng = np.random.default_rng(20251205)
     depth_level = [32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16, 8, 32, 16]
@@ -444,6 +495,9 @@ if __name__ == "__main__":
     if "--tracker-host-only" in sys.argv:
         make_tracker_host()
         sys.exit(0)
+    if "--smoothness-only" in sys.argv:
+        make_smoothness()
+        sys.exit(0)
     make_pst_fixture()
     make_decoder()
     make_render()
@@ -451,4 +505,5 @@ if __name__ == "__main__":
     make_host()
     make_volume_bounds()
     make_mapping()
+    make_smoothness()
     make_tracker_host()

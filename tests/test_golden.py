@@ -263,3 +263,24 @@ def test_constant_velocity_prediction_matches_reference():
         assert mine.dtype == torch.float32 and np.array_equal(mine.numpy(), out[f - 1]), f
         R = mine[:3, :3].double()
         assert float((R @ R.T - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-6
+
+
+def test_smoothness_matches_reference():
+    """mp_slam/slam.py:193-217 `SLAM.smoothness` run from the reference's own code (tests/golden/smoothness.npz): the lattice the
+    two torch.rand draws place (integer and fractional bounds), its normalisation, and the TV sum over the oracle encoder's
+    features.  The oracle's restatement gives the same points and the same value, bit for bit, from the same draws."""
+    g = L("smoothness.npz")
+    meta = FO.hashgrid_meta_from_config(int(g["hash_T"]), int(g["hash_R"]))
+    table = T(g["table"])
+    for name in ("int_bounds", "frac_bounds"):
+        bbox = T(g[f"{name}_bbox"])
+        sp, vox, margin = int(g[f"{name}_args"][0]), float(g[f"{name}_args"][1]), float(g[f"{name}_args"][2])
+        torch.manual_seed(int(g[f"{name}_seed"]))
+        r_off = torch.rand(3)
+        r_jit = torch.rand((1, 1, 1, 3))
+        pts = FO.smoothness_points(bbox, sp, vox, margin, r_off, r_jit)
+        assert pts.shape == (sp - 1, sp - 1, sp - 1, 3)
+        assert torch.equal(pts[::3, ::3, ::3], T(g[f"{name}_pts"])), name
+        assert torch.equal(pts.double().sum(dim=(0, 1, 2)), T(g[f"{name}_pts_sum"])), name
+        feat = FO.grid_encode(pts.reshape(-1, 3), table, meta).reshape(sp - 1, sp - 1, sp - 1, -1)
+        assert torch.equal(FO.smoothness_from_features(feat, sp), T(g[f"{name}_loss"])), name
