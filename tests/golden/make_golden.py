@@ -485,6 +485,28 @@ def make_tracker_host():
     tk.est_c2w_data[0] = ro[0]
     preds = [tk.predict_current_pose(f, True).clone() for f in range(1, n_pred + 2)]
     out["pred_ro"], out["pred_out"] = ro, torch.stack(preds)
+    # ---- which template file the search reads at step k: the reference's readpst (:834-866) + get_PST (:474-492), with cv2.imread
+    #      (absent here) handing out arrays that carry their file's name
+    import model.ROtracker as ref_ro
+    small = [64, 32, 16]
+    names = {}
+
+    def fake_imread(fn, flag):
+        base = os.path.basename(fn)
+        size, num = (int(v) for v in base[len("pst_"):-len(".tiff")].split("_"))
+        names[(size, num)] = base
+        return np.full((size, 6), float(num + 100 * small.index(size)), dtype=np.float32)
+    ref_ro.cv2.imread = fake_imread
+    tr = tracker(200, 0, True, 0.09)
+    tr.readpst("/nonexistent/PFO", small)
+    files = []
+    for k in range(20):
+        a = tr.get_PST(tiff_index[k])
+        code = int(a[0, 0])
+        files.append(f"pst_{small[code // 100]}_{code % 100}.tiff")
+        assert a.shape == (small[code // 100], 6)
+    out["pst_file_at_step"] = np.array(files)
+    out["pst_container_shapes"] = np.array([tr.ALL_PST[c].shape for c in range(3)])
     save("tracker_host.npz", **out)
 
 

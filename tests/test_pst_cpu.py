@@ -116,3 +116,21 @@ def test_reference_templates_match_the_committed_digest():
     A = P.load_pst(d, SIZES, TIFF_INDEX)
     k = list(g["names"]).index("pst_3072_7.tiff")
     assert np.array_equal(A[1][7 // 3][:4], g["heads"][k])
+
+
+def test_template_file_of_every_search_step_matches_reference(tmp_path):
+    """tests/golden/tracker_host.npz `pst_file_at_step`: the file whose particles the reference's search reads at step k
+    (its own readpst + get_PST, model/ROtracker.py:834-866, :474-492, run with cv2.imread handing out arrays that carry their
+    file name).  The product's loader + `pst_slot` serve the same file at every step, from the same container shapes."""
+    P = _pst()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracker_host.npz"))
+    small = [64, 32, 16]
+    for size in small:
+        for num in range(20):
+            P.write_float_tiff(str(tmp_path / f"pst_{size}_{num}.tiff"), np.full((size, 6), float(num + 100 * small.index(size)), np.float32))
+    A = P.load_pst(str(tmp_path), small, TIFF_INDEX)
+    assert [list(A[c].shape) for c in range(3)] == g["pst_container_shapes"].tolist()
+    for k, ti in enumerate(TIFF_INDEX):
+        cls, _, slot = P.pst_slot(ti)
+        code = int(A[cls][slot][0, 0])
+        assert f"pst_{small[code // 100]}_{code % 100}.tiff" == str(g["pst_file_at_step"][k]), k
