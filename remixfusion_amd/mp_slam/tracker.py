@@ -41,6 +41,7 @@ class Tracker:
         self.device = device
         self.RO_Tracker = ROTracker(config, dataset, device=device, volume_factory=volume_factory)
         self.all_poses = []
+        self._key_inv, self._ro_key = (-1, None), (-1, None)
         self._ro_host = {}              # frame id -> the tracker's own result as it left the search (numpy, host): what the
                                         # constant-velocity prediction reads, without a device->host copy (and its wait) per frame
 
@@ -69,8 +70,15 @@ class Tracker:
         self.all_poses.append(torch.from_numpy(RO_pose_np).float())
         ke = self.config["mapping"]["keyframe_every"]
         if frame_id % ke != 0:
-            key = self.RO_c2w_data[(frame_id // ke) * ke]
-            self.est_c2w_data_rel[frame_id] = cur @ torch.linalg.inv_ex(key).inverse
+            # pose relative to the frame's keyframe: the key pose is inverted in float32 on the HOST, as the reference does
+            # (`torch.inverse(c2w_key.cpu())`, :112-116) -- once per keyframe here, its device copy re-used by the frames after it
+            kf = (frame_id // ke) * ke
+            if self._key_inv[0] != kf:
+                key = torch.from_numpy(self._ro_key[1]) if self._ro_key[0] == kf else self.RO_c2w_data[kf].cpu().float()
+                self._key_inv = (kf, torch.inverse(key).float().to(self.device))
+            self.est_c2w_data_rel[frame_id] = cur @ self._key_inv[1]
+        else:
+            self._ro_key = (frame_id, np.asarray(RO_pose_np, np.float32).copy())
         self.RO_Tracker.post_processing(frame_id, RO_pose_np, rgb, depth, self.est_c2w_data)
 
     def run(self):
