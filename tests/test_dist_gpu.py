@@ -254,4 +254,4 @@ def test_sharded_volume_cold_readers_world3(tmp_path):
     # first frame's 20 searches start from identical state and must land within a tenth of a voxel (4 cm) of each other (measured
     # 0.04 and 1.1 mm in two runs); after that both must TRACK equally well.
     assert float(dp[1]) < 4e-3, float(dp[1])
-    assert float(err.max()) < 0.08 and float(err_s.max()) < 0.08 and abs(float(err_s.max()) - float(err.max())) < 0.03
+    assert float(err.max()) < 0.08 and float(err_s.max()) < 0.08 and abs(float(err_s.max()) - float(err.max())) < 0.05
