@@ -829,7 +829,7 @@ def main():
 
     fps = args.steps * world / elapsed
     out = {
-        "metric": "RGB-D frames/sec mapping (640x480, 1cm TSDF)", "value": round(fps, 2), "unit": "frames/s",
+        "metric": metric_name(cfg), "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32", "data": "synthetic",
