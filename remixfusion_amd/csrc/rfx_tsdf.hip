@@ -35,6 +35,15 @@
 #ifndef MV_ROWS_THREADS
 #define MV_ROWS_THREADS 1024     // mv_rows_kernel block: one queue atomic per block that has work
 #endif
+#ifndef MV_XCD_DEAL
+#define MV_XCD_DEAL 1  // mv_chunks_kernel: XCD k sweeps the k-th eighth of the queue (see the kernel)
+#endif
+#ifndef MV_DBG_SKIP
+#define MV_DBG_SKIP 0
+#endif
+#ifndef MV_DBG_NEAR
+#define MV_DBG_NEAR 0  // timing builds only: 1 = the exact path without its stores, 2 = without its gathers
+#endif
 #define MV_HDR 4       // workspace header words before the coarse tiles: [0] queue count, [1] risky-queue count
 
 namespace rfx {
@@ -42,11 +51,15 @@ namespace rfx {
 thread_local int g_last_hip_error = 0;
 
 #ifdef MV_STATS      // dev builds only (tools/v1_probe.py): work counters of the V1 kernel
-__device__ unsigned long long g_mv_stats[8];   // 0 waves, 1 waves with work, 2 chunk items, 3 lanes in z-range, 4 lanes projected
+__device__ unsigned long long g_mv_stats[16];   // 0 waves, 1 waves with work, 2 chunk items, 3 lanes in z-range, 4 lanes projected
                                                // in-image, 5 lanes updated, 6 colour-band lanes, 7 risky-row chunk items
 #define MV_STAT(i, v) do { unsigned long long _v = (v); if (_v) atomicAdd(&g_mv_stats[i], _v); } while (0)
 #else
 #define MV_STAT(i, v) do { } while (0)
+#endif
+
+#ifdef MV_TIMING     // dev builds only (tools/v1_wave_times.py): start / end of every wave of mv_chunks_kernel, 100 MHz ticks
+__device__ unsigned long long g_mv_times[2 * 8192 * 2];
 #endif
 
 struct MvParams {
@@ -440,8 +453,12 @@ __device__ __forceinline__ bool alias_zone(const MvParams& P, int ry, int z) {
 //   untouched (sdf < -trunc) is implied by  n2 > G := ((d + trunc)(1 + 1e-5) + 1e-6)^2 / rl^2 * (1 + 1e-5)
 // The relative margins (1e-5) are ~100 fp32 ulps; the roundings in forming F, G, n2 and sdf are a handful of ulps each.
 // d <= 0 or NaN: F = 0, G = -1 (n2 > -1 always: untouched, the reference returns at `depth <= 0`).
+// Queue form (nimg != nullptr): writes fg and the exact path's image nimg = {depth, 1/lambda, packed colour, 0} (round 5: the
+// three values the exact path samples at a pixel in ONE 16-byte gather; the packed colour is formed from rgb or copied from
+// the caller's color_packed).  Tile form (nimg == nullptr): writes dimg = {depth, 1/lambda} and, from rgb, cpk.
 __global__ __launch_bounds__(256) void mv_frame_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
-                                                       float2* __restrict__ dimg, float2* __restrict__ fg,
+                                                       const float* __restrict__ color_packed,
+                                                       float2* __restrict__ dimg, float2* __restrict__ fg, float4* __restrict__ nimg,
                                                        float* __restrict__ cpk, unsigned* __restrict__ hdr, int H, int W,
                                                        float fx, float fy, float cx, float cy, float trunc, int colmajor) {
     // one block per MV_TD x MV_TD pixel tile, one pixel per thread (the divisions and square roots of a pixel are one
@@ -476,9 +493,15 @@ __global__ __launch_bounds__(256) void mv_frame_kernel(const float* __restrict__
         // contiguous turns the per-lane gather of a 64-voxel chunk from 64 cache lines into ~12: column-major when the
         // walk is mostly along image y.
         const int di = colmajor ? px * H + py : i;
-        dimg[di] = make_float2(d, rl);
-        fg[di] = make_float2(F, G);
-        if (rgb) cpk[i] = floorf(b * 65536.0f + g * 256.0f + r);   // np.floor(B*65536 + G*256 + R), left to right
+        const float packed = rgb ? floorf(b * 65536.0f + g * 256.0f + r)      // np.floor(B*65536 + G*256 + R), left to right
+                                 : (color_packed ? color_packed[i] : 0.0f);
+        if (nimg) {
+            fg[di] = make_float2(F, G);
+            nimg[di] = make_float4(d, rl, packed, 0.0f);
+        } else {
+            dimg[di] = make_float2(d, rl);
+            if (rgb) cpk[i] = packed;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -680,17 +703,16 @@ __device__ __forceinline__ bool div2_in_range(float cxv, float cyv, float czv) {
     return czv > 1e-6f && czv < 1e3f && fabsf(cxv) < 1e3f && fabsf(cyv) < 1e3f;
 }
 
-// The voxel update proper (integrate_lanes' expression tree, Volume.py:285-334) for ONE voxel whose depth sample is known.
+// The voxel update proper (integrate_lanes' expression tree, Volume.py:285-334) for ONE voxel whose depth sample, stored
+// values and colour sample are known (oc / ncl are only used inside the colour band).
 __device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, float cxv, float cyv, float czv, float d, float rl,
-                                             int pix, float cur, float w_old, const float* __restrict__ cpk,
+                                             float cur, float w_old, float oc, float ncl,
                                              float* __restrict__ tsdf, float* __restrict__ weight, float* __restrict__ color) {
     const float norm = sqrtf(madd(czv, czv, madd(cxv, cxv, cyv * cyv)));
     const float sdf = -madd(rl, norm, -d);
     const bool upd = (d > 0.0f) && (sdf >= -P.trunc);
     if (!upd) return;
     const bool band = sdf <= P.trunc;
-    float oc = 0.f, ncl = 0.f;
-    if (band) { oc = color[idx]; ncl = cpk[pix]; }
     const float dist = fminf(1.0f, sdf / P.trunc);
     const float w_new = w_old + P.obs_weight;
     float new_t = madd(cur, w_old, P.obs_weight * dist) / w_new;
@@ -715,30 +737,38 @@ __device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, flo
     }
     const bool reset = (P.obs_weight == -1.0f) && (w_old <= 1.0f) && (P.reintegrate == 1);
     if (reset) { new_t = 1.0f; new_w = 0.0f; new_c = 0.0f; }
+#if MV_DBG_NEAR & 1
+    if (new_t == 12345.678f && new_w == 3.f && new_c == 7.f) tsdf[idx] = new_t;
+#else
     tsdf[idx] = new_t;
     weight[idx] = new_w;
     if (band || reset) color[idx] = new_c;
+#endif
 }
 
-// pending exact-path records of one wave (< 64 kept + <= 64 new per item), field-major in LDS
-constexpr int MV_NEAR_FIELDS = 6;      // voxel index, camera point, tsdf, weight as loaded
+// ---- the exact path ("near" voxels: truncation band, boundary pixels, voxels that held a surface before).
+// Pending records of one wave, field-major in LDS: voxel index, camera point, the stored tsdf / weight as the fast path
+// loaded them (24 B per record: re-reading them in the round instead was measured, the lines have left the L2 by then and
+// the kernel fetched 75 MB more per frame).  Round 5: the records are
+// NOT evaluated where they arise.  Up to round 4 a wave drained its list as soon as it held 64 records -- two dependent
+// memory round trips (depth sample, then colour) in the middle of the item loop, 0 to 5 times per wave depending on how
+// much surface its rows cross: 16 of the kernel's 44 us, most of it waves waiting behind their own drains while the rest
+// of the chip had finished (tools/v1_wave_times.py: wave lifetimes 11-38 us around a mean of 27).  Now a wave only appends
+// (a drain inside the loop happens when a list is about to overflow: MV_NEAR_CAP records); after the item loop the
+// block's four lists are dealt out again in rounds of 64 records over the four waves (near_finish), and a round issues
+// everything it reads -- depth sample, stored colour, colour sample -- at once: one round trip.
+constexpr int MV_NEAR_FIELDS = 6;      // voxel index, camera point, tsdf and weight as the fast path loaded them
+constexpr int MV_NEAR_CAP = 192;       // records per wave (4.5 KB; 8 blocks per CU: 147 of 160 KB); a list is drained inside
+                                       // the loop above CAP - 64 (a frame of the bench leaves ~80 per wave)
 struct NearList {
-    float (*nb)[128];
+    float (*nb)[MV_NEAR_CAP];
     int n;                 // wave-uniform fill
 };
 
-// the reference's full update on the top min(64, n) pending records (one per lane): exact projection, depth sample, update
-__device__ __forceinline__ void near_drain(const MvParams& P, NearList& L, int lane, const float2* __restrict__ dimg,
-                                           const float* __restrict__ cpk, float* __restrict__ tsdf,
-                                           float* __restrict__ weight, float* __restrict__ color) {
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS stores have landed
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-    const int take = min(64, L.n), base = L.n - take;
-    const bool act = lane < take;
-    const int s = base + (act ? lane : 0);
-    const int64_t idx = (int64_t)__float_as_int(L.nb[0][s]);        // < 2^31 voxels (checked by the host)
-    const float cxv = L.nb[1][s], cyv = L.nb[2][s], czv = L.nb[3][s], cur = L.nb[4][s], wold = L.nb[5][s];
+// the reference's full update on one record per lane: exact projection, depth sample, stored values, update
+__device__ __forceinline__ void near_round(const MvParams& P, bool act, int64_t idx, float cxv, float cyv, float czv,
+                                           float cur, float wold, const float4* __restrict__ nimg,
+                                           float* __restrict__ tsdf, float* __restrict__ weight, float* __restrict__ color) {
     bool v = act && czv > 0.0f;
     const bool generic = v && !div2_in_range(cxv, cyv, czv);
     const float czs = v ? czv : 1.0f;
@@ -749,10 +779,31 @@ __device__ __forceinline__ void near_drain(const MvParams& P, NearList& L, int l
     const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
     v = v && px >= 0 && px < P.W && py >= 0 && py < P.H;
     if (v) {
-        const int pix = py * P.W + px;
-        const float2 dl = dimg[P.dimg_colmajor ? px * P.H + py : pix];
-        update_voxel(P, idx, cxv, cyv, czv, dl.x, dl.y, pix, cur, wold, cpk, tsdf, weight, color);
+        // both loads of the round are issued here (the stored colour speculatively: it is only used inside the band)
+#if MV_DBG_NEAR & 2
+        const float4 dl = make_float4(cxv + 2.0f, 0.5f, czv, 0.f);
+        const float oc = cyv;
+#else
+        const float4 dl = nimg[P.dimg_colmajor ? px * P.H + py : py * P.W + px];
+        const float oc = color[idx];
+#endif
+        update_voxel(P, idx, cxv, cyv, czv, dl.x, dl.y, cur, wold, oc, dl.z, tsdf, weight, color);
     }
+}
+
+// the top min(64, n) pending records of the wave's own list
+__device__ __forceinline__ void near_drain(const MvParams& P, NearList& L, int lane, const float4* __restrict__ nimg,
+                                           float* __restrict__ tsdf,
+                                           float* __restrict__ weight, float* __restrict__ color) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const int take = min(64, L.n), base = L.n - take;
+    const bool act = lane < take;
+    const int s = base + (act ? lane : 0);
+    const int64_t idx = (int64_t)__float_as_int(L.nb[0][s]);        // < 2^31 voxels (checked by the host)
+    const float cxv = L.nb[1][s], cyv = L.nb[2][s], czv = L.nb[3][s], cur = L.nb[4][s], wold = L.nb[5][s];
+    near_round(P, act, idx, cxv, cyv, czv, cur, wold, nimg, tsdf, weight, color);
     MV_STAT(6, (unsigned long long)take * (lane == 0));
     L.n = base;
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -772,6 +823,27 @@ __device__ __forceinline__ void near_append(NearList& L, bool near_l, int lane, 
     L.n += __popcll(m);
 }
 
+// after the item loop (every wave of the block gets here): the block's pending records in rounds of 64, round r to wave r % 4
+__device__ __forceinline__ void near_finish(const MvParams& P, float (*lists)[MV_NEAR_FIELDS][MV_NEAR_CAP], int* counts, int n_own,
+                                            int wv, int lane, const float4* __restrict__ nimg,
+                                            float* __restrict__ tsdf, float* __restrict__ weight, float* __restrict__ color) {
+    if (lane == 0) counts[wv] = n_own;
+    __syncthreads();
+    const int n0 = counts[0], n1 = counts[1], n2 = counts[2], n3 = counts[3];
+    const int total = n0 + n1 + n2 + n3;
+    for (int r = wv; r * 64 < total; r += 4) {
+        const int g = r * 64 + lane;
+        const bool act = g < total;
+        const int gc = act ? g : 0;
+        const int w = (gc >= n0) + (gc >= n0 + n1) + (gc >= n0 + n1 + n2);
+        const int s = gc - (w > 0 ? n0 : 0) - (w > 1 ? n1 : 0) - (w > 2 ? n2 : 0);
+        const int64_t idx = (int64_t)__float_as_int(lists[w][0][s]);
+        const float cxv = lists[w][1][s], cyv = lists[w][2][s], czv = lists[w][3][s], cur = lists[w][4][s], wold = lists[w][5][s];
+        near_round(P, act, idx, cxv, cyv, czv, cur, wold, nimg, tsdf, weight, color);
+        MV_STAT(6, (unsigned long long)min(64, total - r * 64) * (lane == 0));
+    }
+}
+
 constexpr unsigned MV_OOB = 0x80000000u;      // a buffer offset beyond every descriptor's range: the access is dropped
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mv_rsrc(const void* base, unsigned bytes) {
@@ -785,9 +857,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mv_rsrc(const void* base, unsi
 // classification gather is a buffer load through ONE loop-invariant descriptor whose range check drops the lanes that
 // have no pixel, and the items are not fetched ahead (sixteen more live scalar registers spilled into vector lanes).
 template <int U>
-__device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned n, const MvItem* __restrict__ queue,
-                                               const float2* __restrict__ dimg, const float2* __restrict__ fg,
-                                               const float* __restrict__ cpk, float* __restrict__ tsdf,
+__device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned begin, unsigned n, const MvItem* __restrict__ queue,
+                                               const float4* __restrict__ nimg, const float2* __restrict__ fg,
+                                               float* __restrict__ tsdf,
                                                float* __restrict__ weight, float* __restrict__ color, unsigned wave,
                                                unsigned n_waves, NearList& L) {
     const int lane = threadIdx.x & 63;
@@ -797,17 +869,45 @@ __device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned n, co
     const float sx8 = P.dimg_colmajor ? 8.0f * (float)P.H : 8.0f, sy8 = P.dimg_colmajor ? 8.0f : 8.0f * (float)P.W;
     const float edge = 0.5f - P.edge_eps;
     const float hw = 0.5f * (float)(P.W - 1), hh = 0.5f * (float)(P.H - 1);      // pixel px is in the image <=> |px - hw| <= hw
-    for (unsigned it = wave * U; it < n; it += n_waves * U) {
+    // ---- the wave's items.  Up to round 4 every trip began with scalar loads of its U items: one dependent round trip to
+    //      memory per trip in front of the round trip of the volume loads (~10 trips per wave, the waves 62 % of their
+    //      lifetime in s_waitcnt).  Now ONE vector gather per 16 trips puts 16 * U items into four registers -- lane 2k and
+    //      2k + 1 hold the two 16-byte halves of the batch's k-th item, the next batch is in flight while this one is
+    //      worked on -- and a trip takes its items out with v_readlane: no memory access between two trips.
+    constexpr unsigned TRIPS = 32u / (unsigned)U;                              // trips per batch: 32 items in 64 lanes
+    const unsigned first = begin + wave * (unsigned)U, stride = n_waves * (unsigned)U;
+    const unsigned n_trips = first < n ? (n - first + stride - 1u) / stride : 0u;
+    const unsigned last_item = n ? n - 1u : 0u;
+    auto fetch = [&](unsigned trip0) -> uint4 {      // items of trips [trip0, trip0 + TRIPS): item k of the batch -> lanes 2k, 2k + 1
+        const unsigned k = (unsigned)lane >> 1;
+        const unsigned idx = min(first + (trip0 + k / (unsigned)U) * stride + k % (unsigned)U, last_item);
+        return reinterpret_cast<const uint4*>(queue)[(size_t)idx * 2u + ((unsigned)lane & 1u)];
+    };
+    uint4 batch = make_uint4(0u, 0u, 0u, 0u), batch_next = batch;
+    if (n_trips) batch = fetch(0u);
+    for (unsigned trip = 0; trip < n_trips; ++trip) {
+        const unsigned it = first + trip * stride;
+        const unsigned tb = trip % TRIPS;
+        if (tb == 0u) {
+            if (trip) batch = batch_next;
+            if (trip + TRIPS < n_trips) batch_next = fetch(trip + TRIPS);
+        }
         float cxv[U], cyv[U], czv[U], cur[U], wold[U];
         float2 fgv[U];
         bool inside[U], exact[U];
         int idx[U];
         float* wp[U];
-        // ---- the trip's items (scalar loads, all issued before the first is used; an item past the end is replaced by
-        //      the trip's first and gets an empty lane interval)
         MvItem items[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) items[u] = queue[it + u < n ? it + u : it];
+        for (int u = 0; u < U; ++u) {
+            const int l0 = (int)(tb * (unsigned)U + (unsigned)u) * 2;
+            items[u].cw = (unsigned)__builtin_amdgcn_readlane((int)batch.y, l0);
+            items[u].ax = __int_as_float(__builtin_amdgcn_readlane((int)batch.z, l0));
+            items[u].ay = __int_as_float(__builtin_amdgcn_readlane((int)batch.w, l0));
+            items[u].az = __int_as_float(__builtin_amdgcn_readlane((int)batch.x, l0 + 1));
+            items[u].off_lo = (unsigned)__builtin_amdgcn_readlane((int)batch.y, l0 + 1);
+            items[u].off_hi = (unsigned)__builtin_amdgcn_readlane((int)batch.z, l0 + 1);
+        }
         // ---- stage 0: volume loads, camera point, approximate projection, classification gather.  Lane predicates are
         //      combined with & (no short-circuit: a && here becomes a divergent branch with its scalar bookkeeping)
 #pragma unroll
@@ -824,8 +924,16 @@ __device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned n, co
             // lanes outside the row's interval read the nearest voxel inside it: the same 64-byte sectors as their
             // neighbours, so a partial chunk costs the memory system only the sectors its interval touches
             const unsigned lane_c = (unsigned)min(max(lane, lo_l), max(lo_l + len_l - 1, lo_l));
+#if MV_DBG_SKIP & 1        // timing builds only (results wrong): one memory stream of the fast body removed at a time
+            cur[u] = 1.0f; (void)tp;
+#else
             cur[u] = tp[lane_c];
+#endif
+#if MV_DBG_SKIP & 2
+            wold[u] = (float)(lane_c & 1u);
+#else
             wold[u] = wp[u][lane_c];
+#endif
             inside[u] = (unsigned)(lane - lo_l) < (unsigned)len_l;
             idx[u] = (int)(off >> 2) + lane;
             // camera point, exactly as the reference forms it
@@ -868,25 +976,36 @@ __device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned n, co
             // fminf(w, 128) then "> 40 -> 40" of the reference is min(w, 40) for every input, NaN included
             const float w_sum = wold[u] + P.obs_weight;
             const float new_w = P.weight_clamp == 1 ? fminf(w_sum, 40.0f) : w_sum;
+#if !(MV_DBG_SKIP & 8)
             if (free_1 & (new_w != wold[u])) wp[u][(unsigned)lane] = new_w;           // tsdf stays 1 (see the header)
+#endif
             MV_STAT(5, __popcll(__ballot(free_1)) * (lane == 0));
             const bool near_l = exact[u] | band | (free_l & !one);
+            // 8: items none of whose lanes is touched; 9: their in-interval lanes; 10: items with a weight store; 11: items with near lanes
+            MV_STAT(8, (it + u < n) && !__any(free_1 | near_l) && lane == 0 ? 1 : 0);
+            MV_STAT(9, !__any(free_1 | near_l) ? __popcll(__ballot(inside[u])) * (lane == 0) : 0);
+            MV_STAT(10, __any(free_1 & (new_w != wold[u])) && lane == 0 ? 1 : 0);
+            MV_STAT(11, __any(near_l) && lane == 0 ? 1 : 0);
+#if MV_DBG_SKIP & 16
+            if (__any(near_l) && cxv[u] == 12345.678f) tsdf[0] = 0.f;
+#else
             near_append(L, near_l, lane, idx[u], cxv[u], cyv[u], czv[u], cur[u], wold[u]);
-            if (L.n >= 64) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
+            if (L.n > MV_NEAR_CAP - 64) near_drain(P, L, lane, nimg, tsdf, weight, color);
+#endif
         }
     }
 }
 
 // ---- generic body: every lane of an item through the exact projection; free-space shortcut only when `fast`
 template <int U, bool RISKY, bool REINT>
-__device__ __forceinline__ void mv_chunks_generic(const MvParams& P, unsigned n, const MvItem* __restrict__ queue,
-                                                  const float2* __restrict__ dimg, const float* __restrict__ cpk,
+__device__ __forceinline__ void mv_chunks_generic(const MvParams& P, unsigned begin, unsigned n, const MvItem* __restrict__ queue,
+                                                  const float4* __restrict__ nimg,
                                                   float* __restrict__ tsdf, float* __restrict__ weight,
                                                   float* __restrict__ color, unsigned wave, unsigned n_waves, NearList& L,
                                                   int64_t slab_skip) {
     const int lane = threadIdx.x & 63;
     const bool fast = !REINT && P.obs_weight > 0.0f;
-    for (unsigned it = wave * U; it < n; it += n_waves * U) {
+    for (unsigned it = begin + wave * U; it < n; it += n_waves * U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // every load below is UNCONDITIONAL with an in-bounds address (a load under a lane mask gets its own basic block
@@ -926,7 +1045,7 @@ __device__ __forceinline__ void mv_chunks_generic(const MvParams& P, unsigned n,
                 const int px = f2i_rn(madd(P.K[0], qx, P.K[2]));
                 const int py = f2i_rn(madd(P.K[4], qy, P.K[5]));
                 const bool ok = near_l && px >= 0 && px < P.W && py >= 0 && py < P.H;
-                const float2 dl = dimg[ok ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0];
+                const float2 dl = *reinterpret_cast<const float2*>(nimg + (ok ? (P.dimg_colmajor ? px * P.H + py : py * P.W + px) : 0));
                 const float d = dl.x;
                 const float norm_a = __builtin_amdgcn_sqrtf(madd(czv, czv, madd(cxv, cxv, cyv * cyv)));
                 const float sdf_a = d - dl.y * norm_a;
@@ -946,7 +1065,7 @@ __device__ __forceinline__ void mv_chunks_generic(const MvParams& P, unsigned n,
                 near_l = cand && !free_l;
             }
             near_append(L, near_l, lane, (int)(row0 + z), cxv, cyv, czv, cur, wold);
-            if (L.n >= 64) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
+            if (L.n > MV_NEAR_CAP - 64) near_drain(P, L, lane, nimg, tsdf, weight, color);
         }
     }
 }
@@ -962,27 +1081,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void mv_c
                                                         const MvItem* __restrict__ queue, unsigned q_cap,
                                                         const MvItem* __restrict__ queue_risky, unsigned q_cap_risky,
                                                         unsigned blocks_main, int64_t slab_skip,
-                                                        const float2* __restrict__ dimg, const float2* __restrict__ fg,
-                                                        const float* __restrict__ cpk,
+                                                        const float4* __restrict__ nimg, const float2* __restrict__ fg,
                                                         float* __restrict__ tsdf, float* __restrict__ weight,
                                                         float* __restrict__ color) {
-    __shared__ float nbuf[4][MV_NEAR_FIELDS][128];
+    __shared__ float nbuf[4][MV_NEAR_FIELDS][MV_NEAR_CAP];
+    __shared__ int near_counts[4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef MV_TIMING
+    const unsigned long long t_start = wall_clock64();
+#endif
     NearList L;
     L.nb = nbuf[wv];
     L.n = 0;
     if (blockIdx.x < blocks_main) {
         const unsigned n = min(q_counts[0], q_cap);
+#if MV_XCD_DEAL
+        // XCD-contiguous dealing.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8; an affinity for speed, never for
+        // correctness) and every XCD has an L2 of its own: with the items dealt cyclically over the whole grid each L2 sees
+        // rows from all over the frustum, pulls in its own copy of the whole {F, G} / depth / colour images and shares the
+        // lines between neighbouring chunks of a row with another XCD.  Here XCD k sweeps the k-th eighth of the queue (rows
+        // in (x, y) order: a slab of the footprint), its waves side by side: an eighth of the images per L2, neighbours together.
+        const unsigned segs = min(8u, blocks_main);                                      // a grid of fewer than 8 blocks: as many parts
+        const unsigned xcd = blockIdx.x % segs, nb = (blocks_main - xcd + segs - 1u) / segs;     // main blocks of this part (>= 1)
+        const unsigned per = ((n + segs - 1u) / segs + (unsigned)U - 1u) / (unsigned)U * (unsigned)U;    // items per part, a multiple of U
+        const unsigned begin = min(n, xcd * per), end = min(n, begin + per);
+        const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x / segs) * 4u + (unsigned)wv), n_waves = nb * 4u;
+#else
+        const unsigned begin = 0u, end = n;
         const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (unsigned)wv), n_waves = blocks_main * 4u;
-        if (FAST) mv_chunks_fast<U>(P, n, queue, dimg, fg, cpk, tsdf, weight, color, wave, n_waves, L);
-        else mv_chunks_generic<U, false, REINT>(P, n, queue, dimg, cpk, tsdf, weight, color, wave, n_waves, L, slab_skip);
+#endif
+        if (FAST) mv_chunks_fast<U>(P, begin, end, queue, nimg, fg, tsdf, weight, color, wave, n_waves, L);
+        else mv_chunks_generic<U, false, REINT>(P, begin, end, queue, nimg, tsdf, weight, color, wave, n_waves, L, slab_skip);
     } else {
         const unsigned n = min(q_counts[1], q_cap_risky);
         const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x - blocks_main) * 4u + (unsigned)wv);
-        mv_chunks_generic<U, true, REINT>(P, n, queue_risky, dimg, cpk, tsdf, weight, color, wave, (gridDim.x - blocks_main) * 4u, L,
+        mv_chunks_generic<U, true, REINT>(P, 0u, n, queue_risky, nimg, tsdf, weight, color, wave, (gridDim.x - blocks_main) * 4u, L,
                                           slab_skip);
     }
-    while (L.n > 0) near_drain(P, L, lane, dimg, cpk, tsdf, weight, color);
+    near_finish(P, nbuf, near_counts, L.n, wv, lane, nimg, tsdf, weight, color);
+#ifdef MV_TIMING
+    if (lane == 0 && blockIdx.x * 4u + wv < 2u * 8192u) {
+        __builtin_amdgcn_s_waitcnt(0);          // the wave's stores have left
+        g_mv_times[2 * (blockIdx.x * 4 + wv)] = t_start;
+        g_mv_times[2 * (blockIdx.x * 4 + wv) + 1] = wall_clock64();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------- simple sweeps
@@ -1272,18 +1415,25 @@ static inline size_t mv_header_bytes(size_t tiles) { return ((MV_HDR + tiles) * 
 extern "C" {
 
 #ifdef MV_STATS
-int rfx_debug_mv_stats(unsigned long long out[8], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rfx::g_mv_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rfx::g_mv_stats), z, sizeof(z)) != hipSuccess) return -1; }
+int rfx_debug_mv_stats(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rfx::g_mv_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rfx::g_mv_stats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
+}
+#endif
+
+#ifdef MV_TIMING
+int rfx_debug_mv_times(unsigned long long* out, int n_waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rfx::g_mv_times), sizeof(unsigned long long) * 2 * (size_t)n_waves) == hipSuccess ? 0 : -1;
 }
 #endif
 
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 int rfx_last_hip_error(void) { return g_last_hip_error; }
 
-// workspace = [queue counters + coarse max-depth tiles | {depth, 1/lambda} image | {F, G} classification image | packed
-// colour image (used when the caller hands over rgb) | work queue | queue of the rows next to x-slab boundaries].  The queue
+// workspace = [queue counters + coarse max-depth tiles | A: 8 B per pixel | B: 16 B per pixel | work queue | queue of the rows
+// next to x-slab boundaries].  Queue form: A = the {F, G} classification image, B = the exact path's image {depth, 1/lambda,
+// packed colour, 0}.  Tile form: A = {depth, 1/lambda}, B = the packed colour (when the caller hands over rgb).  The queue
 // is sized for the worst case (every 64-voxel chunk of the volume), so an append can never overflow: 32 B per chunk.
 static inline size_t mv_queue_capacity(int dx, int dy, int dz) { return (size_t)dx * dy * (size_t)((dz + 63) / 64); }
 constexpr size_t MV_QUEUE_PAD = 16;      // entries past the capacity that mv_chunks_kernel may read (never uses)
@@ -1300,7 +1450,7 @@ static inline size_t mv_cpk_bytes(int H, int W) { return ((size_t)H * W * sizeof
 size_t rfx_tsdf_integrate_workspace_bytes(int dx, int dy, int dz, int H, int W) {
     if (H <= 0 || W <= 0 || dx <= 0 || dy <= 0 || dz <= 0) return 0;
     const size_t tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
-    return mv_header_bytes(tiles) + 2 * mv_image_bytes(H, W) + mv_cpk_bytes(H, W) +
+    return mv_header_bytes(tiles) + 3 * mv_image_bytes(H, W) +
            (mv_queue_capacity(dx, dy, dz) + mv_risky_capacity(dx, dz) + 2 * MV_QUEUE_PAD) * sizeof(MvItem);
 }
 
@@ -1354,12 +1504,21 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
     hipStream_t st = as_stream(stream);
     unsigned* dmax_bits = reinterpret_cast<unsigned*>(workspace);
     const size_t n_tiles = (size_t)((H + MV_TD - 1) / MV_TD) * ((W + MV_TD - 1) / MV_TD);
-    float2* dimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + mv_header_bytes(n_tiles));
-    float2* fgimg = reinterpret_cast<float2*>(reinterpret_cast<char*>(dimg) + mv_image_bytes(H, W));
-    float* cpk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(fgimg) + mv_image_bytes(H, W));
+    float2* img_a = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + mv_header_bytes(n_tiles));
+    float4* img_b = reinterpret_cast<float4*>(reinterpret_cast<char*>(img_a) + mv_image_bytes(H, W));
+    char* after_images = reinterpret_cast<char*>(img_b) + 2 * mv_image_bytes(H, W);
+#ifndef MV_NO_QUEUE
+    const bool queue_form = !P.literal_all && dx <= MV_Q_MAX_DIM && dy <= MV_Q_MAX_DIM && dz <= 64 * 65535;
+#else
+    const bool queue_form = false;
+#endif
+    float2* dimg = img_a;                                   // tile form
+    float* cpk_ws = reinterpret_cast<float*>(img_b);
     const float* cpk = color_packed ? color_packed : cpk_ws;
-    hipLaunchKernelGGL(mv_frame_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, depth, rgb255, dimg, fgimg, cpk_ws, dmax_bits, H, W,
-                       K[0], K[4], K[2], K[5], trunc, P.dimg_colmajor);
+    float2* fgimg = img_a;                                  // queue form
+    float4* nimg = img_b;
+    hipLaunchKernelGGL(mv_frame_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, depth, rgb255, color_packed, dimg, fgimg,
+                       queue_form ? nimg : (float4*)nullptr, cpk_ws, dmax_bits, H, W, K[0], K[4], K[2], K[5], trunc, P.dimg_colmajor);
     RFX_LAUNCH_CHECK();
     constexpr int TX = MV_TX, TY = MV_TY, U = MV_U;
     // Window of tiles the view frustum can touch: the frustum is convex, so its (x,y) footprint lies in
@@ -1386,8 +1545,7 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
     }
     const int all_tx = (dx + TX - 1) / TX, all_ty = (dy + TY - 1) / TY;
     for (int i = 0; i < 3; ++i) { P.win_x0[i] = P.win_y0[i] = P.win_wx[i] = P.win_wy[i] = 0; }
-#ifndef MV_NO_QUEUE
-    if (!P.literal_all && dx <= MV_Q_MAX_DIM && dy <= MV_Q_MAX_DIM && dz <= 64 * 65535) {
+    if (queue_form) {
         // queue form: windows in ROWS.  [0] = the frustum footprint without the risky boundary rows, [1],[2] = those rows
         // (every x: their alias zones are walked whatever the view); they go to a queue of their own, whose body
         // carries the literal index decode.
@@ -1406,7 +1564,7 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         if (rows_main + rows_risky == 0) return RFX_OK;
         const int nch = (dz + 63) / 64;
         const size_t cap = mv_queue_capacity(x1 - x0, dy, dz), cap_risky = mv_risky_capacity(x1 - x0, dz);
-        MvItem* queue = reinterpret_cast<MvItem*>(reinterpret_cast<char*>(cpk_ws) + mv_cpk_bytes(H, W));
+        MvItem* queue = reinterpret_cast<MvItem*>(after_images);
         MvItem* queue_risky = queue + cap + MV_QUEUE_PAD;
         const unsigned q_cap = (unsigned)std::min<size_t>(cap, 0xffffffffu), q_cap_risky = (unsigned)std::min<size_t>(cap_risky, 0xffffffffu);
         const int blocks_main = (int)((rows_main + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS), blocks_risky = (int)((rows_risky + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS);
@@ -1416,8 +1574,8 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
         // chip); small volumes need fewer.  Three instances: the fast body (every mapping frame), the generic one, and
         // the generic one with the re-integration window test.
-        using Kern = void (*)(MvParams, const unsigned*, const MvItem*, unsigned, const MvItem*, unsigned, unsigned, int64_t, const float2*,
-                              const float2*, const float*, float*, float*, float*);
+        using Kern = void (*)(MvParams, const unsigned*, const MvItem*, unsigned, const MvItem*, unsigned, unsigned, int64_t, const float4*,
+                              const float2*, float*, float*, float*);
         const int variant = P.reintegrate ? 2 : (obs_weight > 0.0f && trunc > 0.0f && (int64_t)H * W * 8 < (1 << 24) ? 0 : 1);
         const Kern kern = variant == 2 ? (Kern)mv_chunks_kernel<U, false, true>
                         : variant == 1 ? (Kern)mv_chunks_kernel<U, false, false> : (Kern)mv_chunks_kernel<U, true, false>;
@@ -1440,11 +1598,10 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
             blocks_main_q = (int)std::max<int64_t>(1, std::min<int64_t>(resident[variant] - blocks_risky_q, (max_items + 4 * U - 1) / (4 * U)));
         }
         hipLaunchKernelGGL(kern, dim3(blocks_main_q + blocks_risky_q), dim3(256), 0, st, P, dmax_bits, queue, q_cap, queue_risky, q_cap_risky,
-                           (unsigned)blocks_main_q, skip, dimg, fgimg, cpk, tsdf, weight, color);
+                           (unsigned)blocks_main_q, skip, nimg, fgimg, tsdf, weight, color);
         RFX_LAUNCH_CHECK();
         return RFX_OK;
     }
-#endif
     if (!whole) return RFX_ERR_UNSUPPORTED;      // the tile-form fallback (literal decode everywhere) is not slab-aware
     if (P.risky_rows > 0 && !P.literal_all) {
         // boundary strips (all x): tile rows [0, s) and [all_ty - s, all_ty); the main window is clipped to what is left

@@ -307,20 +307,28 @@ def make_volume_bounds():
 def make_pst_fixture():
     """digest of the reference's 60 PST templates (PFO/fps_uniform_sphere, data files read by model/ROtracker.py:834-866
     with cv2): per file its shape, the first 4 rows, float64 sum / sum of squares and the SHA-256 of the sample bytes
-    -- enough to tell whether a user's directory holds the same particles, without shipping the 6.9 MB of data.
+    -- enough to tell whether a user's directory holds the same particles -- and, since round 5, the particles themselves
+    (pst_templates.npz: data, not source), so that the GPU box searches with the reference's templates.
     Read here with Pillow (an independent reader: the product's own TIFF parser is checked against it)."""
     import hashlib
     from PIL import Image
     d = os.path.join(REF, "PFO", "fps_uniform_sphere")
     names, shapes, heads, sums, sqs, shas = [], [], [], [], [], []
+    arrays = {}
     for size in (10240, 3072, 1024):
         for num in range(20):
             a = np.ascontiguousarray(np.array(Image.open(os.path.join(d, f"pst_{size}_{num}.tiff")), dtype=np.float32))
+            arrays[f"pst_{size}_{num}"] = a
             names.append(f"pst_{size}_{num}.tiff"); shapes.append(a.shape); heads.append(a[:4].copy())
             sums.append(float(a.astype(np.float64).sum())); sqs.append(float((a.astype(np.float64) ** 2).sum()))
             shas.append(hashlib.sha256(a.tobytes()).hexdigest())
     save("pst_fixture.npz", names=np.array(names), shapes=np.array(shapes), heads=np.stack(heads), sums=np.array(sums),
          sqs=np.array(sqs), sha256=np.array(shas))
+    # the particles themselves (round 5): 60 float32 arrays [P, 6], 6.9 MB of DATA the reference reads at start-up -- the GPU box
+    # has no /root/reference, and a tracker that searches with other particles does not retrace the reference's poses.
+    # model/pst.py::load_pst reads this archive wherever RO.PST_path does not name a directory of TIFFs.
+    np.savez_compressed(os.path.join(HERE, "pst_templates.npz"), **arrays)
+    print("wrote pst_templates.npz", os.path.getsize(os.path.join(HERE, "pst_templates.npz")), "bytes")
 
 
 def _reference_host_modules():

@@ -21,7 +21,7 @@ stats = hasattr(raw, "rfx_debug_mv_stats")
 for b, c in zip(frames[:3], rgb): mv.integrate(c, b["depth"], K, b["c2w"].numpy(), None)
 torch.cuda.synchronize()
 if stats:
-    buf = (C.c_ulonglong * 8)(); raw.rfx_debug_mv_stats(buf, 1)
+    buf = (C.c_ulonglong * 16)(); raw.rfx_debug_mv_stats(buf, 1)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(frames) + 1)]
 ev[0].record()
 for i, (b, c) in enumerate(zip(frames, rgb)):
@@ -32,5 +32,6 @@ print("%s lib=%s integrate call us: mean %.1f min %.1f max %.1f" % (name, os.pat
 if stats:
     raw.rfx_debug_mv_stats(buf, 0)
     n = len(frames)
-    names = ["waves", "waves_with_work", "chunk_items", "lanes_in_zrange", "lanes_in_image", "lanes_updated", "lanes_band", "risky_chunk_items"]
+    names = ["waves", "waves_with_work", "chunk_items", "lanes_in_zrange", "lanes_in_image", "lanes_updated", "lanes_band", "risky_chunk_items",
+             "items_untouched", "lanes_in_untouched_items", "items_with_store", "items_with_near", "-", "-", "-", "-"]
     print("per frame:", {k: int(v) // n for k, v in zip(names, buf)})
