@@ -36,7 +36,10 @@
 #define MV_ROWS_THREADS 1024     // mv_rows_kernel block: one queue atomic per block that has work
 #endif
 #ifndef MV_XCD_DEAL
-#define MV_XCD_DEAL 1  // mv_chunks_kernel: XCD k sweeps the k-th eighth of the queue (see the kernel)
+#define MV_XCD_DEAL 1  // mv_chunks_kernel: segments of the queue dealt to the XCDs (see the kernel)
+#endif
+#ifndef MV_XCD_SEGS
+#define MV_XCD_SEGS 32 // segments per XCD (rounded to a power-of-two segment length); 8 / 32 measured: 40.0 / 38.9 us
 #endif
 #ifndef MV_DBG_SKIP
 #define MV_DBG_SKIP 0
@@ -784,7 +787,11 @@ __device__ __forceinline__ void near_round(const MvParams& P, bool act, int64_t 
         const float4 dl = make_float4(cxv + 2.0f, 0.5f, czv, 0.f);
         const float oc = cyv;
 #else
+#if MV_DBG_SKIP & 256
+        const float4 dl = nimg[(P.dimg_colmajor ? px * P.H + py : py * P.W + px) & 0x1fff];
+#else
         const float4 dl = nimg[P.dimg_colmajor ? px * P.H + py : py * P.W + px];
+#endif
         const float oc = color[idx];
 #endif
         update_voxel(P, idx, cxv, cyv, czv, dl.x, dl.y, cur, wold, oc, dl.z, tsdf, weight, color);
@@ -856,8 +863,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mv_rsrc(const void* base, unsi
 // into the row (no descriptor to build per item), the weight store is the only operation under a lane mask, the
 // classification gather is a buffer load through ONE loop-invariant descriptor whose range check drops the lanes that
 // have no pixel, and the items are not fetched ahead (sixteen more live scalar registers spilled into vector lanes).
+// `n` items in the caller's LOCAL numbering; local item j is queue[deal.global(j)] (see mv_chunks_kernel)
+struct MvDeal {
+    unsigned shift, part, parts;         // segments of 2^shift items, segment s of the queue belongs to part s % parts
+    __device__ __forceinline__ unsigned global(unsigned j) const { return (((j >> shift) * parts + part) << shift) | (j & ((1u << shift) - 1u)); }
+};
 template <int U>
-__device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned begin, unsigned n, const MvItem* __restrict__ queue,
+__device__ __forceinline__ void mv_chunks_fast(const MvParams& P, MvDeal deal, unsigned n, const MvItem* __restrict__ queue,
                                                const float4* __restrict__ nimg, const float2* __restrict__ fg,
                                                float* __restrict__ tsdf,
                                                float* __restrict__ weight, float* __restrict__ color, unsigned wave,
@@ -875,13 +887,13 @@ __device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned begin
     //      2k + 1 hold the two 16-byte halves of the batch's k-th item, the next batch is in flight while this one is
     //      worked on -- and a trip takes its items out with v_readlane: no memory access between two trips.
     constexpr unsigned TRIPS = 32u / (unsigned)U;                              // trips per batch: 32 items in 64 lanes
-    const unsigned first = begin + wave * (unsigned)U, stride = n_waves * (unsigned)U;
+    const unsigned first = wave * (unsigned)U, stride = n_waves * (unsigned)U;
     const unsigned n_trips = first < n ? (n - first + stride - 1u) / stride : 0u;
     const unsigned last_item = n ? n - 1u : 0u;
     auto fetch = [&](unsigned trip0) -> uint4 {      // items of trips [trip0, trip0 + TRIPS): item k of the batch -> lanes 2k, 2k + 1
         const unsigned k = (unsigned)lane >> 1;
         const unsigned idx = min(first + (trip0 + k / (unsigned)U) * stride + k % (unsigned)U, last_item);
-        return reinterpret_cast<const uint4*>(queue)[(size_t)idx * 2u + ((unsigned)lane & 1u)];
+        return reinterpret_cast<const uint4*>(queue)[(size_t)deal.global(idx) * 2u + ((unsigned)lane & 1u)];
     };
     uint4 batch = make_uint4(0u, 0u, 0u, 0u), batch_next = batch;
     if (n_trips) batch = fetch(0u);
@@ -958,7 +970,11 @@ __device__ __forceinline__ void mv_chunks_fast(const MvParams& P, unsigned begin
             const bool in_img = (fabsf(ur - hw) <= hw) & (fabsf(vr - hh) <= hh);
             exact[u] = inside[u] & (czv[u] > 0.0f) & !approx_ok;
             const bool gather = inside[u] & approx_ok & in_img;
+#if MV_DBG_SKIP & 256      // timing builds: every gather inside one 128 KB window of the image (no image traffic beyond the L2)
+            const unsigned goff = gather ? ((unsigned)madd(ur, sx8, vr * sy8) & 0x1fff8u) : MV_OOB;
+#else
             const unsigned goff = gather ? (unsigned)madd(ur, sx8, vr * sy8) : MV_OOB;
+#endif
             const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(r_fg, goff, 0, 0);
             const unsigned g2x = g2[0], g2y = g2[1];        // (bit_cast of a vector element reads element 0 twice: clang 22)
             fgv[u] = make_float2(__uint_as_float(g2x), __uint_as_float(g2y));
@@ -1095,23 +1111,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void mv_c
     L.n = 0;
     if (blockIdx.x < blocks_main) {
         const unsigned n = min(q_counts[0], q_cap);
+        if (FAST) {
 #if MV_XCD_DEAL
-        // XCD-contiguous dealing.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8; an affinity for speed, never for
-        // correctness) and every XCD has an L2 of its own: with the items dealt cyclically over the whole grid each L2 sees
-        // rows from all over the frustum, pulls in its own copy of the whole {F, G} / depth / colour images and shares the
-        // lines between neighbouring chunks of a row with another XCD.  Here XCD k sweeps the k-th eighth of the queue (rows
-        // in (x, y) order: a slab of the footprint), its waves side by side: an eighth of the images per L2, neighbours together.
-        const unsigned segs = min(8u, blocks_main);                                      // a grid of fewer than 8 blocks: as many parts
-        const unsigned xcd = blockIdx.x % segs, nb = (blocks_main - xcd + segs - 1u) / segs;     // main blocks of this part (>= 1)
-        const unsigned per = ((n + segs - 1u) / segs + (unsigned)U - 1u) / (unsigned)U * (unsigned)U;    // items per part, a multiple of U
-        const unsigned begin = min(n, xcd * per), end = min(n, begin + per);
-        const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x / segs) * 4u + (unsigned)wv), n_waves = nb * 4u;
+            // XCD-aware dealing.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8; an affinity for speed, never for
+            // correctness) and every XCD has an L2 of its own: with the items dealt cyclically over the whole grid each L2
+            // sees rows from all over the frustum, pulls in its own copy of the whole {F, G} / depth / colour images and
+            // shares the lines between neighbouring chunks of a row with another XCD (measured: 12 % of the kernel's
+            // fetches).  The queue (rows in (x, y) order) is cut into segments of 2^shift items, ~MV_XCD_SEGS per XCD, and
+            // segment s goes to the blocks with blockIdx % 8 == s % 8, whose waves sweep their segments side by side:
+            // a strip of the footprint per L2 at any time, and the strips of one XCD spread over the frustum so that each
+            // XCD gets its share of the surface-crossing rows (one contiguous eighth each left the XCDs 21-33 us apart).
+            const unsigned parts = min(8u, blocks_main);                                   // a grid of fewer than 8 blocks: as many parts
+            const unsigned part = blockIdx.x % parts, nb = (blocks_main - part + parts - 1u) / parts;      // main blocks of this part (>= 1)
+            const unsigned want = max(64u, n / (parts * (unsigned)MV_XCD_SEGS));
+            MvDeal deal; deal.shift = 31u - (unsigned)__builtin_clz(want); deal.part = part; deal.parts = parts;
+            const unsigned full = n >> deal.shift, rem = n & ((1u << deal.shift) - 1u);
+            const unsigned my_full = full > part ? (full - part + parts - 1u) / parts : 0u;
+            const unsigned n_local = (my_full << deal.shift) + (full % parts == part ? rem : 0u);
+            const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x / parts) * 4u + (unsigned)wv), n_waves = nb * 4u;
 #else
-        const unsigned begin = 0u, end = n;
-        const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (unsigned)wv), n_waves = blocks_main * 4u;
+            MvDeal deal; deal.shift = 31u; deal.part = 0u; deal.parts = 1u;
+            const unsigned n_local = n;
+            const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (unsigned)wv), n_waves = blocks_main * 4u;
 #endif
-        if (FAST) mv_chunks_fast<U>(P, begin, end, queue, nimg, fg, tsdf, weight, color, wave, n_waves, L);
-        else mv_chunks_generic<U, false, REINT>(P, begin, end, queue, nimg, tsdf, weight, color, wave, n_waves, L, slab_skip);
+            mv_chunks_fast<U>(P, deal, n_local, queue, nimg, fg, tsdf, weight, color, wave, n_waves, L);
+        } else {
+            const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (unsigned)wv), n_waves = blocks_main * 4u;
+            mv_chunks_generic<U, false, REINT>(P, 0u, n, queue, nimg, tsdf, weight, color, wave, n_waves, L, slab_skip);
+        }
     } else {
         const unsigned n = min(q_counts[1], q_cap_risky);
         const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x - blocks_main) * 4u + (unsigned)wv);
