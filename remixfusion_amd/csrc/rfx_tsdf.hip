@@ -8,10 +8,12 @@
 //                      classification image of the fast path (8 B/pixel each, L2-resident) and coarse max-depth tiles.
 //   mv_rows_kernel   : one thread per (x,y) voxel row of the frustum's footprint.  Each row is a line in camera
 //                      space, so frustum /\ row is one z-interval; its 64-voxel chunks go to a work queue.
-//   mv_chunks_kernel : resident waves pull chunks off the queue, lanes along z (the contiguous axis): every volume
-//                      access is a coalesced 256-B run.  Free-space voxels (85 % of a frame's updates) are classified
-//                      by two compares against the {F, G} image and only move their weight; the truncation band is
-//                      compacted through LDS and evaluated by the reference's full expression tree.
+//   mv_chunks_kernel : resident waves take chunks off the queue (segments of it dealt to the XCDs, a wave's items gathered
+//                      into registers 32 at a time), lanes along z (the contiguous axis): every volume access is a
+//                      coalesced 256-B run.  Free-space voxels (85 % of a frame's updates) are classified by two compares
+//                      against the {F, G} image and only move their weight; the truncation band is compacted through LDS
+//                      and evaluated after the item loop, the block's records dealt over its waves in rounds of 64, by the
+//                      reference's full expression tree.
 // mv_integrate_kernel (one wave per tile of rows, round 1) remains as the fallback for volumes whose every voxel decodes
 // literally (dy*dz >= 2^24).
 // Per-voxel arithmetic is evaluated exactly as the reference kernel text does (same operation
@@ -37,6 +39,11 @@
 #endif
 #ifndef MV_XCD_DEAL
 #define MV_XCD_DEAL 1  // mv_chunks_kernel: segments of the queue dealt to the XCDs (see the kernel)
+#endif
+#ifndef MV_FAR_WALK
+#define MV_FAR_WALK 0  // mv_rows_kernel: far end of a row refined by a walk through the max-depth tiles.  Measured (round 5):
+                       // 159 k -> 137 k items, 7.26 M -> 6.11 M in-interval lanes, mv_chunks 38.3 -> 37.0 us, mv_rows 14.5 -> 22.6 us
+                       // (a divergent per-thread loop): off
 #endif
 #ifndef MV_XCD_SEGS
 #define MV_XCD_SEGS 32 // segments per XCD (rounded to a power-of-two segment length); 8 / 32 measured: 40.0 / 38.9 us
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
     // max-depth pyramid over the coarse tiles: level 0 = the tiles, level l+1 = 2x2 maxima of level l.  A row's
     // projection is a straight segment; its bounding box is looked up at the level where it spans at most 2x2 cells.
     __shared__ float pyr[MV_ROWS_LDS_TILES + MV_PYR_FLOATS];
+    __shared__ float dil[MV_ROWS_LDS_TILES];      // max depth over the 3x3 tiles around a tile (the far-end walk below)
     __shared__ int lvl_off[16], lvl_w[16], lvl_h[16];
     const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     const int n_tiles = tw * th;
@@ -540,6 +548,13 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             lvl_off[15] = l + 1;
         }
         __syncthreads();
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+            const int y = i / tw, x = i - y * tw;
+            float m = 0.0f;
+            for (int yy = max(y - 1, 0); yy <= min(y + 1, th - 1); ++yy)
+                for (int xx = max(x - 1, 0); xx <= min(x + 1, tw - 1); ++xx) m = fmaxf(m, pyr[yy * tw + xx]);
+            dil[i] = m;
+        }
         n_lvl = lvl_off[15];
         for (int l = 1; l < n_lvl; ++l) {
             const int w = lvl_w[l], h = lvl_h[l], pw = lvl_w[l - 1], ph = lvl_h[l - 1];
@@ -623,6 +638,57 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             if (tm > 0.0f) {
                 // cam_z <= (deepest pixel + trunc) / (1 - ratio_eps), on the far side
                 clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz, eps_z);
+#if MV_FAR_WALK
+                // Round 5: the box of the whole projection holds the far wall even where this row ends in the floor, so the
+                // clip above left 2.4 M of 7.3 M in-interval lanes per frame behind a surface.  Walk the projection (a
+                // straight, monotonic segment) from its FAR end through the 16 x 16-pixel tiles: the part of the row inside
+                // one tile sees at most the deepest pixel of the 3 x 3 tiles around it (`dil`: the rounding of a pixel and
+                // the approximate edge crossings stay far inside that margin); if even the nearest voxel of that part lies
+                // deeper, the part is untouched and the walk goes on, else the same clip with this tile's depth ends it.
+                if (in_lds && !empty && lo <= hi && Bz != 0.0f) {
+                    const bool inc = Bz > 0.0f;                    // cam_z grows with z: the far end is `hi`
+                    float zf = inc ? hi : lo;
+                    const float zn = inc ? lo : hi;
+                    const float du = (Bx * Az - Ax * Bz) * fx * (inc ? -1.0f : 1.0f);     // sign of du along the walk (far -> near)
+                    const float dv = (By * Az - Ay * Bz) * fy * (inc ? -1.0f : 1.0f);
+                    const float kb = 1.0001f / (1.0f - P.ratio_eps);
+                    for (int step = 0; step < 12; ++step) {
+                        const float czf = Az + zf * Bz;
+                        if (!(czf > 1e-6f)) break;
+                        const float r = __builtin_amdgcn_rcpf(czf);
+                        const float u = fx * (Ax + zf * Bx) * r + cx, v = fy * (Ay + zf * By) * r + cy;
+                        const int tu = min(max((int)floorf(u * (1.0f / MV_TD)), 0), tw - 1), tv = min(max((int)floorf(v * (1.0f / MV_TD)), 0), th - 1);
+                        const float D = dil[tv * tw + tu];
+                        // z where the segment leaves this tile towards the near end: u(z) = e  <=>  z = (e' Az - fx Ax) / (fx Bx - e' Bz), e' = e - cx
+                        float z_exit = zn;
+                        {
+                            const float e = (float)((du > 0.0f ? tu + 1 : tu) * MV_TD) - cx, den = fx * Bx - e * Bz;
+                            if (du != 0.0f && fabsf(den) > 1e-12f) {
+                                const float ze = (e * Az - fx * Ax) * __builtin_amdgcn_rcpf(den);
+                                if (inc ? (ze < zf && ze > z_exit) : (ze > zf && ze < z_exit)) z_exit = ze;
+                            }
+                        }
+                        {
+                            const float e = (float)((dv > 0.0f ? tv + 1 : tv) * MV_TD) - cy, den = fy * By - e * Bz;
+                            if (dv != 0.0f && fabsf(den) > 1e-12f) {
+                                const float ze = (e * Az - fy * Ay) * __builtin_amdgcn_rcpf(den);
+                                if (inc ? (ze < zf && ze > z_exit) : (ze > zf && ze < z_exit)) z_exit = ze;
+                            }
+                        }
+                        if (fabsf(z_exit - zf) < 0.5f) z_exit = inc ? fmaxf(zn, zf - 0.5f) : fminf(zn, zf + 0.5f);     // always move on
+                        const float bound = D > 0.0f ? (D + P.trunc) * kb + 1e-3f + eps_z : -1.0f;    // cam_z beyond it: untouched
+                        if (Az + z_exit * Bz > bound) {              // the nearest voxel of this part is beyond: all of it is
+                            zf = z_exit;
+                            if (zf == zn) { empty = true; break; }
+                        } else {
+                            const float zb = (bound - Az) * __builtin_amdgcn_rcpf(Bz);
+                            zf = inc ? fminf(zf, zb) : fmaxf(zf, zb);
+                            break;
+                        }
+                    }
+                    if (inc) hi = zf; else lo = zf;
+                }
+#endif
                 if (!empty && lo <= hi) {
                     z0 = max(0, (int)floorf(lo) - 1);
                     z1 = min(P.dz, (int)ceilf(hi) + 2);
@@ -858,11 +924,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mv_rsrc(const void* base, unsi
 }
 
 // ---- fast body (obs_weight > 0, no re-integration, exactly decoded rows)
-// Instruction budget (the kernel is bound by instruction issue, scalar and vector alike, not by memory: with every memory
-// operation removed it ran in 20 of 43 us): the volume reads are plain loads from a scalar base with a lane offset clamped
-// into the row (no descriptor to build per item), the weight store is the only operation under a lane mask, the
-// classification gather is a buffer load through ONE loop-invariant descriptor whose range check drops the lanes that
-// have no pixel, and the items are not fetched ahead (sixteen more live scalar registers spilled into vector lanes).
+// What bounds it, as measured in round 5 (profiles/r5_notes.md; timing builds -DMV_DBG_SKIP / -DMV_DBG_NEAR remove one stream at a
+// time, -DMV_BLOCKS_PER_CU the occupancy, tools/v1_wave_times.py gives the waves' lifetimes):
+//   * 19 us with no volume access and no exact path: vector-instruction issue (62 VALU + 50 SALU per item; the classification
+//     gather itself costs < 1 us, whatever its addresses);
+//   * + 4.0 / 3.4 / 4.5 us for the tsdf load / weight load / weight store, + ~10 us for the exact path (3.7 us of it arithmetic,
+//     the rest its gathers and its three scattered stores);
+//   * by occupancy T = 31 us + 60 us / (waves per SIMD): at 8 waves 7.5 us of exposed latency on a 31 us throughput floor.
+//   The fabric is NOT the bound although FETCH_SIZE x 2 (calibrated on this access shape: the L2 fetches whole 128-byte lines,
+//   the counter tallies them at 64) reads 170 MB for 85 MB of algorithmic work: with every image gather confined to an
+//   L2-resident window the counter drops by 80 MB and the kernel by 2 us -- the surplus is 8 L2s each pulling its own copy of
+//   the images out of the Infinity Cache.  Software pipelining (the loads of trip t + 1 issued before trip t is classified)
+//   was built: 74 registers, 6 waves per SIMD, 43.7 us against 38.3.
+// Structure: the volume reads are plain loads from a scalar base with a lane offset clamped into the row (no descriptor to
+// build per item), the weight store is the only operation under a lane mask, the classification gather is a buffer load
+// through ONE loop-invariant descriptor whose range check drops the lanes that have no pixel.
 // `n` items in the caller's LOCAL numbering; local item j is queue[deal.global(j)] (see mv_chunks_kernel)
 struct MvDeal {
     unsigned shift, part, parts;         // segments of 2^shift items, segment s of the queue belongs to part s % parts
@@ -1613,6 +1689,9 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
             RFX_HIP_TRY(hipGetDevice(&dev));
             RFX_HIP_TRY(hipGetDeviceProperties(&prop, dev));
             RFX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
+#ifdef MV_BLOCKS_PER_CU      // timing builds: the sensitivity of the kernel to its occupancy
+            per_cu = std::min(per_cu, MV_BLOCKS_PER_CU);
+#endif
             resident[variant] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
         }
         int blocks_risky_q = 0, blocks_main_q = 0;
