@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 7
+#define RFX_ABI_VERSION 8
 
 typedef void* rfx_stream;
 
@@ -466,18 +466,21 @@ int rfx_track_normal(const float* vertex4, float* normal3, int H, int W, rfx_str
  * n_candidates pose perturbations q6 dev [n,6] (translation, quaternion vector part; scaled by
  * search_size[6], host) around the pose (R[9] row-major, T[3], host): sum over the sub-sampled pixels
  * (stride `level`, offset `level_index`) of |tsdf(nearest voxel of the transformed vertex) - target|
- * into value dev [n], hit count into count dev [n] (both overwritten). */
+ * into value_q30 dev [n], hit count into count dev [n] (both int64, both overwritten).
+ * ABI 8: the sum is kept in FIXED POINT -- every term (<= 2) truncated to a multiple of 2^-30 and added as an integer -- so
+ * that it does not depend on the order of the additions (the reference adds its pixels with float atomics in whatever order
+ * they arrive: model/ROtracker.py:262-266): value = (float)((double)value_q30 * 2^-30). */
 int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float origin[3], float voxel,
                        const float* vertex4, const float* normal3, const float R[9], const float T[3],
                        const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
-                       int level, int level_index, float* value, float* count, rfx_stream stream);
+                       int level, int level_index, int64_t* value_q30, int64_t* count, rfx_stream stream);
 
-/* T3 on one x-slab [x0, x1) of the volume (tsdf holds the slab's planes): value / count receive the terms of the pixels
- * whose nearest voxel lies in the slab; summed over the slabs they are rfx_track_evaluate's (up to the order of the sums). */
+/* T3 on one x-slab [x0, x1) of the volume (tsdf holds the slab's planes): value_q30 / count receive the terms of the pixels
+ * whose nearest voxel lies in the slab; added over the slabs (integers: exactly) they ARE rfx_track_evaluate's. */
 int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, int x1, const float origin[3], float voxel,
                             const float* vertex4, const float* normal3, const float R[9], const float T[3],
                             const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
-                            int level, int level_index, float* value, float* count, rfx_stream stream);
+                            int level, int level_index, int64_t* value_q30, int64_t* count, rfx_stream stream);
 
 /* ---- the whole pose search of one frame on the device (round 4) ------------------------------------------------------
  * `random_optimization` (model/ROtracker.py:713-831) drives T3 from the host: 20 x (launch, copy 2 x P floats back, pick the
@@ -504,11 +507,11 @@ typedef struct rfx_track_search {
     float K[9]; int32_t H, W;
     int32_t count_search, fix_level_index, iterative_scale, reserved;
     double scaling_coefficient, beta;            /* RO.scaling_coefficient; the smoothing of the box (0.9 in the reference) */
-    float* state; float* value; float* count;
+    float* state; int64_t* value_q30; int64_t* count;     /* sums as in rfx_track_evaluate: [max template rows] each */
 } rfx_track_search;
-/* begin: state <- (R, T, search_size), flags cleared, level_index 5, value/count zeroed.  evaluate: T3 of the current state
- * (adds this volume's -- or slab's -- sums into value/count).  update: cal_transform + bookkeeping of iteration `iteration`,
- * then zeroes value/count.  Between evaluate and update a rank of a sharded volume adds value/count over the ranks.
+/* begin: state <- (R, T, search_size), flags cleared, level_index 5, value_q30/count zeroed.  evaluate: T3 of the current state
+ * (adds this volume's -- or slab's -- sums into value_q30/count).  update: cal_transform + bookkeeping of iteration `iteration`,
+ * then zeroes them.  Between evaluate and update a rank of a sharded volume adds value_q30/count over the ranks (int64: exact).
  * run = begin + iterations x (evaluate, update). */
 size_t rfx_track_search_bytes(void);           /* sizeof(rfx_track_search), for bindings to check their mirror */
 int rfx_track_search_begin(const rfx_track_search* s, const float R[9], const float T[3], const float search_size[6], rfx_stream stream);

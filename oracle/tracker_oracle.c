@@ -81,14 +81,15 @@ void orc_tr_normal(const float* v, float* n3, int H, int W) {
 void orc_tr_evaluate(const float* tsdf, int dx, int dy, int dz, const float* origin, float voxel,
                      const float* vertex4, const float* normal3, const float* R, const float* T,
                      const float* q6, const float* ss, int P, const float* K, int H, int W, int level, int level_index,
-                     float* value, float* count) {
+                     float* value, float* count, long long* value_q30) {
     int ox = (int)origin[0], oy = (int)origin[1], oz = (int)origin[2];      /* (int) other_params[3..5] */
     int gh = H / level, gw = W / level;                                       /* grid dims (int(self.im_h/level)) */
     int im_h = gh * level, im_w = gw * level;
     for (int node = 0; node < P; ++node) {
-        double acc = 0.0; float cnt = 0.f;
-        float accf = 0.f;
-        (void)acc;
+        float cnt = 0.f;
+        float accf = 0.f;          /* the float running sum in pixel order (one of the orders the reference's atomics may take) */
+        long long accq = 0;        /* the same terms, each truncated to a multiple of 2^-30, as an integer: what the product
+                                      (ABI 8) defines as THE sum, because it does not depend on the order (value_q30 may be NULL) */
         for (int i = 0; i < gh; ++i) for (int j = 0; j < gw; ++j) {
             int pi = i * level + level_index, pj = j * level + level_index;
             if (pi > im_h - 1 || pj > im_w - 1 || pi < 0 || pj < 0) continue;
@@ -125,9 +126,11 @@ void orc_tr_evaluate(const float* tsdf, int dx, int dy, int dz, const float* ori
                 if (vxi < 1 || vxi >= dx - 1 || vyi < 1 || vyi >= dy - 1 || vzi < 1 || vzi >= dz - 1) continue;
                 int64_t idx = (int64_t)vzi + (int64_t)vyi * dz + (int64_t)vxi * dy * dz;
                 accf += fabsf(tsdf[idx] - gt);
+                accq += (long long)(unsigned)(fabsf(tsdf[idx] - gt) * 1073741824.0f);
                 cnt += 1.0f;
             }
         }
         value[node] = accf; count[node] = cnt;
+        if (value_q30) value_q30[node] = accq;
     }
 }

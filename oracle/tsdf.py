@@ -51,7 +51,7 @@ class TsdfOracle:
         L.orc_tr_vertex.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F, _F]
         L.orc_tr_normal.argtypes = [_F, _F, C.c_int, C.c_int]
         L.orc_tr_evaluate.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F, C.c_float, _F, _F, _F, _F, _F, _F, C.c_int, _F,
-                                      C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]
+                                      C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
         L.orc_fma_mode.restype = C.c_int
         assert L.orc_fma_mode() == int(fma)
 
@@ -141,14 +141,15 @@ class TsdfOracle:
         return out
 
     def tr_evaluate(self, tsdf, dims, origin, voxel, vertex4, normal3, R, T, q6, ss, K, H, W, level, level_index):
+        """(float32 running sums in pixel order, hit counts, the sums in 2^-30 fixed point: order-independent)"""
         P = q6.shape[0]
-        val, cnt = np.zeros(P, np.float32), np.zeros(P, np.float32)
+        val, cnt, q30 = np.zeros(P, np.float32), np.zeros(P, np.float32), np.zeros(P, np.int64)
         self.lib.orc_tr_evaluate(tsdf, int(dims[0]), int(dims[1]), int(dims[2]), np.ascontiguousarray(origin, np.float32),
                                  float(voxel), np.ascontiguousarray(vertex4, np.float32), np.ascontiguousarray(normal3, np.float32),
                                  np.ascontiguousarray(R, np.float32).reshape(-1), np.ascontiguousarray(T, np.float32),
                                  np.ascontiguousarray(q6, np.float32), np.ascontiguousarray(ss, np.float32), P,
-                                 np.ascontiguousarray(K, np.float32).reshape(-1), H, W, int(level), int(level_index), val, cnt)
-        return val, cnt
+                                 np.ascontiguousarray(K, np.float32).reshape(-1), H, W, int(level), int(level_index), val, cnt, q30)
+        return val, cnt, q30
 
     # -- GBV ---------------------------------------------------------------------------------
     def gbv_integrate(self, trgb, w, res, box, K, c2w, rgb01, depth, trunc, obs_weight=1.0,

@@ -82,7 +82,7 @@ class TrackSearch(C.Structure):
                 ("n_eval", C.c_int32 * RFX_TRACK_STEPS), ("level", C.c_int32 * RFX_TRACK_STEPS), ("K", C.c_float * 9),
                 ("H", C.c_int32), ("W", C.c_int32), ("count_search", C.c_int32), ("fix_level_index", C.c_int32),
                 ("iterative_scale", C.c_int32), ("reserved", C.c_int32), ("scaling_coefficient", C.c_double), ("beta", C.c_double),
-                ("state", C.c_void_p), ("value", C.c_void_p), ("count", C.c_void_p)]
+                ("state", C.c_void_p), ("value_q30", C.c_void_p), ("count", C.c_void_p)]
 
 
 class RbaParams(C.Structure):
@@ -217,7 +217,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 7:
+    if lib.rfx_abi_version() != 8:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

@@ -1608,9 +1608,19 @@ __global__ __launch_bounds__(256) void demb_rows_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- host side
+// the lookups address an entry of a level as (level base, 32-bit byte offset) -- at32() in rfx_field_device.h: a level of
+// 4 GiB or more would wrap silently, so the entry points refuse it
+static bool grid_levels_addressable(const rfx_grid_desc& g) {
+    for (int l = 0; l < g.n_levels && l < RFX_MAX_LEVELS; ++l)
+        if ((uint64_t)g.size[l] * (uint64_t)g.n_feat * sizeof(float) >= (1ull << 32)) return false;
+    return true;
+}
+
 int make_fieldk(const rfx_field_desc* d, FieldK* k) {
     if (!d || !d->hash_table || !d->gbv || !d->w1 || !d->w2 || !d->w3 || !d->w4) return RFX_ERR_ARG;
     if (d->hash.n_levels != 16 || d->hash.n_feat != 2) return RFX_ERR_UNSUPPORTED;   // decoder input is 32+48+1
+    if (!grid_levels_addressable(d->hash)) return RFX_ERR_UNSUPPORTED;
+    if ((uint64_t)d->gbv_res * d->gbv_res * d->gbv_res * 16ull >= (1ull << 32)) return RFX_ERR_UNSUPPORTED;   // float4 entries, 32-bit byte offsets
     if (d->gbv_res <= 1 || !(d->trunc > 0.f)) return RFX_ERR_ARG;
     k->hash = d->hash;
     k->table = d->hash_table;
@@ -1666,6 +1676,7 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
     if (!g || !table || !x01 || !feat || n < 0) return RFX_ERR_ARG;
     if (g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_ARG;
     if (g->n_feat != 1 && g->n_feat != 2 && g->n_feat != 4) return RFX_ERR_UNSUPPORTED;
+    if (!grid_levels_addressable(*g)) return RFX_ERR_UNSUPPORTED;
     if (n == 0) return RFX_OK;
     if (g->n_feat == 2 && (n << 4) < (int64_t)0x7fffffff * 256) {
         const int sh = lp_shift_of(g->n_levels);
@@ -1699,6 +1710,7 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
     if (n == 0) return RFX_OK;
     if (!g || !table || !x01 || !dfeat || n < 0) return RFX_ERR_ARG;
     if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
+    if (!grid_levels_addressable(*g)) return RFX_ERR_UNSUPPORTED;
     if (n == 0 || (!dtable && !dx01)) return RFX_OK;
     if (dtable) {
         if (workspace && (workspace_bytes < rfx_grid_encode_backward_workspace_bytes(n, g->n_levels) || ((uintptr_t)workspace & 7)))
@@ -1873,6 +1885,7 @@ int rfx_grid_encode_backward_merged(const rfx_grid_desc* g, const float* table, 
     if (n_a + n_b == 0) return RFX_OK;
     if (!g || !table || !dtable || (n_a > 0 && (!x01_a || !dfeat_a)) || (n_b > 0 && (!x01_b || !dfeat_b))) return RFX_ERR_ARG;
     if (g->n_feat != 2 || g->n_levels < 1 || g->n_levels > RFX_MAX_LEVELS) return RFX_ERR_UNSUPPORTED;
+    if (!grid_levels_addressable(*g)) return RFX_ERR_UNSUPPORTED;
     if (workspace && (workspace_bytes < rfx_grid_encode_backward_workspace_bytes(n_a + n_b, g->n_levels) || ((uintptr_t)workspace & 7)))
         return RFX_ERR_WORKSPACE;
     if (n_a == 0) {           // the first source carries the selection in the fused callers: keep it the non-empty one

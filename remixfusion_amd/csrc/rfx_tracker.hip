@@ -6,6 +6,13 @@
 // thread owns a candidate pose and walks a slab of the sub-sampled pixels, accumulating in registers:
 // the vertex / normal of a pixel is wave-uniform (scalar loads), only the nearest-voxel TSDF lookup
 // is a per-lane gather, and the slabs of one candidate are combined with a handful of atomics.
+//
+// Round 5: the sums are ORDER-INDEPENDENT.  Every term |tsdf - target| (<= 2) is converted to 30-bit fixed point
+// (truncation: (uint32)(term * 2^30)) and added as a 64-bit integer -- in the thread, between the pixel slabs of a candidate
+// (integer atomics), between the x-slabs of a volume spread over several GPUs (an int64 all-reduce) -- so the sum is the same
+// number whatever the grouping, and sharded == single GPU bit for bit; the hit counts are integers too.  (Up to round 4 the
+// slabs were combined with float atomics, like the reference combines its pixels: a 20-iteration search amplifies the last
+// bit of such a sum into centimetres between two runs.)  value = acc * 2^-30, rounded to float32 once, where it is used.
 #include "rfx_common.h"
 #include <algorithm>
 
@@ -75,7 +82,8 @@ struct EvalK {
 // one (candidate, pixel-slab) pair's share of compute_tsdf_value: thread = candidate `node`, walks pixel slab `slab`
 __device__ __forceinline__ void evaluate_share(const EvalK& E, int node, int slab, const float* __restrict__ tsdf,
                                                const float4* __restrict__ vertex, const float* __restrict__ n3,
-                                               const float* __restrict__ q6, float* __restrict__ value, float* __restrict__ count) {
+                                               const float* __restrict__ q6, unsigned long long* __restrict__ value,
+                                               unsigned long long* __restrict__ count) {
     const bool live = node < E.P;
     float tx = 0.f, ty = 0.f, tz = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
     if (live) {
@@ -87,7 +95,8 @@ __device__ __forceinline__ void evaluate_share(const EvalK& E, int node, int sla
     const int per = (n_pix + E.n_slabs - 1) / E.n_slabs;
     const int p0 = slab * per, p1 = min(n_pix, p0 + per);
     const int im_h = E.gh * E.level, im_w = E.gw * E.level;
-    float acc = 0.f, cnt = 0.f;
+    unsigned long long acc = 0ull;                        // sum of the terms in 2^-30 units (a term is <= 2: tsdf and target lie in [-1, 1])
+    unsigned cnt = 0u;
     for (int p = p0; p < p1; ++p) {                      // wave-uniform pixel walk
         const int i = p / E.gw, j = p - i * E.gw;
         const int pi = i * E.level + E.level_index, pj = j * E.level + E.level_index;
@@ -119,19 +128,19 @@ __device__ __forceinline__ void evaluate_share(const EvalK& E, int node, int sla
         if (vxi < 1 || vxi >= E.dx - 1 || vyi < 1 || vyi >= E.dy - 1 || vzi < 1 || vzi >= E.dz - 1) continue;
         if (vxi < E.x0 || vxi >= E.x1) continue;             // another slab's voxel: that rank adds this term
         const int64_t idx = (int64_t)vzi + (int64_t)vyi * E.dz + (int64_t)(vxi - E.x0) * E.dy * E.dz;
-        acc += fabsf(tsdf[idx] - v.w);
-        cnt += 1.0f;
+        acc += (unsigned long long)(unsigned)(fabsf(tsdf[idx] - v.w) * 1073741824.0f);      // v_cvt_u32_f32: truncates, saturates, NaN -> 0
+        cnt += 1u;
     }
-    if (live && cnt > 0.f) {
-        if (E.n_slabs == 1) { value[node] = acc; count[node] = cnt; }
-        else { atomicAdd(value + node, acc); atomicAdd(count + node, cnt); }
+    if (live && cnt > 0u) {
+        if (E.n_slabs == 1) { value[node] = acc; count[node] = (unsigned long long)cnt; }
+        else { atomicAdd(value + node, acc); atomicAdd(count + node, (unsigned long long)cnt); }
     }
 }
 
 __global__ __launch_bounds__(256) void track_evaluate_kernel(EvalK E, const float* __restrict__ tsdf,
                                                              const float4* __restrict__ vertex, const float* __restrict__ n3,
-                                                             const float* __restrict__ q6, float* __restrict__ value,
-                                                             float* __restrict__ count) {
+                                                             const float* __restrict__ q6, unsigned long long* __restrict__ value,
+                                                             unsigned long long* __restrict__ count) {
     evaluate_share(E, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, tsdf, vertex, n3, q6, value, count);
 }
 
@@ -157,21 +166,26 @@ struct SearchK {
     float voxel;
     int count_search, fix_level_index, iterative_scale, max_rows;
     double scale_d, beta_d;                                    // RO.scaling_coefficient, beta as the host's Python floats
-    float* state; float* value; float* count;
+    float* state; unsigned long long* value; unsigned long long* count;
 };
 
-__global__ __launch_bounds__(64) void track_search_begin_kernel(float* __restrict__ state, float* __restrict__ value,
-                                                                float* __restrict__ count, int max_rows, EvalK init) {
+// mean |tsdf - target| of a candidate from its fixed-point sum and hit count, in float32 like the host's numpy arrays:
+// value = acc * 2^-30 rounded once (exact in double: acc < 2^53), then value / (count + 1e-6)
+__device__ __forceinline__ float search_mean(const unsigned long long* __restrict__ value, const unsigned long long* __restrict__ count, int i) {
+    return (float)((double)value[i] * 9.313225746154785e-10) / ((float)count[i] + 1e-6f);
+}
+
+__global__ __launch_bounds__(64) void track_search_begin_kernel(float* __restrict__ state, unsigned long long* __restrict__ value,
+                                                                unsigned long long* __restrict__ count, int max_rows, EvalK init) {
     int* si = reinterpret_cast<int*>(state);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {
         if (t < 9) state[ST_R + t] = init.R[t];
         if (t < 3) state[ST_T + t] = init.T[t];
         if (t < 6) { state[ST_SS + t] = init.ss[t]; state[ST_PSS + t] = 0.f; }
-        if (t >= 24 && t < RFX_TRACK_STATE_WORDS) si[t] = 0;
-        if (t == 0) si[ST_LEVEL_INDEX] = 5;                        // reference :737 `level_index = 5`
+        if (t >= 24 && t < RFX_TRACK_STATE_WORDS) si[t] = (t == ST_LEVEL_INDEX) ? 5 : 0;     // one owner per word; reference :737 `level_index = 5`
     }
-    for (int i = t; i < max_rows; i += gridDim.x * blockDim.x) { value[i] = 0.f; count[i] = 0.f; }
+    for (int i = t; i < max_rows; i += gridDim.x * blockDim.x) { value[i] = 0ull; count[i] = 0ull; }
 }
 
 __global__ __launch_bounds__(256) void track_search_evaluate_kernel(SearchK S) {
@@ -205,14 +219,14 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
     const int n_all = S.rows[cp], P = S.n_eval[cp];
     const float* __restrict__ cand = S.templates[cp];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float origin = S.value[0] / (S.count[0] + 1e-6f);
+    const float origin = search_mean(S.value, S.count, 0);
     const int ipt = (n_all + 1023) / 1024;                         // <= 16 (checked on the host)
     const int i0 = t * ipt, i1 = min(n_all, i0 + ipt);
     if (t == 0) bad = 0;
     // ---- rank of every candidate that beats candidate 0, in index order
     int mine = 0;
     for (int i = max(i0, 1); i < i1; ++i) {
-        const float m = i < P ? S.value[i] / (S.count[i] + 1e-6f) : 0.f;     // rows past P are never evaluated: sums 0 (host: zeros)
+        const float m = i < P ? search_mean(S.value, S.count, i) : 0.f;     // rows past P are never evaluated: sums 0 (host: zeros)
         mine += m < origin ? 1 : 0;
     }
     int scan = mine;
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
     __syncthreads();
     int rank = wave_base[wave] + scan - mine;
     for (int i = max(i0, 1); i < i1 && rank < S.count_search; ++i) {
-        const float m = i < P ? S.value[i] / (S.count[i] + 1e-6f) : 0.f;
+        const float m = i < P ? search_mean(S.value, S.count, i) : 0.f;
         if (m < origin) { sel_idx[rank] = i; sel_fit[rank] = m; ++rank; }
     }
     __syncthreads();
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(1024) void track_search_update_kernel(SearchK S, in
     if (t < 9) { double a = 0.0; for (int k = 0; k < m_sel; ++k) a += col[t][k]; sums[t] = a; }   // in candidate order, like the reference's loop
     __syncthreads();
     // ---- zero the sums for the next evaluation
-    for (int i = t; i < S.max_rows; i += 1024) { S.value[i] = 0.f; S.count[i] = 0.f; }
+    for (int i = t; i < S.max_rows; i += 1024) { S.value[i] = 0ull; S.count[i] = 0ull; }
     if (t != 0) return;
     float* st = S.state;
     const bool success = m_sel > 0;
@@ -332,16 +346,19 @@ int rfx_track_normal(const float* vertex4, float* normal3, int H, int W, rfx_str
 int rfx_track_evaluate(const float* tsdf, int dx, int dy, int dz, const float origin[3], float voxel,
                        const float* vertex4, const float* normal3, const float R[9], const float T[3],
                        const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
-                       int level, int level_index, float* value, float* count, rfx_stream stream) {
+                       int level, int level_index, int64_t* value_q30, int64_t* count, rfx_stream stream) {
     return rfx_track_evaluate_slab(tsdf, dx, dy, dz, 0, dx, origin, voxel, vertex4, normal3, R, T, q6, search_size, n_candidates, K, H, W,
-                                   level, level_index, value, count, stream);
+                                   level, level_index, value_q30, count, stream);
 }
 
 int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, int x1, const float origin[3], float voxel,
                             const float* vertex4, const float* normal3, const float R[9], const float T[3],
                             const float* q6, const float search_size[6], int n_candidates, const float K[9], int H, int W,
-                            int level, int level_index, float* value, float* count, rfx_stream stream) {
-    if (!tsdf || !origin || !vertex4 || !normal3 || !R || !T || !q6 || !search_size || !K || !value || !count) return RFX_ERR_ARG;
+                            int level, int level_index, int64_t* value_q30, int64_t* count, rfx_stream stream) {
+    if (!tsdf || !origin || !vertex4 || !normal3 || !R || !T || !q6 || !search_size || !K || !value_q30 || !count) return RFX_ERR_ARG;
+    if (((uintptr_t)value_q30 | (uintptr_t)count) & 7) return RFX_ERR_ARG;
+    unsigned long long* value = reinterpret_cast<unsigned long long*>(value_q30);
+    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(count);
     if (dx <= 2 || dy <= 2 || dz <= 2 || n_candidates <= 0 || H <= 0 || W <= 0 || level <= 0 || !(voxel > 0.f)) return RFX_ERR_ARG;
     if (x0 < 0 || x1 > dx || x1 < x0) return RFX_ERR_ARG;
     EvalK E;
@@ -358,16 +375,17 @@ int rfx_track_evaluate_slab(const float* tsdf, int dx, int dy, int dz, int x0, i
     const int blocks_x = (n_candidates + 255) / 256;
     E.n_slabs = eval_slabs(blocks_x, n_pix);
     hipStream_t st = as_stream(stream);
-    RFX_HIP_TRY(hipMemsetAsync(value, 0, sizeof(float) * n_candidates, st));
-    RFX_HIP_TRY(hipMemsetAsync(count, 0, sizeof(float) * n_candidates, st));
+    RFX_HIP_TRY(hipMemsetAsync(value, 0, sizeof(unsigned long long) * n_candidates, st));
+    RFX_HIP_TRY(hipMemsetAsync(cnt64, 0, sizeof(unsigned long long) * n_candidates, st));
     hipLaunchKernelGGL(track_evaluate_kernel, dim3(blocks_x, E.n_slabs), dim3(256), 0, st, E, tsdf,
-                       reinterpret_cast<const float4*>(vertex4), normal3, q6, value, count);
+                       reinterpret_cast<const float4*>(vertex4), normal3, q6, value, cnt64);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
 
 static int search_kernel_args(const rfx_track_search* s, SearchK* S, int* eval_blocks) {
-    if (!s || !s->tsdf || !s->vertex4 || !s->normal3 || !s->state || !s->value || !s->count) return RFX_ERR_ARG;
+    if (!s || !s->tsdf || !s->vertex4 || !s->normal3 || !s->state || !s->value_q30 || !s->count) return RFX_ERR_ARG;
+    if (((uintptr_t)s->value_q30 | (uintptr_t)s->count) & 7) return RFX_ERR_ARG;
     if (s->dx <= 2 || s->dy <= 2 || s->dz <= 2 || s->H <= 0 || s->W <= 0 || !(s->voxel > 0.f)) return RFX_ERR_ARG;
     if (s->x0 < 0 || s->x1 > s->dx || s->x1 < s->x0) return RFX_ERR_ARG;
     if (s->count_search <= 0 || s->count_search > RFX_TRACK_MAX_COUNT_SEARCH) return RFX_ERR_ARG;
@@ -392,7 +410,8 @@ static int search_kernel_args(const rfx_track_search* s, SearchK* S, int* eval_b
     S->count_search = s->count_search; S->fix_level_index = s->fix_level_index; S->iterative_scale = s->iterative_scale;
     S->max_rows = max_rows;
     S->scale_d = s->scaling_coefficient; S->beta_d = s->beta;
-    S->state = s->state; S->value = s->value; S->count = s->count;
+    S->state = s->state;
+    S->value = reinterpret_cast<unsigned long long*>(s->value_q30); S->count = reinterpret_cast<unsigned long long*>(s->count);
     *eval_blocks = blocks;
     return RFX_OK;
 }

@@ -472,8 +472,8 @@ class sharded_volume(moving_volume):
 
     def track_evaluate(self, vertex4, normal3, R, T, cand, search_size, n_cand, K9, H, W, level, level_index, value, count):
         """the tracker's nearest-voxel reads (reference model/ROtracker.py:244-259) on a sharded volume: every rank evaluates the
-        pixels whose nearest voxel lies in its slab (rfx_track_evaluate_slab), the sums and hit counts are added over the ranks
-        -- the single-GPU values up to the order of the additions -- and every rank continues with the same numbers."""
+        pixels whose nearest voxel lies in its slab (rfx_track_evaluate_slab), the fixed-point sums and hit counts (int64) are
+        added over the ranks -- integers: exactly the single-GPU values -- and every rank continues with the same numbers."""
         from . import _lib
         from ._lib import _F3, _F6, _F9, check, farr, ptr, stream_ptr
         self._wait_for_producer()
@@ -492,7 +492,8 @@ class sharded_volume(moving_volume):
                 "origin": self.vol_origin, "voxel": float(self.voxel_size)}
 
     def track_search_reduce(self, sums):
-        """value / count of one evaluation of the device-side search (rfx_track_search_evaluate), added over the slabs"""
+        """value_q30 / count (int64 [2, rows]) of one evaluation of the device-side search (rfx_track_search_evaluate), added
+        over the slabs: one collective, exact"""
         all_reduce_sum_(self.dist, [sums])
 
     def copy_volume(self):
@@ -645,6 +646,10 @@ def ShardedPipeline(config: Dict, dist, rank: int, world: int, device: str = "cu
             self.sync_replicas()
 
         def sync_replicas(self):
+            # rank 0's table is whole only while no level-partitioned iteration has run since the last sync_field(): bring the
+            # ranges home from their owners first, or the broadcast would overwrite them with rank 0's stale copies
+            if self.mapper is not None and hasattr(self.mapper, "sync_field"):
+                self.mapper.sync_field()
             with torch.no_grad():
                 for prm in self.model.parameters():
                     if prm.numel():

@@ -5,8 +5,9 @@ PyCUDA kernels replaced by librfx (``rfx_track_vertex / _normal / _evaluate``).
 Differences, on purpose:
   * the pre-sampled particle templates ("PST", 60 float32 TIFFs under PFO/fps_uniform_sphere in the reference,
     read there with cv2) are read from ``RO.PST_path`` by ``model/pst.py`` (own baseline-TIFF reader) into the
-    same ``ALL_PST[class][index]`` container; only when a configuration says ``RO.PST_fallback: "generated"`` and
-    the directory is absent are seeded templates of the same structure used instead, with a warning;
+    same ``ALL_PST[class][index]`` container, or -- where that directory does not exist -- from the archive of the same
+    60 arrays committed under ``tests/golden/pst_templates.npz``; seeded templates of the same structure only when
+    both are missing AND a configuration says ``RO.PST_fallback: "generated"``, with a warning;
   * ``cal_transform``'s python loop over up to 10 240 candidates is vectorised with numpy (same
     selection: the first ``count_search`` candidates that beat candidate 0, same weights);
   * compute_vertex's cuRAND jitter is replaced by a counter-based hash (exactly zero anyway for
@@ -88,22 +89,23 @@ class ROTracker(object):
     # ------------------------------------------------------------------ particle templates
     def readpst(self, PST_path, PST_size):
         """reference :834-866: ``ALL_PST[class][index]`` <- ``PST_path/pst_{size}_{num}.tiff`` ([P,6] float32), plus
-        device copies.  ``RFX_PST_PATH`` in the environment overrides the configured directory.  Generated templates are
-        used only if the directory is absent AND the configuration carries ``RO.PST_fallback: "generated"``."""
-        import os
+        device copies.  ``RFX_PST_PATH`` in the environment overrides the configured directory; where neither names the
+        templates they come from the archive committed with the repository (``model/pst.py::PACKAGED_ARCHIVE``: the same 60
+        arrays).  Generated templates only if that is missing too AND the configuration says ``RO.PST_fallback: "generated"``."""
         import warnings
-        path = os.environ.get("RFX_PST_PATH") or PST_path
+        from .pst import resolve_pst_source
         ro = self.cfg["RO"]
-        if path and os.path.isdir(path):
+        path = resolve_pst_source(PST_path)
+        if path is not None:
             self.ALL_PST = load_pst(path, PST_size, self.tiff_index)
             self.PST_source = path
         elif ro.get("PST_fallback") == "generated":
-            warnings.warn(f"ROTracker: PST directory {path!r} not found; searching with GENERATED templates "
-                          "(RO.PST_fallback='generated'): poses will differ from the reference's", stacklevel=2)
+            warnings.warn(f"ROTracker: no PST templates at {PST_path!r} and no packaged archive; searching with GENERATED "
+                          "templates (RO.PST_fallback='generated'): poses will differ from the reference's", stacklevel=2)
             self.ALL_PST = generated_pst(ro.get("PST_seed", 20251205), PST_size, self.tiff_index)
             self.PST_source = "generated"
         else:
-            self.ALL_PST = load_pst(path or "", PST_size, self.tiff_index)      # raises with the explanation
+            self.ALL_PST = load_pst(PST_path or "", PST_size, self.tiff_index)      # raises with the explanation
         self.ALL_PST_dev = {c: torch.from_numpy(a).to(self.device) for c, a in self.ALL_PST.items()}
 
     def get_PST(self, tiff_index):
@@ -138,16 +140,17 @@ class ROTracker(object):
     def evaluate_tsdf(self, cur_id, level, node_size, cam_intr, level_index):
         """mean |tsdf - target| per candidate (reference :536-604).  Returns (mean, sum, count) as numpy."""
         P = int(node_size // 1024) * 1024            # grid = int(node_size/(32*32)) blocks of 1024 candidates
-        val = torch.empty(P, dtype=torch.float32, device=self.device)
-        cnt = torch.empty(P, dtype=torch.float32, device=self.device)
+        sums = torch.empty((2, P), dtype=torch.int64, device=self.device)      # fixed-point sums (2^-30 units), hit counts
+        val, cnt = sums[0], sums[1]
         self.MV.track_evaluate(self.depth_vertex_gpu, self.normal_vertex_gpu, self.current_global_R.reshape(-1), self.current_global_T,
                                self._cand_dev, self.search_size, P, np.asarray(cam_intr).reshape(-1), self.im_h, self.im_w, level,
                                level_index, val, cnt)
         n_all = self.transform_candidate.shape[0]
         sv = np.zeros(n_all, np.float32)
         sc = np.zeros(n_all, np.float32)
-        both = torch.stack([val, cnt]).cpu().numpy()
-        sv[:P], sc[:P] = both[0], both[1]
+        both = sums.cpu().numpy()
+        sv[:P] = (both[0].astype(np.float64) * 2.0 ** -30).astype(np.float32)      # rounded to float32 once (rfx_track_search_update: the same)
+        sc[:P] = both[1].astype(np.float32)
         return sv / (sc + 1e-6), sv, sc
 
     # ------------------------------------------------------------------ the search on the device
@@ -156,7 +159,7 @@ class ROTracker(object):
         if getattr(self, "_search_state", None) is None:
             rows = max(int(a.shape[1]) for a in self.ALL_PST_dev.values())
             self._search_state = torch.zeros(_lib.RFX_TRACK_STATE_WORDS, dtype=torch.float32, device=self.device)
-            self._search_sums = torch.zeros((2, rows), dtype=torch.float32, device=self.device)
+            self._search_sums = torch.zeros((2, rows), dtype=torch.int64, device=self.device)      # value_q30, count
         s = _lib.TrackSearch()
         vol = self.MV.track_search_volume()
         s.tsdf = ptr(vol["tsdf"])
@@ -178,7 +181,7 @@ class ROTracker(object):
         s.count_search, s.fix_level_index = int(self.count_search), int(bool(self.fix_level_index))
         s.iterative_scale = int(bool(self.iterative_scale))
         s.scaling_coefficient = float(self.scaling_coefficient)
-        s.state, s.value, s.count = ptr(self._search_state), ptr(self._search_sums[0]), ptr(self._search_sums[1])
+        s.state, s.value_q30, s.count = ptr(self._search_state), self._search_sums[0].data_ptr(), self._search_sums[1].data_ptr()
         return s
 
     def random_optimization_device(self, cur_id, cam_pose, rgb_im, depth_im, cam_intr, beta=0.9, inherit=False):

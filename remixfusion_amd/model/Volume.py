@@ -245,7 +245,8 @@ class moving_volume:
 
     def track_evaluate(self, vertex4, normal3, R, T, cand, search_size, n_cand, K9, H, W, level, level_index, value, count):
         """nearest-voxel TSDF residuals of the tracker's pose candidates against THIS volume (reference kernel
-        model/ROtracker.py:144-270): value / count dev [n_cand].  A sharded volume overrides it (its slab + a sum over ranks)."""
+        model/ROtracker.py:144-270): value (sum of |tsdf - target| in 2^-30 units) / count dev int64 [n_cand].  A sharded
+        volume overrides it (its slab + an exact integer sum over ranks)."""
         d = self.vol_dim
         check(_lib.load().rfx_track_evaluate(ptr(self.tsdf_vol_gpu), int(d[0]), int(d[1]), int(d[2]), farr(_F3, self.vol_origin),
                                              float(self.voxel_size), ptr(vertex4), ptr(normal3), farr(_F9, R), farr(_F3, T), ptr(cand),
@@ -253,7 +254,7 @@ class moving_volume:
                                              int(level_index), ptr(value), ptr(count), stream_ptr(self.device)), "rfx_track_evaluate")
 
     # the device-side search (rfx_track_search_*): what it reads of this volume; a sharded volume overrides both
-    track_search_reduce = None                         # callable(sums [2, rows]) adding the evaluation's sums over ranks, or None
+    track_search_reduce = None                         # callable(sums int64 [2, rows]) adding the evaluation's sums over ranks, or None
 
     def track_search_volume(self):
         d = self.vol_dim

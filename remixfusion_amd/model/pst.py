@@ -3,8 +3,9 @@
 The reference ships 60 float32 TIFFs under ``PFO/fps_uniform_sphere`` (``pst_{10240,3072,1024}_{0..19}.tiff``,
 each [P, 6]: row 0 is the null perturbation, the rest are farthest-point samples of the 6-D unit ball) and reads
 them with ``cv2.imread(path, -1)`` into ``ALL_PST[class][index]`` (reference model/ROtracker.py:834-866).
-``load_pst`` builds the same container from the same files; the files themselves are the user's (the
-reference checkout's ``PFO/`` directory, named by ``RO.PST_path`` exactly as in the reference YAMLs).
+``load_pst`` builds the same container from the same files (``RO.PST_path`` exactly as in the reference YAMLs) or, where no
+such directory exists, from ``tests/golden/pst_templates.npz``: the same 60 arrays in one archive (round 5; written by
+``tests/golden/make_golden.py`` from the reference's files and checked against their SHA-256 digests).
 
 ``read_float_tiff`` is a baseline-TIFF reader for exactly that file kind (uncompressed, one float32 sample per
 pixel, strips): neither cv2 nor Pillow is needed.  ``make_pst`` -- seeded templates of the same structure -- is
@@ -117,18 +118,45 @@ def _empty(tiff_index: Sequence[int], PST_size: Sequence[int]) -> Dict[int, np.n
             2: np.zeros((n // 3, PST_size[2], 6), np.float32)}
 
 
+# The reference's 60 templates as ONE archive of float32 arrays (keys ``pst_{size}_{num}``), written from the reference's
+# TIFFs by tests/golden/make_golden.py::make_pst_fixture (data the reference reads at start-up, not source).  It travels with
+# the repository, so a machine without the reference checkout (the GPU box) searches with the reference's particles.
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PACKAGED_ARCHIVE = os.path.join(_ROOT, "tests", "golden", "pst_templates.npz")
+
+
+def resolve_pst_source(PST_path):
+    """Where the templates come from: ``RFX_PST_PATH`` / ``RO.PST_path`` when it names a directory of TIFFs or an ``.npz``
+    archive, else the archive committed with the repository; ``None`` when none of them exists."""
+    for cand in (os.environ.get("RFX_PST_PATH"), PST_path):
+        if cand and (os.path.isdir(cand) or (os.path.isfile(cand) and cand.endswith(".npz"))):
+            return cand
+    return PACKAGED_ARCHIVE if os.path.isfile(PACKAGED_ARCHIVE) else None
+
+
 def load_pst(PST_path: str, PST_size: Sequence[int], tiff_index: Sequence[int]) -> Dict[int, np.ndarray]:
-    """ALL_PST as the reference's readpst builds it (model/ROtracker.py:834-866) from ``pst_{size}_{num}.tiff``."""
-    if not os.path.isdir(PST_path):
+    """ALL_PST as the reference's readpst builds it (model/ROtracker.py:834-866) from ``pst_{size}_{num}.tiff`` in the
+    directory ``PST_path``, or from the arrays ``pst_{size}_{num}`` of the ``.npz`` archive ``PST_path``."""
+    archive = None
+    if os.path.isfile(PST_path) and PST_path.endswith(".npz"):
+        archive = np.load(PST_path)
+    elif not os.path.isdir(PST_path):
         raise FileNotFoundError(
-            f"RO.PST_path {PST_path!r} is not a directory.  Point it at the reference checkout's PFO/fps_uniform_sphere "
-            "(60 float32 TIFFs), or set RO.PST_path: null and RO.PST_fallback: 'generated' to search with seeded "
-            "templates instead (poses will then differ from the reference's).")
+            f"RO.PST_path {PST_path!r} is neither a directory of the reference's 60 float32 TIFFs (PFO/fps_uniform_sphere) "
+            f"nor an .npz archive of them, and the packaged archive {PACKAGED_ARCHIVE!r} is missing.  Set RO.PST_fallback: "
+            "'generated' to search with seeded templates instead (poses will then differ from the reference's).")
     out = _empty(tiff_index, PST_size)
     for ti in tiff_index:
         cls, num, slot = pst_slot(ti)
-        path = os.path.join(PST_path, f"pst_{PST_size[cls]}_{num}.tiff")
-        a = read_float_tiff(path)
+        name = f"pst_{PST_size[cls]}_{num}"
+        if archive is not None:
+            if name not in archive:
+                raise ValueError(f"{PST_path}: no array {name!r}")
+            a = np.ascontiguousarray(archive[name], np.float32)
+            path = f"{PST_path}:{name}"
+        else:
+            path = os.path.join(PST_path, name + ".tiff")
+            a = read_float_tiff(path)
         if a.shape != (PST_size[cls], 6):
             raise ValueError(f"{path}: shape {a.shape}, expected {(PST_size[cls], 6)}")
         out[cls][slot] = a

@@ -106,6 +106,7 @@ class Mapper:
         self.trunc_margin = self.config["training"]["c_trunc"]
 
     def save_ckpt(self, save_path):
+        self.wait_meshes()              # a failed in-loop export raises here, like the reference's blocking export would have
         self.sync_field()               # (a sharded scene: the table whole on every rank; collective)
         torch.save({"pose": self.est_c2w_data, "pose_rel": self.est_c2w_data_rel, "model": self.model.state_dict()}, save_path)
 
@@ -402,6 +403,7 @@ class Mapper:
                 self.step(current_map_id)
             if self.tracking_stop_flag[0] != 0:
                 break
+        self.wait_meshes()              # the in-loop exports are on disk (or their error is raised) when run() returns
         if m["save_ckpt"]:
             import os
             self.save_ckpt(os.path.join(self.config["data"]["output"], self.config["data"]["exp_name"], "checkpoint.pt"))

@@ -65,6 +65,12 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         if not self._native():
+            if self.slices:
+                # torch's Adam would step the WHOLE tensor: outside a rank's own range the gradient buffer is never written
+                # (nor zeroed), so the other ranks' levels and their moments would be corrupted silently
+                raise _lib.RfxError("Adam.slices is set (a level-partitioned table) but the native step is unavailable for this "
+                                    "configuration (amsgrad / capturable / tensor lr / non-contiguous gradient): refusing to "
+                                    "fall back to a step over the whole tensor")
             torch_step = torch.optim.Adam.step             # un-wrapped: step() above has dealt with the hooks already
             getattr(torch_step, "__wrapped__", torch_step)(self, None)
             return loss

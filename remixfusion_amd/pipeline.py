@@ -127,6 +127,13 @@ class MappingPipeline:
                 if self.track_stream is None:
                     self.tracker.tracking(b, i)
                 else:
+                    if batch.get("rgb255") is None:     # not prefetched: the frame was just produced on the current stream
+                        self.track_stream.wait_stream(torch.cuda.current_stream(self.device))
+                        # ... and was allocated there: the tracker's stream reads these blocks (compute_vertex, integrate), so
+                        # the caching allocator must not hand them to new current-stream work while that is still queued
+                        for v in b.values():
+                            if isinstance(v, torch.Tensor) and v.is_cuda:
+                                v.record_stream(self.track_stream)
                     with torch.cuda.stream(self.track_stream):
                         self.tracker.tracking(b, i)
                 self.slam.tracking_idx[0] = i

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, fn), f"{fn} declared in include/rfx.h but not exported"
         assert fn in _lib.PROTOTYPES, f"{fn} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == declared
-    assert lib.rfx_abi_version() == 7
+    assert lib.rfx_abi_version() == 8
 
 
 def test_struct_layouts_match_header():
@@ -55,6 +55,13 @@ def test_argument_validation_without_gpu():
     assert lib.rfx_sample_z(C.byref(s), None, None, 0, None, None) == 0
     fake = C.c_void_p(16)
     assert lib.rfx_sample_z(C.byref(s), fake, None, 4, fake, None) == -3             # S > 128: RFX_ERR_UNSUPPORTED
+    # a grid level of 4 GiB or more cannot be addressed by the lookups' 32-bit byte offsets: refused, not wrapped (round 5)
+    g = _lib.GridDesc()
+    g.n_levels, g.n_feat = 1, 4
+    g.scale[0], g.res[0], g.size[0], g.offset[0], g.hashed[0] = 699.0, 700, 700 ** 3, 0, 0      # 700^3 float4 entries = 5.5 GB
+    assert lib.rfx_grid_encode_forward(C.byref(g), fake, fake, 4, fake, None) == -3
+    g.n_feat, g.size[0] = 2, 1 << 29                                                        # 2^29 float2 entries = 4 GiB
+    assert lib.rfx_grid_encode_backward(C.byref(g), fake, fake, 4, fake, fake, None, None, 0, None) == -3
 
 
 def test_product_fails_loudly_without_gpu():

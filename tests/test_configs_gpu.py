@@ -150,9 +150,10 @@ def test_north_star_volume_1000_cubed():
 @pytest.mark.timeout(900)
 def test_config3_scene0000_mapping_with_the_tracker_on():
     """BASELINE config 3 end to end at its own sizes (620x460, moving volume 250x250x150 @ 4 cm, T = 2^19, 117 samples per
-    ray, 63^3-point TV lattice): poses come from the ROTracker, not from the ground truth.  Generated search templates here
-    (the reference's PST files do not travel): the check is that the loop runs, keeps the pose error bounded on the
-    depth-observable axis and leaves finite maps; kernel parity of the tracker is test_tracker_gpu.py's."""
+    ray, 63^3-point TV lattice): poses come from the ROTracker, not from the ground truth, and the search runs on the
+    REFERENCE's particle templates (round 5: tests/golden/pst_templates.npz, the 60 arrays of PFO/fps_uniform_sphere): the check
+    is that the loop runs, keeps the pose error bounded on the depth-observable axis and leaves finite maps; kernel parity of
+    the tracker is test_tracker_gpu.py's."""
     import random
     import warnings
     import torch
@@ -167,7 +168,8 @@ def test_config3_scene0000_mapping_with_the_tracker_on():
         warnings.simplefilter("ignore")
         pipe = MappingPipeline(cfg, n_frames=24)
     assert pipe.tracker is not None and tuple(int(v) for v in pipe.mv.vol_dim) == (250, 250, 150)
-    assert pipe.tracker.RO_Tracker.PST_source in ("generated",) or pipe.tracker.RO_Tracker.PST_source.endswith("fps_uniform_sphere")
+    # the reference's particles (its TIFF directory, or the archive of the same arrays that travels with the repository): never generated
+    assert pipe.tracker.RO_Tracker.PST_source.endswith(("fps_uniform_sphere", "pst_templates.npz"))
     frames = pipe.prefetch(list(range(16)))
     pipe.start(frames[0])
     for i in range(1, 16):
@@ -193,9 +195,9 @@ def test_config3_tracker_follows_a_120_frame_sequence():
     the scene0000-sized stream with the tracker on, absolute trajectory error against the synthetic ground truth (no alignment:
     both start from the same pose).  The room is furnished (synthetic.clutter = 48 spheres): in the bare box room a translation
     along a flat wall changes no depth and a geometric tracker slides along it (measured: 1.8 cm of every 3 cm step lost,
-    ATE 28 cm after 120 frames; tools/tracker_dbg.py), which says nothing about the tracker.  Generated search templates (the
-    reference's PST files do not travel to the GPU box; tests/test_pst_cpu.py checks the reader against their digest).
-    Measured: ATE rmse 2.2 cm, max 3.3 cm, rotation rmse 0.8 deg at 4 cm voxels."""
+    ATE 28 cm after 120 frames; tools/tracker_dbg.py), which says nothing about the tracker.  The search uses the reference's
+    particle templates (round 5: the archive of its 60 PST arrays travels with the repository; round 4 measured this test on
+    generated ones: ATE rmse 2.2-2.4 cm, max 3.3 cm, rotation rmse 0.8 deg at 4 cm voxels)."""
     import random
     import warnings
     import numpy as np

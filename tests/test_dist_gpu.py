@@ -244,14 +244,11 @@ def test_sharded_volume_cold_readers_world3(tmp_path):
     assert all(r["volume_class"] == "sharded_volume" for r in rs) and ref["volume_class"] == "moving_volume"
     for r in rs[1:]:
         assert torch.equal(r["poses"], rs[0]["poses"])     # every rank continues with the same sums: the same poses
-    dp = (rs[0]["poses"][:, :3, 3] - ref["poses"][:, :3, 3]).norm(dim=1)
     err = (ref["poses"][:, :3, 3] - ref["gt"][:, :3, 3]).norm(dim=1)
-    print(f"tracker on 3 slabs vs one volume: max |dt| {float(dp.max()) * 1e3:.3f} mm; single-GPU error vs ground truth {float(err.max()) * 1e3:.1f} mm")
-    err_s = (rs[0]["poses"][:, :3, 3] - ref["gt"][:, :3, 3]).norm(dim=1)
-    # The slab sums are the single-GPU sums with the terms added in another order (tests/test_tracker_gpu.py holds them to 1e-5);
-    # the search that follows picks "the first 200 candidates that beat candidate 0", which a last-bit difference can re-order, so
-    # the trajectories separate by millimetres within a few frames -- as two single-GPU runs do (its sums use float atomics).  The
-    # first frame's 20 searches start from identical state and must land within a tenth of a voxel (4 cm) of each other (measured
-    # 0.04 and 1.1 mm in two runs); after that both must TRACK equally well.
-    assert float(dp[1]) < 4e-3, float(dp[1])
-    assert float(err.max()) < 0.08 and float(err_s.max()) < 0.08 and abs(float(err_s.max()) - float(err.max())) < 0.05
+    # The slab sums ARE the single-GPU sums (round 5: 30-bit fixed-point terms added as integers, in the threads, between the
+    # pixel slabs and over the ranks -- tests/test_tracker_gpu.py holds them to the oracle's exactly), so the search sees the
+    # same fitness values, picks the same candidates and leaves the same pose: the trajectory on 3 slabs is the single-GPU
+    # trajectory BIT FOR BIT.  (Up to round 4 the sums came from float atomics; the search amplified their last bit into
+    # millimetres within a few frames and this test bounded both runs against the truth instead.)
+    assert torch.equal(rs[0]["poses"], ref["poses"])
+    assert float(err.max()) < 0.08

@@ -134,3 +134,38 @@ def test_template_file_of_every_search_step_matches_reference(tmp_path):
         cls, _, slot = P.pst_slot(ti)
         code = int(A[cls][slot][0, 0])
         assert f"pst_{small[code // 100]}_{code % 100}.tiff" == str(g["pst_file_at_step"][k]), k
+
+
+def test_packaged_archive_holds_the_reference_templates():
+    """tests/golden/pst_templates.npz (round 5): the 60 arrays themselves, identical -- SHA-256 of the sample bytes, shape,
+    first rows, float64 sums -- to what the committed digest recorded from the reference's TIFFs (PFO/fps_uniform_sphere,
+    read by model/ROtracker.py:834-866), and `load_pst` / `resolve_pst_source` serve them where no TIFF directory exists."""
+    P = _pst()
+    g = np.load(os.path.join(HERE, "golden", "pst_fixture.npz"))
+    arc = os.path.join(HERE, "golden", "pst_templates.npz")
+    assert P.PACKAGED_ARCHIVE == arc and os.path.isfile(arc)
+    z = np.load(arc)
+    assert sorted(z.files) == sorted(str(n)[:-len(".tiff")] for n in g["names"])
+    for i, name in enumerate(g["names"]):
+        a = z[str(name)[:-len(".tiff")]]
+        assert a.dtype == np.float32 and a.shape == tuple(g["shapes"][i]) and np.array_equal(a[:4], g["heads"][i])
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == str(g["sha256"][i])
+        assert abs(float(a.astype(np.float64).sum()) - float(g["sums"][i])) < 1e-9
+    A = P.load_pst(arc, SIZES, TIFF_INDEX)
+    for ti in TIFF_INDEX:
+        cls, num, slot = P.pst_slot(ti)
+        assert np.array_equal(A[cls][slot], z[f"pst_{SIZES[cls]}_{num}"])
+    # resolution order: an existing directory / archive named by the configuration wins, anything else -> the packaged archive
+    old = os.environ.pop("RFX_PST_PATH", None)
+    try:
+        assert P.resolve_pst_source("PFO/fps_uniform_sphere_that_does_not_exist") == arc
+        assert P.resolve_pst_source(None) == arc
+        assert P.resolve_pst_source(arc) == arc
+        assert P.resolve_pst_source(HERE) == HERE
+    finally:
+        if old is not None:
+            os.environ["RFX_PST_PATH"] = old
+    d = _ref_dir()
+    if d is not None:         # the authoring container: directory and archive give the same container, bit for bit
+        B = P.load_pst(d, SIZES, TIFF_INDEX)
+        assert all(np.array_equal(A[c], B[c]) for c in range(3))

@@ -40,12 +40,15 @@ def test_one_scene_pipeline_through_a_one_rank_rccl_communicator():
     assert d["levels_iterations"] == "LevelShardedIterations" and d["replicas_iterations"] == "ShardedIterations"
     for mode in ("levels", "replicas"):
         assert d[f"{mode}_volume_voxels"] == 250 * 250 * 150 and d[f"{mode}_trilerp_rows"] == 2000
-        # tracker + mapper followed the camera as the single-process pipeline does (the two differ through float atomics only)
-        # both follow the camera (errors of 1.3-2.7 cm seen; the two runs differ through float atomics, which the tracker amplifies
-        # to centimetres: 2.9 cm between them seen once in six runs -- hence bounds on each against the truth, not on their difference)
-        assert d[f"{mode}_sharded_pose_err_cm"] < 6.0 and d[f"{mode}_single_pose_err_cm"] < 6.0, d
+        # The tracker's trajectory through the communicator IS the single-process one, bit for bit (round 5: its evaluation sums
+        # are order-independent integers, rfx_track_evaluate; up to round 4 float atomics let the two runs drift centimetres apart
+        # and this test bounded each against the truth instead).
+        assert d[f"{mode}_sharded_ro_hex"] == d[f"{mode}_single_ro_hex"], mode
+        assert d[f"{mode}_sharded_pose_err_cm"] < 5.0 and d[f"{mode}_single_pose_err_cm"] < 5.0, d
+        # est_c2w_data also carries the mapper's pose refinement of the keyframes, whose hash-table gradients are float atomics:
+        # the same poses to the refinement's own run-to-run noise
         a, b = d[f"{mode}_sharded_pose_t"], d[f"{mode}_single_pose_t"]
-        assert max(abs(x - y) for x, y in zip(a, b)) < 0.10, d
+        assert max(abs(x - y) for x, y in zip(a, b)) < 2e-3, d
 
 
 @pytest.mark.timeout(900)

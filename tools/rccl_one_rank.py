@@ -48,6 +48,9 @@ for mode in ("levels", "replicas"):
         losses[sharded] = [float(v) for v in pipe.mapper.last_losses.values()] if hasattr(pipe.mapper, "last_losses") else None
         pose = pipe.slam.est_c2w_data[N - 1].cpu().numpy()
         out[f"{mode}_{'sharded' if sharded else 'single'}_pose_t"] = [float(v) for v in pose[:3, 3]]
+        # the tracker's own trajectory (what its search produced, before the mapper's pose refinement moves the keyframes)
+        ro = pipe.slam.RO_c2w_data[1:N].cpu().numpy()
+        out[f"{mode}_{'sharded' if sharded else 'single'}_ro_hex"] = ro.astype(np.float32).tobytes().hex()
         gt = frames[N - 1]["c2w"].numpy()
         out[f"{mode}_{'sharded' if sharded else 'single'}_pose_err_cm"] = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 100)
         del pipe
