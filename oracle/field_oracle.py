@@ -178,13 +178,51 @@ def oneblob_encode(x: torch.Tensor, n_bins: int = 16, pos_fp16: bool = False) ->
 
 
 # ----------------------------------------------------------------------------- MLP (D1)
+MLP_PROBE = None       # tests: a dict that mlp_forward fills with its layer inputs, pre-activations and hidden activations
+                       # (the latter with retain_grad) -- what relu_tie_bounds() below needs
+
+
 def mlp_forward(embed, embed_pos, ex_tsdf, ex_rgb, W1, W2, W3, W4):
     """model/decoder.py:132-146 with torch Linear weights W[out,in], no bias.
     W1 [32,81], W2 [16,32], W3 [32,66], W4 [3,32]."""
-    h = F.linear(torch.relu(F.linear(torch.cat([embed, embed_pos, ex_tsdf], -1), W1)), W2)
+    x1 = torch.cat([embed, embed_pos, ex_tsdf], -1)
+    p1 = F.linear(x1, W1)
+    h1 = torch.relu(p1)
+    h = F.linear(h1, W2)
     sdf, geo = h[..., :1], h[..., 1:]
-    rgb = F.linear(torch.relu(F.linear(torch.cat([embed_pos, geo, ex_rgb], -1), W3)), W4)
+    x3 = torch.cat([embed_pos, geo, ex_rgb], -1)
+    p3 = F.linear(x3, W3)
+    h3 = torch.relu(p3)
+    rgb = F.linear(h3, W4)
+    if MLP_PROBE is not None:
+        for t in (h1, h3):
+            if t.requires_grad:
+                t.retain_grad()
+        MLP_PROBE.update(X1=x1, P1=p1, H1=h1, X3=x3, P3=p3, H3=h3, W1=W1, W3=W3)
     return torch.cat([rgb, sdf], -1)
+
+
+def relu_tie_bounds(probe, n_terms=(81, 66)):
+    """Per ELEMENT of dW1 [32,81] and dW3 [32,66]: how much of the gradient hangs on hidden pre-activations that any fp32
+    evaluation may round to the other side of zero.  `probe` = MLP_PROBE after a float64 forward + backward.
+    A dot product of n fp32 terms, summed in whatever order, lies within gamma_n * sum |terms| of the exact value
+    (gamma_n = n u / (1 - n u), u = 2^-24), so the sign of pre-activation (p, r) is the same in EVERY fp32 evaluation unless
+    |exact| <= gamma_n * sum_i |W[r,i] X[p,i]|.  Only for those (sample, unit) pairs -- the possible ties -- may the sample's term
+    dH[p,r] * X[p,:] enter or leave row r of the weight gradient.  The bound returned for element (r, i) is the sum of
+    |dH[p,r] X[p,i]| over the possible ties of row r: zero for a row without one."""
+    out = []
+    for X, Pre, H, W, n, gk in ((probe["X1"], probe["P1"], probe["H1"], probe["W1"], n_terms[0], "G1"),
+                                (probe["X3"], probe["P3"], probe["H3"], probe["W3"], n_terms[1], "G3")):
+        X, Pre, W = X.detach().double().reshape(-1, X.shape[-1]), Pre.detach().double().reshape(-1, Pre.shape[-1]), W.detach().double()
+        G = probe.get(gk, H.grad)                    # (callers that differentiate with autograd.grad store G1 / G3 themselves)
+        if G is None:
+            raise RuntimeError("relu_tie_bounds: run the backward first (no gradient at the hidden activations)")
+        G = G.detach().double().reshape(-1, H.shape[-1])
+        u = 2.0 ** -24
+        gamma = n * u / (1.0 - n * u)
+        tie = Pre.abs() <= 2.0 * gamma * (X.abs() @ W.abs().T)          # either of two evaluations may be off by gamma: 2 gamma apart
+        out.append(((tie.double() * G.abs()).T @ X.abs(), int(tie.sum())))
+    return out
 
 
 # ----------------------------------------------------------------------------- field (Q1/Q2)

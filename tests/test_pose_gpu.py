@@ -255,7 +255,7 @@ def test_direct_iterations_equal_autograd_iterations():
     # formulations draw the same batch), per element
     from oracle import field_oracle as FO
     from oracle import rba_oracle as RO
-    from test_field_gpu import _f64_params, _grad_close, _level_groups, _oracle_params
+    from test_field_gpu import _f64_params, _grad_close, _level_groups, _oracle_params, _probe
     from test_timed_path_gpu import _oracle_iteration, _ws_fields
     from remixfusion_amd import _lib as L
     lib = L.load()
@@ -274,13 +274,15 @@ def test_direct_iterations_equal_autograd_iterations():
         t.requires_grad_(True)
     _oracle_iteration(fp, cfg, bbox, f["o"], f["d"], f["z"], f["tgt"], f["td"], False, f["pts"])[2].backward()
     fq = _f64_params(fp)
-    _oracle_iteration(fq, cfg, bbox, f["o"], f["d"], f["z"], f["tgt"], f["td"], False, f["pts"])[2].backward()
+    with _probe() as pr:
+        _oracle_iteration(fq, cfg, bbox, f["o"], f["d"], f["z"], f["tgt"], f["td"], False, f["pts"])[2].backward()
+        ties = pr.bounds()
     o32 = [fp.hash_table.grad, fp.W1.grad, fp.W2.grad, fp.W3.grad, fp.W4.grad]
     o64 = [fq.hash_table.grad, fq.W1.grad, fq.W2.grad, fq.W3.grad, fq.W4.grad]
     for which, grads in (("direct", got), ("autograd", ref)):
         for g, a, q, nm in zip(grads, o32, o64, ("d_hash", "dW1", "dW2", "dW3", "dW4")):
             _grad_close(g, a, q, f"{nm} ({which}, map phase)", _level_groups(fp.hash_meta) if nm == "d_hash" else None,
-                        relu_ties=0 if nm == "d_hash" else 2 * 81)
+                        tie_bound=ties.get(nm))
     assert float((ref[0] != 0).float().mean()) > 0.001
     # ---- pose phase
     reset()
@@ -305,12 +307,19 @@ def test_direct_iterations_equal_autograd_iterations():
         o = c2w[pidx, :3, 3]
         d = torch.sum(f["d_cam"].to(dtype)[:, None, :] * c2w[pidx, :3, :3], -1)
         tot = _oracle_iteration(fpp, cfg, bbox, o, d, f["z"], f["tgt"], f["td"], True, f["pts"])[2]
+        if FO.MLP_PROBE is not None:                 # the float64 run: also the gradients at the hidden activations (ReLU tie bounds)
+            gs = torch.autograd.grad(tot, prm + [fpp.hash_table, fpp.W1, fpp.W2, fpp.W3, fpp.W4, FO.MLP_PROBE["H1"], FO.MLP_PROBE["H3"]])
+            FO.MLP_PROBE.update(G1=gs[-2], G3=gs[-1])
+            return gs[:-2]
         return torch.autograd.grad(tot, prm + [fpp.hash_table, fpp.W1, fpp.W2, fpp.W3, fpp.W4])
 
     fp2 = _oracle_params(cfg, model)
     for t in (fp2.hash_table, fp2.W1, fp2.W2, fp2.W3, fp2.W4):
         t.requires_grad_(True)
-    p32, p64 = pose_chain(fp2, torch.float32), pose_chain(_f64_params(fp2), torch.float64)
+    p32 = pose_chain(fp2, torch.float32)
+    with _probe() as pr:
+        p64 = pose_chain(_f64_params(fp2), torch.float64)
+        ties = pr.bounds()
     by_lin = lambda grads: [dict(zip(rba_params, grads))[t] for l in lin for t in (l.weight, l.bias)]    # noqa: E731
     for which, grads in (("direct", got_r), ("autograd", ref_r)):
         for g, a, q in zip(by_lin(grads), p32[:8], p64[:8]):
@@ -319,7 +328,7 @@ def test_direct_iterations_equal_autograd_iterations():
     for which, grads in (("direct", got_m), ("autograd", ref_m)):
         for g, a, q, nm in zip(grads, p32[8:], p64[8:], ("d_hash", "dW1", "dW2", "dW3", "dW4")):
             _grad_close(g, a, q, f"{nm} ({which}, pose phase)", _level_groups(fp2.hash_meta) if nm == "d_hash" else None,
-                        relu_ties=0 if nm == "d_hash" else 2 * 81)
+                        tie_bound=ties.get(nm))
     # ---- the one-call driver (rfx_ba_forward_backward) vs the same iteration issued stage by stage
     direct.stagewise_every = 1
     reset()
