@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak
 MLP_FLOP_PER_POINT = 2 * (81 * 32 + 32 * 16 + 66 * 32 + 32 * 3)     # 10 624
-PMC_TRAFFIC_FILE, PMC_V1_FILE = "r4_pmc_traffic.json", "r4_pmc_v1_frame25.json"      # written by tools/r4_measure.sh
+PMC_TRAFFIC_FILE, PMC_V1_FILE = "r5_pmc_traffic.json", "r5_pmc_v1_frame25.json"      # written by tools/r5_measure.sh
 
 
 def parse():
@@ -764,7 +764,7 @@ def main():
                     "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
                     "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # HBM traffic per launch: NOT measured by this run (PMC counters need rocprofv3 passes of their own).  The figure is
-    # taken from the committed summary of those passes, profiles/r4_pmc_traffic.json (tools/summarize_pmc.py), which
+    # taken from the committed summary of those passes, profiles/r5_pmc_traffic.json (tools/summarize_pmc.py), which
     # carries the digest of the kernel sources the passes ran on (remixfusion_amd.build.sources_digest): when this tree's
     # digest differs -- the binary timed here is not the one the counters saw -- traffic stays null and says so.
     from remixfusion_amd.build import sources_digest
@@ -792,7 +792,7 @@ def main():
     except Exception:
         pass
     # V1: traffic of the SAME frame the algorithmic bytes above were counted on (frame 1 + warmup + steps - 1), when the
-    # committed passes cover it (profiles/r4_pmc_v1_frame25.json: the driver's settings) and ran on these kernel sources
+    # committed passes cover it (profiles/r5_pmc_v1_frame25.json: the driver's settings) and ran on these kernel sources
     try:
         v1p = json.load(open(os.path.join(ROOT, "profiles", PMC_V1_FILE)))
         if "tsdf_integrate" in extra_rooflines and v1p.get("kernel_sources_digest") != digest_now:

@@ -530,7 +530,9 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
     // max-depth pyramid over the coarse tiles: level 0 = the tiles, level l+1 = 2x2 maxima of level l.  A row's
     // projection is a straight segment; its bounding box is looked up at the level where it spans at most 2x2 cells.
     __shared__ float pyr[MV_ROWS_LDS_TILES + MV_PYR_FLOATS];
+#if MV_FAR_WALK
     __shared__ float dil[MV_ROWS_LDS_TILES];      // max depth over the 3x3 tiles around a tile (the far-end walk below)
+#endif
     __shared__ int lvl_off[16], lvl_w[16], lvl_h[16];
     const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     const int n_tiles = tw * th;
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             lvl_off[15] = l + 1;
         }
         __syncthreads();
+#if MV_FAR_WALK
         for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
             const int y = i / tw, x = i - y * tw;
             float m = 0.0f;
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
                 for (int xx = max(x - 1, 0); xx <= min(x + 1, tw - 1); ++xx) m = fmaxf(m, pyr[yy * tw + xx]);
             dil[i] = m;
         }
+#endif
         n_lvl = lvl_off[15];
         for (int l = 1; l < n_lvl; ++l) {
             const int w = lvl_w[l], h = lvl_h[l], pw = lvl_w[l - 1], ph = lvl_h[l - 1];
@@ -709,7 +713,10 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
         for (int c = 0; c < nch_row; ++c) n_items += ((c >= c0 && c < c1) || alias_chunk(c)) ? 1 : 0;
     }
     // ---- append: wave prefix sums, then ONE returning atomic per block (a single counter word retires ~90 such atomics
-    //      per microsecond; one per wave, ~900 a frame, would cost as much as the rest of this kernel)
+    //      per microsecond; one per wave, ~900 a frame, would cost as much as the rest of this kernel).
+    //      Where this kernel's 14.5 us go (round 5, timing builds that return early): launch + pyramid 4.8, + the rows'
+    //      intervals 2.8, + scans, barriers and the atomic 5.8 (2 of them waiting for the atomic), + the item stores 1.
+    //      A block-wide, coalesced form of the stores (item i by thread i, its row found by bisection) was built: 14.4 us.
     int incl = n_items;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
