@@ -130,7 +130,13 @@ def grid_encode(x: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> torch.T
     outs = []
     for l in range(meta.n_levels):
         scale = torch.tensor(meta.scales[l], dtype=torch.float32)
-        pos = torch.addcmul(torch.tensor(0.5, dtype=torch.float32), x, scale)  # scale*x + 0.5 (fp32)
+        # scale*x + 0.5 as ONE rounding, like tiny-cuda-nn's `fmaf(scale, x, 0.5f)` (grid.h, pos_fract) and the kernels' fmaf:
+        # torch.addcmul on float32 CPU tensors rounds the product first, so the sum is formed in float64 (the product of two
+        # float32 values is exact there; the one rounding of the sum differs from a true fma only where the float64 sum itself
+        # rounds -- 29 bits below the float32 result: a double-rounding case no test point has met) and rounded once.
+        # Differentiable in x like the addcmul it replaces (d pos / d x = scale).
+        pos = (x.double() * scale.double() + 0.5).to(x.dtype) if x.dtype == torch.float32 else torch.addcmul(
+            torch.tensor(0.5, dtype=x.dtype), x, scale.to(x.dtype))
         flo = torch.floor(pos)
         g = flo.detach().to(torch.int64) & _M32   # (uint32)(int)floor
         f = pos - flo.detach()
