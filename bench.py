@@ -804,8 +804,9 @@ def main():
             extra_rooflines["tsdf_integrate"]["traffic_raw_counters"] = int(sum(k["hbm_bytes_raw"] for k in v1p["kernels"].values()))
             extra_rooflines["tsdf_integrate"]["traffic_source"] = (
                 f"profiles/{PMC_V1_FILE}: rocprofv3 --pmc passes of tools/pmc_v1.py at commit {v1p['measured_at_commit']} on frame "
-                f"{v1p['frame']} (this frame; not this run): 2 x FETCH_SIZE + WRITE_SIZE, the factor 2 calibrated on a coalesced "
-                "dword-per-lane read of known size in the same passes; traffic_raw_counters = FETCH_SIZE + WRITE_SIZE")
+                f"{v1p['frame']} (this frame; not this run): 2 x FETCH_SIZE + WRITE_SIZE = the bytes the L2s pulled in (every miss is a whole "
+                "128-byte line tallied at 64, calibrated on V1's own access shape: profiles/r5_fetch_calib.txt) -- Infinity-Cache hits "
+                "included: ~80 MB of it are the frame's images fetched once per XCD; traffic_raw_counters = FETCH_SIZE + WRITE_SIZE")
         elif "tsdf_integrate" in extra_rooflines:
             extra_rooflines["tsdf_integrate"]["traffic"] = None         # passes of other frames are not comparable
             extra_rooflines["tsdf_integrate"].pop("traffic_source", None)

@@ -3,7 +3,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; T=${1:-x}; O=/tmp/qb_$T
 mkdir -p $O $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O -o bench --output-format rocpd -- python3 $R/bench.py --steps 80 --warmup 20 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/busy_$T.json 2> $O/err.log
+rocprofv3 --kernel-trace -d $O -o bench --output-format rocpd -- python3 $R/bench.py --steps 80 --warmup 20 --no-cpu-baseline > $R/gpurun_out/busy_$T.json 2> $O/err.log
 cd $R
 python3 tools/gpu_busy.py $(ls $O/*.db | head -1) 40 > gpurun_out/busy_$T.txt 2>&1
 cat gpurun_out/busy_$T.txt
