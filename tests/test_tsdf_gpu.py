@@ -104,6 +104,18 @@ def test_integrate_above_2pow24_reference_vs_exact_decode():
         _run_pair(dims, (-3, -4, -2), 0.02, 0.06, [(K, c2w, rgb, depth)], decode=decode)
 
 
+def test_integrate_every_voxel_in_the_truncation_band_and_tiny_grids():
+    """round 5's chunk kernel keeps the exact-path voxels of a wave in a 192-record LDS list and evaluates them after the item
+    loop; with a truncation band as wide as the room nearly EVERY lane is such a voxel, so a list fills within three items and the
+    in-loop drain (list about to overflow) runs all the time, over several frames (stored values re-read by later rounds).  The
+    small volumes give queues of a few items on grids of fewer than eight workgroups (the XCD dealing's degenerate cases)."""
+    frames = [small_frame(H=120, W=160, frame=f)[:4] for f in (0, 5, 11)]
+    _run_pair((200, 200, 150), (-4, -5, -3), 0.04, 3.0, frames)             # trunc 3 m: the band covers the whole frustum
+    K, c2w, rgb, depth, _ = small_frame(H=60, W=80)
+    for dims, voxel in (((6, 5, 70), 0.5), ((3, 3, 3), 1.0), ((9, 9, 130), 0.1), ((16, 12, 64), 0.3)):
+        _run_pair(dims, (-2, -2, -2), voxel, 0.6, [(K, c2w, rgb, depth)] * 2)
+
+
 def test_integrate_weight_clamp_saturates_at_40():
     K, c2w, rgb, depth, _ = small_frame(H=60, W=80)
     _run_pair((80, 80, 60), (-2, -3, -2), 0.05, 0.2, [(K, c2w, rgb, depth)] * 43, weight_clamp=1)
