@@ -275,3 +275,45 @@ def test_device_search_reports_an_invalid_template_and_refuses_bad_descriptors()
     s.n_eval[0] = s.template_rows[0] + 1
     assert lib.rfx_track_search_update(C.byref(s), 0, st) == -1
     torch.cuda.synchronize()
+
+
+def test_tracker_pipeline_is_reproducible_and_takes_unprefetched_frames():
+    """Two things that round 5 made testable.  (1) The tracker's evaluation sums no longer depend on the order of their
+    additions (ABI 8), so two runs of one stream give the SAME trajectory, bit for bit (up to round 4 float atomics let them
+    drift millimetres apart within a few frames).  (2) A frame handed to `step()` straight from the dataset -- produced on the
+    current stream just before the call, not prefetched -- is read by the tracker's own stream only after that stream has
+    been ordered behind its producer (pipeline.py: wait_stream + record_stream, as for the volume's stream): the same
+    trajectory again."""
+    import random
+    import warnings
+    from remixfusion_amd.config import synthetic_config
+    from remixfusion_amd.pipeline import MappingPipeline
+    N = 9
+
+    def run(prefetch):
+        random.seed(0)
+        cfg = synthetic_config("office0")
+        cfg["cam"].update({"H": 120, "W": 160, "fx": 144.0, "fy": 144.0, "cx": 79.5, "cy": 59.5})
+        cfg["volume"].update({"voxel_size": 0.04, "trunc": 0.15})
+        cfg["mapping"].update({"first_iters": 6, "sample": 512})
+        cfg["synthetic"].update({"depth_noise": 0.0, "dropout": 0.02, "tracker": True, "clutter": 32})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pipe = MappingPipeline(cfg, n_frames=N + 4, seed=5)
+        assert pipe.track_stream is not None
+        if prefetch:
+            frames = pipe.prefetch(list(range(N)))
+            pipe.start(frames[0])
+            for i in range(1, N):
+                pipe.step(i, frames[i])
+        else:
+            pipe.start(pipe.dataset[0])
+            for i in range(1, N):
+                pipe.step(i, pipe.dataset[i])          # rendered on the current stream right here
+        torch.cuda.synchronize()
+        return pipe.slam.RO_c2w_data[:N].detach().cpu().clone()
+
+    a, b, c = run(True), run(True), run(False)
+    assert float((a[1:, :3, 3] - a[0, :3, 3]).norm(dim=1).max()) > 0.02       # the camera moved and was followed
+    assert torch.equal(a, b)
+    assert torch.equal(a, c)
