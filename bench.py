@@ -486,6 +486,15 @@ def main_sharded(args, dist, rank, world, device):
         import traceback
         traceback.print_exc()
         fail(f"rank {rank}: {type(e).__name__}: {e}"[:400])
+    # what the process group itself saw: the number of ranks, the backend and each rank's device (all-gathered), so that the
+    # line proves N ranks ran on N devices (tests/test_bench_gpu.py)
+    try:
+        seen = [None] * dist.get_world_size()
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        dist.all_gather_object(seen, {"rank": rank, "device_index": torch.cuda.current_device(), "pid": os.getpid(),
+                                      "device_uuid": str(getattr(props, "uuid", "")), "device_name": props.name})
+    except Exception as e:          # noqa: BLE001
+        fail(f"rank {rank}: all_gather_object of the rank devices: {type(e).__name__}: {e}"[:400])
     done.set()
     if rank == 0:
         summ = timer.summary()
@@ -510,6 +519,9 @@ def main_sharded(args, dist, rank, world, device):
                     "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32",
                     "config": info, "roofline": roofline, "rooflines": rl, "kernels": per_kernel, "dominant_call": dominant,
                     "iterations_timed": iters, "cpu_baseline": None, "n1_same_workload": n1, "exchange": exchange,
+                    "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": seen,
+                    "distinct_devices": len({(r["device_uuid"] or r["device_index"]) for r in seen}),
+                    "launched_by": "bench.py itself (child ranks)" if os.environ.get("RFX_BENCH_SELF_LAUNCHED") == "1" else "external launcher",
                     "speedup_vs_n1_same_workload": round((args.steps / elapsed) / n1["value"], 3) if n1 else None,
                     "note": "rooflines are rank 0's share of each launch (1/N of the batch); cpu_baseline is reported at N = 1 only"})
         if rooms is not None:
@@ -519,8 +531,48 @@ def main_sharded(args, dist, rank, world, device):
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without an external launcher: start the N ranks as FRESH child processes (torch.distributed.run,
+    rendezvous on 127.0.0.1) and leave with their status.  This parent has not touched the GPU (no HIP call, no
+    torch.cuda.is_available()) and never does; nothing is exec'ed over a running process.  The children's stdout / stderr are
+    this process's own, so rank 0's JSON line streams through unchanged."""
+    import subprocess
+    port = os.environ.get("RFX_BENCH_MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RFX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        rc = child.wait()
+    except KeyboardInterrupt:
+        child.terminate()              # the exact child we started, never a pattern
+        rc = child.wait()
+    if rc != 0:
+        print(f"[bench] the {args.gpus}-rank run ended with status {rc}", file=sys.stderr, flush=True)
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args)            # before any torch.cuda call
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                         "they must agree (the line's n_gpus is the number of ranks that ran)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

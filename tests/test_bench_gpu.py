@@ -68,3 +68,38 @@ def test_bench_two_ranks_failure_is_a_nonzero_exit():
     assert res.returncode != 0
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and "error" in json.loads(lines[0])
+
+
+def _self_launch(extra, timeout=600, env_extra=None):
+    """`python bench.py --gpus N ...` with NO launcher and no WORLD_SIZE: the command the driver runs"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RFX_DIST_BACKEND="gloo")
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """round 5's bench parsed --gpus and never read it: `python bench.py --gpus 8` printed an N = 1 line.  Now the flag starts
+    the ranks (fresh children, the parent never touches the GPU) and the line says what the process group saw."""
+    res = _self_launch(["--gpus", "2", "--steps", "6", "--warmup", "5", "--first-iters", "5", "--sharded-config", "office0",
+                        "--shard-field", "levels", "--no-n1"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["value"] > 0
+    assert sorted(r["rank"] for r in d["rank_devices"]) == [0, 1]
+    assert len({r["pid"] for r in d["rank_devices"]}) == 2                 # two processes
+    assert d["launched_by"].startswith("bench.py itself")
+    assert "starting 2 ranks" in res.stderr
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launch_child_failure_is_a_nonzero_exit():
+    res = _self_launch(["--gpus", "2", "--steps", "2", "--warmup", "1", "--first-iters", "2", "--sharded-config", "no_such_config",
+                        "--one-scene-timeout", "60"], timeout=300)
+    assert res.returncode != 0
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "error" in json.loads(lines[0])
