@@ -300,8 +300,8 @@ static size_t scatter_scratch_floats(int64_t n, int n_levels) {
     const size_t slots = (size_t)n + (size_t)((n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS + 1) * SCATTER_THREADS;
     const size_t sweep = slots * (size_t)(2 * n_levels + 3);
     if (n < SCATTER_MIN_POINTS) return sweep;              // below it nothing is staged or binned (direct atomics)
-    const size_t n_blk = (size_t)((n + 2 * 1024 - 1) / (2 * 1024));         // BIN_THREADS * BIN_PPT points per block
-    const size_t one_binned = (size_t)n * 8 * 3 + 2 * n_blk * 1024 + 2 * (1024 + 1) + 8;      // SCATTER_BIN_MAX_SEGMENTS = 1024
+    const size_t n_blk = (size_t)((n + 4 * 1024 - 1) / (4 * 1024));         // BIN_THREADS * BIN_PPT points per sort block
+    const size_t one_binned = n_blk * (4 * 1024 * 8) * 4 + n_blk * (1024 + 1) + 8;           // BIN_BLOCK_RECS 16-byte records; SCATTER_BIN_MAX_SEGMENTS = 1024
     return std::max(sweep, one_binned);
 }
 
@@ -545,14 +545,24 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 // ---------------------------------------------------------------- E1 backward, binned scatter (large tables)
 // A level cut into many LDS segments makes every segment's block scan every point for the few corners that land in it:
 // 32-256 scans of the point list per level at T = 2^19-2^21.  Such a level (>= SCATTER_BIN_MIN_SEGMENTS segments) is
-// instead sorted by segment first (the levels in groups, see BinLevels):
-//   bin_count   : per block of 1 024 points, an LDS histogram of the segments its 8 x points corners fall into
-//   bin_scan    : exclusive offsets per (segment, block): every block gets a range of its own inside every segment's bin
-//   bin_records : the same walk again; each corner becomes a 12-byte record (slot in segment, w*g0, w*g1) at the next
-//                 free place of its block's range (LDS cursors)
-//   bin_reduce  : the blocks of a segment add its bin's records into 128 KB of LDS (double accumulators) and add the
-//                 non-zero sums to the table with contiguous float atomics.
-// Records of one level take 96 B per point: they re-use the staging buffer the LDS sweep of the small levels is done with.
+// instead sorted by segment first, block by block (the levels in groups, see BinLevels):
+//   bin_sort   : a block takes 4 096 points, ONE walk: it locates and hashes every corner once, ranks each x-PAIR of corners
+//                inside its segment with an LDS counter (the rank stays in a register), scans the <= 1 024 counters in LDS and
+//                writes each pair as a 16-byte record at `offset of its segment + rank` inside the block's OWN region: the
+//                records of a block come out sorted by segment, and the block leaves its exclusive offsets [n_seg + 1] for the
+//                readers.  No global histogram, no global scan, no second walk over the points (rounds 3-5 ran bin_count ->
+//                bin_scan -> bin_records: the points located and hashed twice, and one 1 024-thread block per level of pure
+//                latency in between).
+//   bin_reduce : a block owns one segment and one share of the sort blocks; its 16 waves walk the runs those blocks hold for the
+//                segment, add them into 128 KB of LDS (double accumulators) and add the non-zero sums to the table with
+//                contiguous float atomics.
+// Why pairs.  The kernels move records at the memory system's pace (measured, round 6: 12-byte records per corner, 96 B per
+// point and level written and read again, at 3.7 TB/s), so the record is what to shrink.  The two corners of a cell that
+// differ in x only fall into the SAME segment: on a dense level they are neighbours in the table, on a hashed one the x
+// coordinate enters the index un-multiplied (tiny-cuda-nn's first prime is 1) and a level's resolution is below the 8 192
+// entries of a segment, so x never reaches the segment bits.  One record (both slots, fx, w_yz g0, w_yz g1) serves both:
+// 64 B per point and level instead of 96, and half the rank atomics.  A pair that does straddle a segment boundary (a
+// dense level's entries 8 191 | 8 192 mod 8 192, or a resolution above 8 192) becomes two one-corner records.
 #ifndef SCATTER_BIN_MIN_SEGMENTS
 #define SCATTER_BIN_MIN_SEGMENTS 12      // with grouped launches: 12 against 16 = -5 % at scene0000 (its 15-segment level), 10 and 8 no better
 #endif
@@ -560,232 +570,337 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #define SCATTER_BIN_MAX_SEGMENTS 1024
 #endif
 constexpr int BIN_THREADS = 1024;
-constexpr unsigned BIN_SEG_SHIFT = 13, BIN_SEG = 1u << BIN_SEG_SHIFT;        // 8 192 entries x 2 doubles = 128 KB
+#ifndef BIN_SEG_SHIFT_N
+#define BIN_SEG_SHIFT_N 13
+#endif
+constexpr unsigned BIN_SEG_SHIFT = BIN_SEG_SHIFT_N, BIN_SEG = 1u << BIN_SEG_SHIFT;        // 8 192 entries x 2 doubles = 128 KB
 constexpr int BIN_MAX_SEGS = 1024;
 
-struct BinRec { unsigned slot; float a, b; };
+// slots: slot of the x = 0 corner | slot of the x = 1 corner << 13 | (1 << 26 when the second corner is part of the record).
+// The corners receive (1 - fx) * (a, b) and fx * (a, b); a one-corner record has fx = 0 and its whole weight in (a, b).
+struct __attribute__((aligned(16))) BinRec { unsigned slots; float fx, a, b; };
+static_assert(sizeof(BinRec) == 16, "records are moved as one 16-byte access");
+constexpr unsigned BIN_REC_FLOATS = sizeof(BinRec) / sizeof(float);
 
-__device__ __forceinline__ bool bin_load(const ScatterSrc& a, const ScatterSrc& b, int64_t j, int level, float x[3], float2& gv) {
-    const bool in_a = j < a.n;
-    const ScatterSrc& s = in_a ? a : b;
-    const int64_t p = in_a ? j : j - a.n;
-    if (p >= s.n || (s.n_sel && p >= *s.n_sel)) return false;
-    gv = reinterpret_cast<const float2*>(s.dfeat + p * (int64_t)s.ld)[level];
-    if (gv.x == 0.f && gv.y == 0.f) return false;
-    const int64_t px = s.perm ? s.perm[p] : p;
-    x[0] = s.x01[px * 3]; x[1] = s.x01[px * 3 + 1]; x[2] = s.x01[px * 3 + 2];
-    return true;
+// The BIN_PPT points of a thread (j0, j0 + stride, ...), all loads issued together: a load under a per-lane condition makes the
+// compiler wait for the one before it (the destination keeps its old value in the masked lanes), which turned a thread's
+// points into a chain of 3 BIN_PPT round trips.  So every lane loads -- inactive ones from a clamped, valid row -- and the
+// conditions select afterwards: two round trips per thread (gradient rows + selection, then positions).
+template <int N>
+__device__ __forceinline__ void bin_load(const ScatterSrc& a, const ScatterSrc& b, int64_t j0, int64_t stride, int level,
+                                         float x[N][3], float2 gv[N], bool act[N]) {
+    const int64_t na = a.n_sel ? min(a.n, (int64_t)*a.n_sel) : a.n;       // (only the first source carries a selection)
+    int64_t pa[N], pb[N];
+    bool in_a[N];
+    int px[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int64_t j = j0 + q * stride;
+        in_a[q] = j < a.n;
+        const int64_t p = in_a[q] ? j : j - a.n;
+        act[q] = in_a[q] ? p < na : p < b.n;
+        pa[q] = in_a[q] && act[q] ? p : 0;                                    // row 0 exists whenever the source has points
+        pb[q] = !in_a[q] && act[q] ? p : 0;
+    }
+    // straight-line loads: a source without points lends the other one's (valid) arrays to the clamped row-0 loads
+    const float* __restrict__ dfa = a.n > 0 ? a.dfeat : b.dfeat;
+    const float* __restrict__ dfb = b.n > 0 ? b.dfeat : a.dfeat;
+    const float* __restrict__ xsa = a.n > 0 ? a.x01 : b.x01;
+    const float* __restrict__ xsb = b.n > 0 ? b.x01 : a.x01;
+    const int64_t lda = a.n > 0 ? a.ld : b.ld, ldb = b.n > 0 ? b.ld : a.ld;
+    const int* __restrict__ perm = a.n > 0 ? a.perm : nullptr;
+    float2 ga[N], gb[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        ga[q] = reinterpret_cast<const float2*>(dfa + pa[q] * lda)[level];
+        gb[q] = reinterpret_cast<const float2*>(dfb + pb[q] * ldb)[level];
+        px[q] = (int)pa[q];
+    }
+    if (perm) {                       // block-uniform
+#pragma unroll
+        for (int q = 0; q < N; ++q) px[q] = perm[pa[q]];
+    }
+    float xa[N][3], xb[N][3];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { xa[q][d] = xsa[(int64_t)px[q] * 3 + d]; xb[q][d] = xsb[pb[q] * 3 + d]; }
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        gv[q] = in_a[q] ? ga[q] : gb[q];
+        x[q][0] = in_a[q] ? xa[q][0] : xb[q][0]; x[q][1] = in_a[q] ? xa[q][1] : xb[q][1]; x[q][2] = in_a[q] ? xa[q][2] : xb[q][2];
+        act[q] = act[q] && (gv[q].x != 0.f || gv[q].y != 0.f);
+        if (!act[q]) { gv[q] = make_float2(0.f, 0.f); x[q][0] = 0.5f; x[q][1] = 0.5f; x[q][2] = 0.5f; }
+    }
 }
 
 // LDS atomics to ONE address from all 64 lanes serialise (a dense level's neighbouring points fall into the same segment):
 // when the whole wave agrees on the segment, one lane adds for all and the lanes take consecutive ranks.
+template <bool TRY_UNIFORM>
 __device__ __forceinline__ unsigned bin_take(unsigned* counters, unsigned seg, bool active) {
     const unsigned long long m = __ballot(active);
     if (m == 0ull) return 0u;
-    const int leader = __ffsll((long long)m) - 1;
-    const unsigned seg0 = __shfl(seg, leader);
-    const int lane = threadIdx.x & 63;
-    if (__ballot(active && seg != seg0) == 0ull) {          // wave-uniform segment
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&counters[seg0], (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (TRY_UNIFORM) {
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned seg0 = __shfl(seg, leader);
+        const int lane = threadIdx.x & 63;
+        if (__ballot(active && seg != seg0) == 0ull) {          // wave-uniform segment
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&counters[seg0], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        }
     }
     return active ? atomicAdd(&counters[seg], 1u) : 0u;
 }
 
-constexpr int BIN_PPT = 2;            // points per thread in the count / record kernels: 2 048 points per block
-static_assert(BIN_THREADS * BIN_PPT == 2 * 1024 && SCATTER_BIN_MAX_SEGMENTS <= 1024 && BIN_MAX_SEGS <= 1024, "scatter_scratch_floats() prices one binned level with these");
+constexpr int BIN_PPT = 4;            // points per thread of the sort kernel: 4 096 points per block
+constexpr unsigned BIN_BLOCK_RECS = BIN_THREADS * BIN_PPT * 8;      // records a sort block writes at most (every pair split): its region
+static_assert(BIN_THREADS * BIN_PPT == 4 * 1024 && SCATTER_BIN_MAX_SEGMENTS <= 1024 && BIN_MAX_SEGS <= BIN_THREADS, "scatter_scratch_floats() prices one binned level with these; one scan thread per segment");
+static_assert(BIN_BLOCK_RECS <= 65536, "ranks are packed as two 16-bit halves");
 
-// The binned levels of one sweep that are in flight TOGETHER (as many as the caller's scratch holds records for: 96 B per point
-// and level).  One level at a time meant four launches per level -- 44 dependent launches per scatter at T = 2^19, each a few
-// hundred blocks at most -- so the kernels below take a group of levels: blockIdx.y (count, records), blockIdx.x (scan) or a
-// flattened (level, segment) index (reduce) says which.
+// The binned levels of one sweep that are in flight TOGETHER (as many as the caller's scratch holds records for):
+// blockIdx.y (sort) or a flattened (level, segment, share) index (reduce) says which level a block works on.
 struct BinLevels {
     int n;                                   // levels in the group
     Level lv[RFX_MAX_LEVELS];
     int level[RFX_MAX_LEVELS];               // index of the level in the grid (its column pair in dfeat)
     int n_seg[RFX_MAX_LEVELS];
-    int seg_base[RFX_MAX_LEVELS + 1];        // first flattened (level, segment) index of each level
-    unsigned* counts[RFX_MAX_LEVELS];        // [blk][seg]
-    unsigned* offsets[RFX_MAX_LEVELS];       // [blk][seg]
-    unsigned* seg_start[RFX_MAX_LEVELS];     // [n_seg + 1]
-    unsigned* chunk_start[RFX_MAX_LEVELS];   // [n_seg + 1]: first BIN_CHUNK-record piece of each segment's bin (see bin_reduce_kernel)
-    int blk_base[RFX_MAX_LEVELS + 1];        // first reduce block of each level (an upper bound of its pieces)
-    BinRec* rec[RFX_MAX_LEVELS];
+    int parts[RFX_MAX_LEVELS];               // reduce blocks per segment: each takes a contiguous share of the sort blocks
+    int blk_base[RFX_MAX_LEVELS + 1];        // first reduce block of each level (n_seg * parts blocks per level)
+    unsigned* excl[RFX_MAX_LEVELS];          // [n_blk][n_seg + 1]: where each segment's run starts inside a sort block's region
+    BinRec* rec[RFX_MAX_LEVELS];             // [n_blk][BIN_BLOCK_RECS]
 };
+#ifndef BIN_DENSE_FACTOR
+#define BIN_DENSE_FACTOR 4.0
+#endif
 #ifndef BIN_CHUNK_RECORDS
-#define BIN_CHUNK_RECORDS 32768
+#define BIN_CHUNK_RECORDS 16384
 #endif
-constexpr unsigned BIN_CHUNK = BIN_CHUNK_RECORDS;      // records one reduce block adds at most
+constexpr unsigned BIN_CHUNK = BIN_CHUNK_RECORDS;      // (pair) records one reduce block is meant to add (sets `parts`)
 
-__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(BinLevels B, ScatterSrc a, ScatterSrc b, int n_blk) {
-    __shared__ unsigned h[BIN_MAX_SEGS];
-    const int g = blockIdx.y;
+template <bool DENSE>
+__device__ __forceinline__ void bin_sort_body(const BinLevels& B, int g, const ScatterSrc& a, const ScatterSrc& b, unsigned* h, unsigned* wsum) {
     const Level lv = B.lv[g];
     const int n_seg = B.n_seg[g], level = B.level[g];
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) h[i] = 0u;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < n_seg) h[t] = 0u;
     __syncthreads();
+    // ---- the one walk: corners, their segment and the pair's rank inside (block, segment)
+    unsigned i0[BIN_PPT][4], i1[BIN_PPT][4], rank[BIN_PPT][4];
+    float fr[BIN_PPT][3];
+    float2 gv[BIN_PPT];
+    bool act[BIN_PPT];
+    float xq[BIN_PPT][3];
+    bin_load<BIN_PPT>(a, b, (int64_t)blockIdx.x * BIN_PPT * BIN_THREADS + t, BIN_THREADS, level, xq, gv, act);
 #pragma unroll
     for (int q = 0; q < BIN_PPT; ++q) {
-        const int64_t j = ((int64_t)blockIdx.x * BIN_PPT + q) * BIN_THREADS + threadIdx.x;
-        float x[3] = {0.5f, 0.5f, 0.5f};
-        float2 gv;
-        const bool act = bin_load(a, b, j, level, x, gv);
-        const Cell c = locate(lv, x);
-        unsigned idx8[8];
-        corner_indices(lv, c, idx8);
+        const Cell c = locate(lv, xq[q]);
+        fr[q][0] = c.f[0]; fr[q][1] = c.f[1]; fr[q][2] = c.f[2];
+        unsigned idx[8];
+        corner_indices(lv, c, idx);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bin_take(h, idx8[k] >> BIN_SEG_SHIFT, act);
-    }
-    __syncthreads();
-    unsigned* __restrict__ counts = B.counts[g];
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) counts[(size_t)blockIdx.x * n_seg + i] = h[i];      // [blk][seg]
-}
-
-// counts / offsets are [blk][seg].  offsets[blk][seg] = start of block blk's range in segment seg's bin; seg_start[seg] =
-// start of the bin (seg_start[n_seg] = total); chunk_start: the bins cut into pieces for the reduce kernel.  One block per
-// level, one THREAD per segment (n_seg <= 1 024): every pass reads a row of counts per step, coalesced across the threads.
-// (A wave per segment with lanes over the blocks, [seg][blk] layout, took 53 us at T = 2^21: 16 segments per wave in turn.)
-__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(BinLevels B, int n_blk) {
-    __shared__ unsigned tot[BIN_MAX_SEGS + 1], first[BIN_MAX_SEGS];
-    const int g = blockIdx.x;
-    const int n_seg = B.n_seg[g];
-    const unsigned* __restrict__ counts = B.counts[g];
-    unsigned* __restrict__ offsets = B.offsets[g];
-    unsigned* __restrict__ seg_start = B.seg_start[g];
-    unsigned* __restrict__ chunk_start = B.chunk_start[g];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sg = threadIdx.x;
-    unsigned mine = 0;
-    if (sg < n_seg) {
-#pragma unroll 8
-        for (int b = 0; b < n_blk; ++b) mine += counts[(size_t)b * n_seg + sg];
-        tot[sg] = mine;
-    }
-    __syncthreads();
-    if (wv < 2) {       // wave 0: exclusive scan of the segment totals; wave 1: of their piece counts.  A run of segments per lane
-        const int per = (n_seg + 63) / 64;
-        unsigned run = 0;
-        for (int i = 0; i < per; ++i) {
-            const int sidx = lane * per + i;
-            if (sidx < n_seg) run += wv == 0 ? tot[sidx] : (tot[sidx] + BIN_CHUNK - 1) / BIN_CHUNK;
-        }
-        unsigned incl = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        unsigned start = incl - run;
-        unsigned* __restrict__ dst = wv == 0 ? seg_start : chunk_start;
-        for (int i = 0; i < per; ++i) {
-            const int sidx = lane * per + i;
-            if (sidx < n_seg) {
-                dst[sidx] = start;
-                if (wv == 0) first[sidx] = start;
-                start += wv == 0 ? tot[sidx] : (tot[sidx] + BIN_CHUNK - 1) / BIN_CHUNK;
-            }
-        }
-        if (lane == 63) dst[n_seg] = incl;
-    }
-    __syncthreads();
-    if (sg < n_seg) {
-        unsigned run = first[sg];
-#pragma unroll 8
-        for (int b = 0; b < n_blk; ++b) {
-            const unsigned v = counts[(size_t)b * n_seg + sg];
-            offsets[(size_t)b * n_seg + sg] = run;
-            run += v;
-        }
-    }
-}
-
-__global__ __launch_bounds__(BIN_THREADS) void bin_records_kernel(BinLevels B, ScatterSrc a, ScatterSrc b, int n_blk) {
-    __shared__ unsigned cur[BIN_MAX_SEGS];
-    const int g = blockIdx.y;
-    const Level lv = B.lv[g];
-    const int n_seg = B.n_seg[g], level = B.level[g];
-    const unsigned* __restrict__ offsets = B.offsets[g];
-    BinRec* __restrict__ rec = B.rec[g];
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS) cur[i] = offsets[(size_t)blockIdx.x * n_seg + i];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < BIN_PPT; ++q) {
-        const int64_t j = ((int64_t)blockIdx.x * BIN_PPT + q) * BIN_THREADS + threadIdx.x;
-        float x[3] = {0.5f, 0.5f, 0.5f};
-        float2 gv = make_float2(0.f, 0.f);
-        const bool act = bin_load(a, b, j, level, x, gv);
-        const Cell c = locate(lv, x);
-        unsigned idx8[8];
-        corner_indices(lv, c, idx8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float w = corner_weight(c, k);
-            const unsigned pos = bin_take(cur, idx8[k] >> BIN_SEG_SHIFT, act);
-            if (act) {
-                BinRec r;
-                r.slot = idx8[k] & (BIN_SEG - 1u); r.a = w * gv.x; r.b = w * gv.y;
-                rec[pos] = r;
-            }
-        }
-    }
-}
-
-#ifdef BIN_PROF          // dev builds only (tools/bin_prof.py): per-block clocks of the last bin_reduce launch: start, zeroed, added, end
-__device__ unsigned long long g_bin_prof[4 * 4096];
-#define BIN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_bin_prof[4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+        for (int k = 0; k < 4; ++k) {
+            i0[q][k] = idx[2 * k]; i1[q][k] = idx[2 * k + 1];
+            const unsigned s0 = idx[2 * k] >> BIN_SEG_SHIFT, s1 = idx[2 * k + 1] >> BIN_SEG_SHIFT;
+#if defined(BIN_DBG) && (BIN_DBG & 8)
+            const unsigned r0 = (unsigned)(q * 4 + k), r1 = 0;
 #else
-#define BIN_STAMP(k) do { } while (0)
+            const unsigned r0 = bin_take<DENSE>(h, s0, act[q]);
+            const unsigned r1 = bin_take<false>(h, s1, act[q] && s1 != s0);       // (a wave without a split pair leaves at its ballot)
 #endif
+            rank[q][k] = r0 | r1 << 16;
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the segment counters, one thread per segment
+    const unsigned v = t < n_seg ? h[t] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        const unsigned w = lane < BIN_THREADS / 64 ? wsum[lane] : 0u;
+        unsigned wi = w;
+#pragma unroll
+        for (int d = 1; d < BIN_THREADS / 64; d <<= 1) {
+            const unsigned u = __shfl_up(wi, d);
+            if (lane >= d) wi += u;
+        }
+        if (lane < BIN_THREADS / 64) wsum[lane] = wi - w;
+    }
+    __syncthreads();
+    const unsigned excl = incl - v + wsum[wv];
+    unsigned* __restrict__ eo = B.excl[g] + (size_t)blockIdx.x * (n_seg + 1);
+    if (t < n_seg) { h[t] = excl; eo[t] = excl; }
+    if (t == n_seg - 1) eo[n_seg] = excl + v;
+    __syncthreads();
+    // ---- the records, from the registers
+    BinRec* __restrict__ rec = B.rec[g] + (size_t)blockIdx.x * BIN_BLOCK_RECS;
+#pragma unroll
+    for (int q = 0; q < BIN_PPT; ++q) {
+        if (!act[q]) continue;
+        const float fx = fr[q][0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wyz = ((k & 1) ? fr[q][1] : 1.0f - fr[q][1]) * ((k >> 1) ? fr[q][2] : 1.0f - fr[q][2]);
+            const unsigned s0 = i0[q][k] >> BIN_SEG_SHIFT, s1 = i1[q][k] >> BIN_SEG_SHIFT;
+            const unsigned l0 = i0[q][k] & (BIN_SEG - 1u), l1 = i1[q][k] & (BIN_SEG - 1u);
+            const float ga = wyz * gv[q].x, gb = wyz * gv[q].y;
+            if (s0 == s1) {
+                BinRec r;
+                r.slots = l0 | l1 << BIN_SEG_SHIFT | 1u << 26; r.fx = fx; r.a = ga; r.b = gb;
+#if defined(BIN_DBG) && (BIN_DBG & 4)
+                if (fx == 12345.f)
+#endif
+                rec[h[s0] + (rank[q][k] & 0xffffu)] = r;
+            } else {
+                BinRec r;
+                r.slots = l0; r.fx = 0.f; r.a = (1.0f - fx) * ga; r.b = (1.0f - fx) * gb;
+                rec[h[s0] + (rank[q][k] & 0xffffu)] = r;
+                r.slots = l1; r.a = fx * ga; r.b = fx * gb;
+                rec[h[s1] + (rank[q][k] >> 16)] = r;
+            }
+        }
+    }
+}
 
-// One block adds one PIECE of a segment's bin (at most BIN_CHUNK records) into 128 KB of LDS and adds the non-zero sums to the
-// table.  Pieces, not segments: on a dense level a segment is a slab of space, and a scene fills a few of them (one block per
-// segment took 230 us on the fullest while the rest were done in 20); the scan kernel cut every bin into pieces and left
-// their prefix in chunk_start.  The grid holds an upper bound of pieces per level (n_seg + records / BIN_CHUNK); the blocks
-// behind the last piece leave at once.
-__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable) {
+__global__ __launch_bounds__(BIN_THREADS) void bin_sort_kernel(BinLevels B, ScatterSrc a, ScatterSrc b) {
+    __shared__ unsigned h[BIN_MAX_SEGS + 1];
+    __shared__ unsigned wsum[BIN_THREADS / 64];
+    const int g = blockIdx.y;
+    if (B.lv[g].hashed) bin_sort_body<false>(B, g, a, b, h, wsum);      // block-uniform
+    else bin_sort_body<true>(B, g, a, b, h, wsum);
+}
+
+#ifndef BIN_RUNS_N
+#define BIN_RUNS_N 4
+#endif
+constexpr int BIN_RUNS = BIN_RUNS_N;       // runs a wave of the reduce kernel reads together (2 x 64 records of each in flight)
+
+__device__ __forceinline__ void bin_add(double* acc, const BinRec& q) {
+#if defined(BIN_DBG) && (BIN_DBG & 1)
+    if (q.fx != 12345.f) return;
+#endif
+    const unsigned l0 = q.slots & (BIN_SEG - 1u), l1 = (q.slots >> BIN_SEG_SHIFT) & (BIN_SEG - 1u);
+    const float u = 1.0f - q.fx;
+    atomicAdd(&acc[2 * l0], (double)(u * q.a));
+    atomicAdd(&acc[2 * l0 + 1], (double)(u * q.b));
+    if (q.slots >> 26) {
+        atomicAdd(&acc[2 * l1], (double)(q.fx * q.a));
+        atomicAdd(&acc[2 * l1 + 1], (double)(q.fx * q.b));
+    }
+}
+
+// One block adds, for ONE segment, the runs a contiguous share of the sort blocks hold for it.  Shares, because on a dense
+// level a segment is a slab of space and a scene fills a few of them: `parts` blocks per segment keep the fullest segment's
+// work spread (launch_binned_levels picks it per level); a (segment, share) without records leaves before it touches its LDS.
+// Wave w takes the sort blocks b0 + w, b0 + w + 16, ...: a lane per block fetches the run's bounds up front (no dependent
+// round trip per run), then the runs are read BIN_RUNS at a time, 128 records of each, before any of them is added (a block's time is a chain of
+// round trips: 16 waves, one block per CU).
+__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable, int n_blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     double* acc = reinterpret_cast<double*>(acc_raw);
-    __shared__ int seg_s;
-    BIN_STAMP(0);
     int g = 0;
     while (g + 1 < B.n && (int)blockIdx.x >= B.blk_base[g + 1]) ++g;
     const Level lv = B.lv[g];
-    const int n_seg = B.n_seg[g];
-    const unsigned* __restrict__ chunk_start = B.chunk_start[g];
-    const unsigned piece = blockIdx.x - (unsigned)B.blk_base[g];
-    if (piece >= chunk_start[n_seg]) return;                // block-uniform
-    for (int i = threadIdx.x; i < n_seg; i += BIN_THREADS)
-        if (chunk_start[i] <= piece && piece < chunk_start[i + 1]) seg_s = i;      // exactly one i (empty segments have no piece)
-    __syncthreads();
-    const unsigned seg = (unsigned)seg_s, base = seg << BIN_SEG_SHIFT;
+    const int n_seg = B.n_seg[g], parts = B.parts[g];
+    const unsigned local = blockIdx.x - (unsigned)B.blk_base[g];
+    const unsigned seg = local / (unsigned)parts, part = local % (unsigned)parts;
+    const int b0 = (int)((int64_t)part * n_blk / parts), b1 = (int)((int64_t)(part + 1) * n_blk / parts);
+    const unsigned* __restrict__ ex = B.excl[g];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NW = BIN_THREADS / 64;
+    const unsigned base = seg << BIN_SEG_SHIFT;
     const unsigned cnt = min(BIN_SEG, lv.size - base);
-    const unsigned* __restrict__ seg_start = B.seg_start[g];
-    const BinRec* __restrict__ rec = B.rec[g];
-    // the segment's pieces are equally long (ceil(records / pieces)), not BIN_CHUNK and a remainder
-    const unsigned s0 = seg_start[seg], s1 = seg_start[seg + 1], n_pc = chunk_start[seg + 1] - chunk_start[seg];
-    const unsigned len = (s1 - s0 + n_pc - 1) / n_pc;
-    const unsigned r0 = min(s1, s0 + (piece - chunk_start[seg]) * len), r1 = min(s1, r0 + len);
-    for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) acc[i] = 0.0;
-    __syncthreads();
-    BIN_STAMP(1);
-    for (unsigned r = r0 + threadIdx.x; r < r1; r += BIN_THREADS) {
-        const BinRec q = rec[r];
-        atomicAdd(&acc[2 * q.slot], (double)q.a);
-        atomicAdd(&acc[2 * q.slot + 1], (double)q.b);
+    bool zeroed = false;
+    // 64 x NW sort blocks per round (one round up to 1 024 sort blocks = 4 M points)
+    for (int r0 = b0; r0 < b1; r0 += 64 * NW) {
+        const int mine = r0 + wv + NW * lane;            // lane j holds the bounds of the wave's j-th run
+        unsigned e0 = 0, e1 = 0;
+        if (mine < b1) {
+            const unsigned* q = ex + (size_t)mine * (n_seg + 1) + seg;
+            e0 = q[0]; e1 = q[1];
+        }
+        const int any = __syncthreads_or(e1 > e0);       // block-uniform
+        if (!any) continue;
+        if (!zeroed) {
+            for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) acc[i] = 0.0;
+            __syncthreads();
+            zeroed = true;
+        }
+        const unsigned long long have = __ballot(e1 > e0);
+        const int n_runs = have ? 64 - __clzll((long long)have) : 0;          // wave-uniform
+        for (int j = 0; j < n_runs; j += BIN_RUNS) {
+            unsigned s0[BIN_RUNS], s1[BIN_RUNS];
+            const BinRec* __restrict__ rp[BIN_RUNS];
+            BinRec q[BIN_RUNS][2];
+            bool ok[BIN_RUNS][2];
+#pragma unroll
+            for (int u = 0; u < BIN_RUNS; ++u) {
+                const int jj = min(j + u, 63);
+                s0[u] = __shfl(e0, jj); s1[u] = j + u < 64 ? __shfl(e1, jj) : s0[u];
+                rp[u] = B.rec[g] + (size_t)min(r0 + wv + NW * jj, b1 - 1) * BIN_BLOCK_RECS;          // (a valid region for the lanes past the last run)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    ok[u][k] = s0[u] + 64u * k + lane < s1[u];
+                    q[u][k] = rp[u][min(s0[u] + 64u * k + lane, BIN_BLOCK_RECS - 1u)];        // unconditional: see bin_load
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BIN_RUNS; ++u)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (ok[u][k]) bin_add(acc, q[u][k]);
+#pragma unroll
+            for (int u = 0; u < BIN_RUNS; ++u) {          // runs longer than two waves (dense levels): the rest, four loads in flight
+                if (s1[u] - s0[u] <= 128u) continue;      // wave-uniform
+                for (unsigned r = s0[u] + 128u + lane; r < s1[u]; r += 256u) {
+                    BinRec t4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t4[k] = rp[u][min(r + 64u * k, BIN_BLOCK_RECS - 1u)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (r + 64u * k < s1[u]) bin_add(acc, t4[k]);
+                }
+            }
+        }
     }
+    if (!zeroed) return;                                  // block-uniform
+#if defined(BIN_DBG) && (BIN_DBG & 2)
+    if (cnt != 12345u) return;
+#endif
     __syncthreads();
-    BIN_STAMP(2);
     float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
+    #ifndef BIN_FLUSH_ATOMIC
+    if (parts == 1 && (cnt & 1u) == 0u && ((uintptr_t)out & 15) == 0) {
+        // this block is the segment's only writer in the launch (and the other kernels of a scatter touch other levels): a plain
+        // read-modify-write, 16 bytes per lane.  The float atomics this replaces ran at 2e11 per second chip-wide -- 4.2 M of them
+        // per level of 2^21 entries were most of the kernel (round 6: 254 us for 12 levels with them)
+        float4* __restrict__ o4 = reinterpret_cast<float4*>(out);
+        constexpr int NV = BIN_SEG / 2 / BIN_THREADS;       // 4: all of a thread's loads are issued before the first add
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = o4[min(threadIdx.x + k * BIN_THREADS, cnt / 2 - 1u)];          // unconditional: see bin_load
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const unsigned i = threadIdx.x + k * BIN_THREADS;
+            if (i < cnt / 2) {
+                v[k].x += (float)acc[4 * i]; v[k].y += (float)acc[4 * i + 1]; v[k].z += (float)acc[4 * i + 2]; v[k].w += (float)acc[4 * i + 3];
+                o4[i] = v[k];
+            }
+        }
+        return;
+    }
+#endif
     for (unsigned i = threadIdx.x; i < cnt * 2; i += BIN_THREADS) {
         const float v = (float)acc[i];
         if (v != 0.f) atomicAdd(out + i, v);                // contiguous float atomics: the memory side's fast path
     }
-#ifdef BIN_PROF
-    __syncthreads();
-#endif
-    BIN_STAMP(3);
 }
 
 static bool level_is_binned(const rfx_grid_desc& g, int l) {
@@ -793,21 +908,28 @@ static bool level_is_binned(const rfx_grid_desc& g, int l) {
     return segs >= (unsigned)SCATTER_BIN_MIN_SEGMENTS && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
 }
 
-// scratch one binned level needs: its records (8 per point) + counts and offsets [seg][blk] + the bins' starts
+static inline size_t bin_sort_blocks(int64_t n_all) { return (size_t)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT)); }
+
+// scratch one binned level needs: the sort blocks' record regions + their exclusive offsets [n_blk][n_seg + 1]
 static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) {
     const size_t n_seg = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
-    const size_t n_blk = (size_t)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
-    return (size_t)n_all * 8 * 3 + 2 * n_blk * n_seg + 2 * (n_seg + 1) + 4;      // (+4: keeps the next level's records 16-byte aligned)
+    const size_t n_blk = bin_sort_blocks(n_all);
+    return n_blk * BIN_BLOCK_RECS * BIN_REC_FLOATS + ((n_blk * (n_seg + 1) + 3) & ~(size_t)3) + 4;      // (records stay 16-byte aligned; + 4: the alignment slack)
 }
 
-// the binned levels `levels[0..n_lv)` through the four kernels above, as many levels per group of launches as the scratch
+// the binned levels `levels[0..n_lv)` through the two kernels above, as many levels per group of launches as the scratch
 // holds (at least one: the caller's minimum, rfx_grid_encode_backward_workspace_bytes = scatter_scratch_floats, covers one
 // level of any admissible segment count for every n_levels)
 static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n_lv, const ScatterSrc& a, const ScatterSrc& b,
                                 float* dtable, float* scratch, size_t scratch_floats, hipStream_t st) {
     const int64_t n_all = a.n + b.n;
-    const int n_blk = (int)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT));
+    const int n_blk = (int)bin_sort_blocks(n_all);
     const size_t lds = (size_t)BIN_SEG * 2 * sizeof(double);
+    {   // records are 16-byte accesses, the caller's workspace is 8-byte aligned: binned_level_floats() carries the slack
+        const size_t skip = (size_t)((16 - ((uintptr_t)scratch & 15)) & 15) / sizeof(float);
+        if (scratch_floats < skip) return RFX_ERR_WORKSPACE;
+        scratch += skip; scratch_floats -= skip;
+    }
     static bool attr_set[64] = {};            // per device (the attribute is per device; benign if raced)
     static const bool debug = getenv("RFX_DEBUG_BINS") != nullptr;
     int dev = 0;
@@ -820,36 +942,33 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
     while (i < n_lv) {
         BinLevels B;
         B.n = 0;
-        B.seg_base[0] = 0;
+        B.blk_base[0] = 0;
         size_t used = 0;
         while (i < n_lv && B.n < RFX_MAX_LEVELS) {
             const int l = levels[i];
             const size_t need = (binned_level_floats(g, l, n_all) + 3) & ~(size_t)3;
             if (used + need > scratch_floats) break;
             const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
-            const size_t rec_floats = (size_t)n_all * 8 * 3, cnt_words = (size_t)n_blk * n_seg;
             const int k = B.n++;
             B.lv[k].scale = g.scale[l]; B.lv[k].res = g.res[l]; B.lv[k].size = g.size[l]; B.lv[k].offset = g.offset[l]; B.lv[k].hashed = g.hashed[l];
-            B.level[k] = l; B.n_seg[k] = n_seg; B.seg_base[k + 1] = B.seg_base[k] + n_seg;
-            if (k == 0) B.blk_base[0] = 0;
-            B.blk_base[k + 1] = B.blk_base[k] + n_seg + (int)(((size_t)n_all * 8 + BIN_CHUNK - 1) / BIN_CHUNK);      // >= its pieces
+            B.level[k] = l; B.n_seg[k] = n_seg;
+            // reduce blocks per segment: ~BIN_CHUNK records each.  A hashed level spreads its 4 n_all pairs evenly over the
+            // segments; a dense level's segments are slabs of space of which a scene (and the TV lattice, a small cube) fills
+            // a fraction: priced as if a quarter of them held everything
+            const double per_seg = (double)n_all * 4.0 * (g.hashed[l] ? 1.0 : BIN_DENSE_FACTOR) / n_seg;
+            B.parts[k] = std::max(1, std::min(n_blk, (int)(per_seg / BIN_CHUNK + 0.5)));
+            B.blk_base[k + 1] = B.blk_base[k] + n_seg * B.parts[k];
             float* base = scratch + used;
             B.rec[k] = reinterpret_cast<BinRec*>(base);
-            B.counts[k] = reinterpret_cast<unsigned*>(base + rec_floats);
-            B.offsets[k] = B.counts[k] + cnt_words;
-            B.seg_start[k] = B.offsets[k] + cnt_words;
-            B.chunk_start[k] = B.seg_start[k] + n_seg + 1;
+            B.excl[k] = reinterpret_cast<unsigned*>(base + (size_t)n_blk * BIN_BLOCK_RECS * BIN_REC_FLOATS);
             used += need;
             ++i;
         }
         if (debug) fprintf(stderr, "[bins] group of %d levels (%d of %d done), %zu of %zu floats, %lld points\n", B.n, i, n_lv, used, scratch_floats, (long long)n_all);
         if (B.n == 0) return RFX_ERR_WORKSPACE;
-        for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.seg_base[k] = B.seg_base[B.n];
-        hipLaunchKernelGGL(bin_count_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(B.n), dim3(BIN_THREADS), 0, st, B, n_blk);
-        hipLaunchKernelGGL(bin_records_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b, n_blk);
         for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.blk_base[k] = B.blk_base[B.n];
-        hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable);
+        hipLaunchKernelGGL(bin_sort_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b);
+        hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable, n_blk);
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;
@@ -1728,11 +1847,6 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
     return RFX_OK;
 }
 
-#ifdef BIN_PROF
-extern "C" int rfx_debug_bin_prof(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_prof), sizeof(unsigned long long) * (size_t)std::min(n, 4 * 4096)) == hipSuccess ? 0 : -2;
-}
-#endif
 
 #ifdef SCATTER_PROF
 extern "C" int rfx_debug_scatter_prof(unsigned long long* out, int n) {
