@@ -126,7 +126,10 @@ void orc_tr_evaluate(const float* tsdf, int dx, int dy, int dz, const float* ori
                 if (vxi < 1 || vxi >= dx - 1 || vyi < 1 || vyi >= dy - 1 || vzi < 1 || vzi >= dz - 1) continue;
                 int64_t idx = (int64_t)vzi + (int64_t)vyi * dz + (int64_t)vxi * dy * dz;
                 accf += fabsf(tsdf[idx] - gt);
-                accq += (long long)(unsigned)(fabsf(tsdf[idx] - gt) * 1073741824.0f);
+                {   /* terms above 3 and NaN count as 3 (csrc/rfx_tracker.hip): defined conversion, a NaN never helps a candidate */
+                    float term = fabsf(tsdf[idx] - gt);
+                    accq += (long long)(unsigned)((term <= 3.0f ? term : 3.0f) * 1073741824.0f);
+                }
                 cnt += 1.0f;
             }
         }

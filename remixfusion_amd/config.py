@@ -84,7 +84,8 @@ _BASE: Dict[str, Any] = {   # values of configs/Replica/replica.yaml
                "t_treshold": 1, "x_config": _axis(4), "y_config": _axis(4), "z_config": _axis(3),
                "first_len": 4, "second_len": 4, "third_len": 3, "more_angel_t": 20},
     "RO": {"init_size": 0.02, "scaling_coefficient": 0.09, "particle_iter_lens": 20, "PST_size": [10240, 3072, 1024],
-           "PST_path": "PFO/fps_uniform_sphere",     # absent here: model/pst.py falls back to the packaged archive of the same templates
+           "PST_path": "PFO/fps_uniform_sphere",     # the reference's directory (relative to ITS checkout); RFX_PST_PATH overrides
+           "PST_fallback": "generated",              # nothing found: seeded templates + a warning (the package ships no template data)
            "PST_seed": 20251205, "count_search": 200, "fix_level_index": 0, "filter_weight": 2, "rgb_rose": 0,
            "save_volume": 0, "save_freq": 1000, "cut": 0, "cut_dist": 8.0, "sample_range": 0.0, "iterative_scale": True},
     "tracking": {"ignore_edge_W": 20, "ignore_edge_H": 20, "const_speed": True},

@@ -252,6 +252,12 @@ constexpr int SCATTER_THREADS = 1024;
 constexpr int SCATTER_MAX_SEGMENTS = SCATTER_MAX_SEGMENTS_N;     // T = 2^21: ~1300 segments
 constexpr int64_t SCATTER_MIN_POINTS = 4096;
 
+#if defined(SCATTER_DBG) || defined(BIN_DBG) || defined(FIELD_DBG)
+#ifndef RFX_DEV_BUILD
+#error "SCATTER_DBG / BIN_DBG / FIELD_DBG produce WRONG results on purpose (timing builds): they need -DRFX_DEV_BUILD as well"
+#endif
+#endif
+
 struct ScatterPlan {
     int seg_start[RFX_MAX_LEVELS + 1];
     int chunks;          // slices of the point list

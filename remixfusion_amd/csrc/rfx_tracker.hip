@@ -128,7 +128,11 @@ __device__ __forceinline__ void evaluate_share(const EvalK& E, int node, int sla
         if (vxi < 1 || vxi >= E.dx - 1 || vyi < 1 || vyi >= E.dy - 1 || vzi < 1 || vzi >= E.dz - 1) continue;
         if (vxi < E.x0 || vxi >= E.x1) continue;             // another slab's voxel: that rank adds this term
         const int64_t idx = (int64_t)vzi + (int64_t)vyi * E.dz + (int64_t)(vxi - E.x0) * E.dy * E.dz;
-        acc += (unsigned long long)(unsigned)(fabsf(tsdf[idx] - v.w) * 1073741824.0f);      // v_cvt_u32_f32: truncates, saturates, NaN -> 0
+        // the term as a multiple of 2^-30, truncated.  |tsdf - target| <= 2 for valid data; anything above 3 -- and a NaN, which
+        // in the reference poisons the candidate's float sum so that `m < origin` rejects it -- counts as 3: the conversion is
+        // then defined in C++ (no reliance on v_cvt_u32_f32 saturating) and a NaN makes the candidate WORSE, never better
+        const float term = fabsf(tsdf[idx] - v.w);
+        acc += (unsigned long long)(unsigned)((term <= 3.0f ? term : 3.0f) * 1073741824.0f);
         cnt += 1u;
     }
     if (live && cnt > 0u) {

@@ -21,6 +21,8 @@
 // oracle/tsdf_oracle.c; the cull and the fast path only remove work whose outcome is provably the reference's.
 #include "rfx_common.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #ifndef MV_TX
 #define MV_TX 2
@@ -40,16 +42,24 @@
 #ifndef MV_XCD_DEAL
 #define MV_XCD_DEAL 1  // mv_chunks_kernel: segments of the queue dealt to the XCDs (see the kernel)
 #endif
-#ifndef MV_FAR_WALK
-#define MV_FAR_WALK 0  // mv_rows_kernel: far end of a row refined by a walk through the max-depth tiles.  Measured (round 5):
-                       // 159 k -> 137 k items, 7.26 M -> 6.11 M in-interval lanes, mv_chunks 38.3 -> 37.0 us, mv_rows 14.5 -> 22.6 us
-                       // (a divergent per-thread loop): off
+// mv_rows_kernel<FAR_WALK>: far end of a row refined by a walk through the max-depth tiles.  Measured (round 5, office0):
+// 159 k -> 137 k items, 7.26 M -> 6.11 M in-interval lanes, mv_chunks 38.3 -> 37.0 us, mv_rows 14.5 -> 22.6 us (a divergent
+// per-thread loop): a loss where the chunk kernel is short.  Round 6: a RUN-TIME choice by the size of the footprint window
+// (rows x 64-voxel chunks per row >= MV_FAR_WALK_MIN_ITEMS: the chunk kernel then runs for hundreds of microseconds and 14 % of
+// its items are worth more than the walk -- the 1.5e9-voxel apartment volume), see the launch.
+#ifndef MV_FAR_WALK_MIN_ITEMS
+#define MV_FAR_WALK_MIN_ITEMS 6000000ll
 #endif
 #ifndef MV_XCD_SEGS
 #define MV_XCD_SEGS 32 // segments per XCD (rounded to a power-of-two segment length); 8 / 32 measured: 40.0 / 38.9 us
 #endif
 #ifndef MV_DBG_SKIP
 #define MV_DBG_SKIP 0
+#endif
+#if (defined(MV_DBG_SKIP) && MV_DBG_SKIP) || (defined(MV_DBG_NEAR) && MV_DBG_NEAR)
+#ifndef RFX_DEV_BUILD
+#error "MV_DBG_SKIP / MV_DBG_NEAR produce WRONG results on purpose (timing builds): they need -DRFX_DEV_BUILD as well"
+#endif
 #endif
 #ifndef MV_DBG_NEAR
 #define MV_DBG_NEAR 0  // timing builds only: 1 = the exact path without its stores, 2 = without its gathers
@@ -523,6 +533,7 @@ __global__ __launch_bounds__(256) void mv_frame_kernel(const float* __restrict__
 }
 
 // ---- rows kernel
+template <bool FAR_WALK>
 __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, const unsigned* __restrict__ dmax_bits,
                                                        unsigned* __restrict__ q_counts, MvItem* __restrict__ queue,
                                                        unsigned q_cap, MvItem* __restrict__ queue_risky, unsigned q_cap_risky,
@@ -530,9 +541,7 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
     // max-depth pyramid over the coarse tiles: level 0 = the tiles, level l+1 = 2x2 maxima of level l.  A row's
     // projection is a straight segment; its bounding box is looked up at the level where it spans at most 2x2 cells.
     __shared__ float pyr[MV_ROWS_LDS_TILES + MV_PYR_FLOATS];
-#if MV_FAR_WALK
-    __shared__ float dil[MV_ROWS_LDS_TILES];      // max depth over the 3x3 tiles around a tile (the far-end walk below)
-#endif
+    __shared__ float dil[FAR_WALK ? MV_ROWS_LDS_TILES : 1];      // max depth over the 3x3 tiles around a tile (the far-end walk below)
     __shared__ int lvl_off[16], lvl_w[16], lvl_h[16];
     const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     const int n_tiles = tw * th;
@@ -550,15 +559,15 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             lvl_off[15] = l + 1;
         }
         __syncthreads();
-#if MV_FAR_WALK
-        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-            const int y = i / tw, x = i - y * tw;
-            float m = 0.0f;
-            for (int yy = max(y - 1, 0); yy <= min(y + 1, th - 1); ++yy)
-                for (int xx = max(x - 1, 0); xx <= min(x + 1, tw - 1); ++xx) m = fmaxf(m, pyr[yy * tw + xx]);
-            dil[i] = m;
+        if (FAR_WALK) {
+            for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+                const int y = i / tw, x = i - y * tw;
+                float m = 0.0f;
+                for (int yy = max(y - 1, 0); yy <= min(y + 1, th - 1); ++yy)
+                    for (int xx = max(x - 1, 0); xx <= min(x + 1, tw - 1); ++xx) m = fmaxf(m, pyr[yy * tw + xx]);
+                dil[i] = m;
+            }
         }
-#endif
         n_lvl = lvl_off[15];
         for (int l = 1; l < n_lvl; ++l) {
             const int w = lvl_w[l], h = lvl_h[l], pw = lvl_w[l - 1], ph = lvl_h[l - 1];
@@ -642,14 +651,13 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             if (tm > 0.0f) {
                 // cam_z <= (deepest pixel + trunc) / (1 - ratio_eps), on the far side
                 clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz, eps_z);
-#if MV_FAR_WALK
                 // Round 5: the box of the whole projection holds the far wall even where this row ends in the floor, so the
                 // clip above left 2.4 M of 7.3 M in-interval lanes per frame behind a surface.  Walk the projection (a
                 // straight, monotonic segment) from its FAR end through the 16 x 16-pixel tiles: the part of the row inside
                 // one tile sees at most the deepest pixel of the 3 x 3 tiles around it (`dil`: the rounding of a pixel and
                 // the approximate edge crossings stay far inside that margin); if even the nearest voxel of that part lies
                 // deeper, the part is untouched and the walk goes on, else the same clip with this tile's depth ends it.
-                if (in_lds && !empty && lo <= hi && Bz != 0.0f) {
+                if (FAR_WALK && in_lds && !empty && lo <= hi && Bz != 0.0f) {
                     const bool inc = Bz > 0.0f;                    // cam_z grows with z: the far end is `hi`
                     float zf = inc ? hi : lo;
                     const float zn = inc ? lo : hi;
@@ -692,7 +700,6 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
                     }
                     if (inc) hi = zf; else lo = zf;
                 }
-#endif
                 if (!empty && lo <= hi) {
                     z0 = max(0, (int)floorf(lo) - 1);
                     z1 = min(P.dz, (int)ceilf(hi) + 2);
@@ -836,6 +843,8 @@ __device__ __forceinline__ void update_voxel(const MvParams& P, int64_t idx, flo
 constexpr int MV_NEAR_FIELDS = 6;      // voxel index, camera point, tsdf and weight as the fast path loaded them
 constexpr int MV_NEAR_CAP = 192;       // records per wave (4.5 KB; 8 blocks per CU: 147 of 160 KB); a list is drained inside
                                        // the loop above CAP - 64 (a frame of the bench leaves ~80 per wave)
+// the append / drain invariant: a drain inside the loop leaves at most CAP - 64 records, one trip then appends at most 64
+static_assert(MV_NEAR_CAP >= 128 && MV_NEAR_CAP % 64 == 0, "near lists: drained above CAP - 64, appended 64 at a time");
 struct NearList {
     float (*nb)[MV_NEAR_CAP];
     int n;                 // wave-uniform fill
@@ -1678,8 +1687,17 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         MvItem* queue_risky = queue + cap + MV_QUEUE_PAD;
         const unsigned q_cap = (unsigned)std::min<size_t>(cap, 0xffffffffu), q_cap_risky = (unsigned)std::min<size_t>(cap_risky, 0xffffffffu);
         const int blocks_main = (int)((rows_main + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS), blocks_risky = (int)((rows_risky + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS);
-        hipLaunchKernelGGL(mv_rows_kernel, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
-                           q_cap, queue_risky, q_cap_risky, blocks_main, skip);
+        // the far-end walk pays where the chunk kernel is long (see MV_FAR_WALK_MIN_ITEMS); RFX_MV_FAR_WALK=0/1 forces it (A/B runs)
+        static const char* fw_env = getenv("RFX_MV_FAR_WALK");
+        const bool far_walk = fw_env ? fw_env[0] == '1' : rows_main * nch >= MV_FAR_WALK_MIN_ITEMS;
+        static const bool fw_dbg = getenv("RFX_DEBUG_MV") != nullptr;
+        if (fw_dbg) fprintf(stderr, "[mv] rows_main %lld x %d chunks = %lld items bound, far walk %d\n", (long long)rows_main, nch, (long long)(rows_main * nch), (int)far_walk);
+        if (far_walk)
+            hipLaunchKernelGGL(mv_rows_kernel<true>, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
+                               q_cap, queue_risky, q_cap_risky, blocks_main, skip);
+        else
+            hipLaunchKernelGGL(mv_rows_kernel<false>, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
+                               q_cap, queue_risky, q_cap_risky, blocks_main, skip);
         RFX_LAUNCH_CHECK();
         // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
         // chip); small volumes need fewer.  Three instances: the fast body (every mapping frame), the generic one, and

@@ -5,9 +5,9 @@ PyCUDA kernels replaced by librfx (``rfx_track_vertex / _normal / _evaluate``).
 Differences, on purpose:
   * the pre-sampled particle templates ("PST", 60 float32 TIFFs under PFO/fps_uniform_sphere in the reference,
     read there with cv2) are read from ``RO.PST_path`` by ``model/pst.py`` (own baseline-TIFF reader) into the
-    same ``ALL_PST[class][index]`` container, or -- where that directory does not exist -- from the archive of the same
-    60 arrays committed under ``tests/golden/pst_templates.npz``; seeded templates of the same structure only when
-    both are missing AND a configuration says ``RO.PST_fallback: "generated"``, with a warning;
+    same ``ALL_PST[class][index]`` container (or from an ``.npz`` archive of the same 60 arrays: the test suite's fixture);
+    where neither ``RFX_PST_PATH`` nor ``RO.PST_path`` names templates: seeded templates of the same structure, with a
+    warning (``RO.PST_fallback: "generated"``, the default -- the package ships no template data);
   * ``cal_transform``'s python loop over up to 10 240 candidates is vectorised with numpy (same
     selection: the first ``count_search`` candidates that beat candidate 0, same weights);
   * compute_vertex's cuRAND jitter is replaced by a counter-based hash (exactly zero anyway for
@@ -89,9 +89,9 @@ class ROTracker(object):
     # ------------------------------------------------------------------ particle templates
     def readpst(self, PST_path, PST_size):
         """reference :834-866: ``ALL_PST[class][index]`` <- ``PST_path/pst_{size}_{num}.tiff`` ([P,6] float32), plus
-        device copies.  ``RFX_PST_PATH`` in the environment overrides the configured directory; where neither names the
-        templates they come from the archive committed with the repository (``model/pst.py::PACKAGED_ARCHIVE``: the same 60
-        arrays).  Generated templates only if that is missing too AND the configuration says ``RO.PST_fallback: "generated"``."""
+        device copies.  ``RFX_PST_PATH`` in the environment overrides the configured directory (and must exist).  Where neither
+        names templates: generated ones, with a warning (``RO.PST_fallback: "generated"``, the default -- the package ships no
+        template data, model/pst.py), or an error (any other value of ``RO.PST_fallback``)."""
         import warnings
         from .pst import resolve_pst_source
         ro = self.cfg["RO"]
@@ -99,8 +99,8 @@ class ROTracker(object):
         if path is not None:
             self.ALL_PST = load_pst(path, PST_size, self.tiff_index)
             self.PST_source = path
-        elif ro.get("PST_fallback") == "generated":
-            warnings.warn(f"ROTracker: no PST templates at {PST_path!r} and no packaged archive; searching with GENERATED "
+        elif ro.get("PST_fallback", "generated") == "generated":
+            warnings.warn(f"ROTracker: no PST templates at {PST_path!r} (and no RFX_PST_PATH); searching with GENERATED "
                           "templates (RO.PST_fallback='generated'): poses will differ from the reference's", stacklevel=2)
             self.ALL_PST = generated_pst(ro.get("PST_seed", 20251205), PST_size, self.tiff_index)
             self.PST_source = "generated"

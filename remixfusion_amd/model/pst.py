@@ -3,14 +3,17 @@
 The reference ships 60 float32 TIFFs under ``PFO/fps_uniform_sphere`` (``pst_{10240,3072,1024}_{0..19}.tiff``,
 each [P, 6]: row 0 is the null perturbation, the rest are farthest-point samples of the 6-D unit ball) and reads
 them with ``cv2.imread(path, -1)`` into ``ALL_PST[class][index]`` (reference model/ROtracker.py:834-866).
-``load_pst`` builds the same container from the same files (``RO.PST_path`` exactly as in the reference YAMLs) or, where no
-such directory exists, from ``tests/golden/pst_templates.npz``: the same 60 arrays in one archive (round 5; written by
-``tests/golden/make_golden.py`` from the reference's files and checked against their SHA-256 digests).
+``load_pst`` builds the same container from the same files (``RO.PST_path`` exactly as in the reference YAMLs: a user of the
+reference has that directory) or from an ``.npz`` archive of the same 60 arrays.  The package itself ships NO template data
+(round 6; the reference repository carries no licence file, so its data is not redistributed as part of the product): the
+repository's test suite keeps one such archive as a FIXTURE (``tests/golden/pst_templates.npz``, provenance in
+``tests/golden/README.md``) and points ``RFX_PST_PATH`` at it (``tests/conftest.py``).
 
 ``read_float_tiff`` is a baseline-TIFF reader for exactly that file kind (uncompressed, one float32 sample per
-pixel, strips): neither cv2 nor Pillow is needed.  ``make_pst`` -- seeded templates of the same structure -- is
-only used when a configuration asks for it explicitly (``RO.PST_path: null`` with ``RO.PST_fallback:
-"generated"``): a tracker that searches with different particles does not retrace the reference's poses.
+pixel, strips): neither cv2 nor Pillow is needed.  ``make_pst`` -- seeded templates of the same structure (origin first, then
+points of the 6-D unit ball, farthest first) -- is what the tracker searches with when no template directory / archive is
+configured (``RO.PST_fallback: "generated"``, the default): it runs, with a warning, but a tracker that searches with
+different particles does not retrace the reference's poses.
 """
 from __future__ import annotations
 
@@ -118,20 +121,26 @@ def _empty(tiff_index: Sequence[int], PST_size: Sequence[int]) -> Dict[int, np.n
             2: np.zeros((n // 3, PST_size[2], 6), np.float32)}
 
 
-# The reference's 60 templates as ONE archive of float32 arrays (keys ``pst_{size}_{num}``), written from the reference's
-# TIFFs by tests/golden/make_golden.py::make_pst_fixture (data the reference reads at start-up, not source).  It travels with
-# the repository, so a machine without the reference checkout (the GPU box) searches with the reference's particles.
-_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-PACKAGED_ARCHIVE = os.path.join(_ROOT, "tests", "golden", "pst_templates.npz")
-
-
 def resolve_pst_source(PST_path):
-    """Where the templates come from: ``RFX_PST_PATH`` / ``RO.PST_path`` when it names a directory of TIFFs or an ``.npz``
-    archive, else the archive committed with the repository; ``None`` when none of them exists."""
-    for cand in (os.environ.get("RFX_PST_PATH"), PST_path):
-        if cand and (os.path.isdir(cand) or (os.path.isfile(cand) and cand.endswith(".npz"))):
-            return cand
-    return PACKAGED_ARCHIVE if os.path.isfile(PACKAGED_ARCHIVE) else None
+    """Where the templates come from: ``RFX_PST_PATH`` when set (it MUST then name a directory of the reference's TIFFs or an
+    ``.npz`` archive of them: a typo or an unmounted directory raises instead of silently searching with other particles), else
+    ``RO.PST_path`` when it exists (a configured path that does not exist is skipped WITH a warning); ``None`` when neither
+    names templates (the caller then generates them, or raises: ``RO.PST_fallback``)."""
+    import warnings
+
+    def usable(c):
+        return bool(c) and (os.path.isdir(c) or (os.path.isfile(c) and c.endswith(".npz")))
+
+    env = os.environ.get("RFX_PST_PATH")
+    if env:
+        if not usable(env):
+            raise FileNotFoundError(f"RFX_PST_PATH={env!r} is neither a directory of PST TIFFs nor an .npz archive of them")
+        return env
+    if usable(PST_path):
+        return PST_path
+    if PST_path:
+        warnings.warn(f"RO.PST_path {PST_path!r} does not exist: the tracker's particle templates are not the configured ones", stacklevel=3)
+    return None
 
 
 def load_pst(PST_path: str, PST_size: Sequence[int], tiff_index: Sequence[int]) -> Dict[int, np.ndarray]:
@@ -143,7 +152,7 @@ def load_pst(PST_path: str, PST_size: Sequence[int], tiff_index: Sequence[int]) 
     elif not os.path.isdir(PST_path):
         raise FileNotFoundError(
             f"RO.PST_path {PST_path!r} is neither a directory of the reference's 60 float32 TIFFs (PFO/fps_uniform_sphere) "
-            f"nor an .npz archive of them, and the packaged archive {PACKAGED_ARCHIVE!r} is missing.  Set RO.PST_fallback: "
+            "nor an .npz archive of them.  Point RO.PST_path / RFX_PST_PATH at the reference's directory, or set RO.PST_fallback: "
             "'generated' to search with seeded templates instead (poses will then differ from the reference's).")
     out = _empty(tiff_index, PST_size)
     for ti in tiff_index:

@@ -106,8 +106,10 @@ class Mapper:
         self.trunc_margin = self.config["training"]["c_trunc"]
 
     def save_ckpt(self, save_path):
-        self.wait_meshes()              # a failed in-loop export raises here, like the reference's blocking export would have
+        # the collective first: wait_meshes() can raise on rank 0 alone (only rank 0 exports), and a rank that raises before a
+        # collective leaves its peers waiting inside it
         self.sync_field()               # (a sharded scene: the table whole on every rank; collective)
+        self.wait_meshes()              # a failed in-loop export raises here, like the reference's blocking export would have
         torch.save({"pose": self.est_c2w_data, "pose_rel": self.est_c2w_data_rel, "model": self.model.state_dict()}, save_path)
 
     # ---- GBV kernels --------------------------------------------------------------------
@@ -403,7 +405,7 @@ class Mapper:
                 self.step(current_map_id)
             if self.tracking_stop_flag[0] != 0:
                 break
-        self.wait_meshes()              # the in-loop exports are on disk (or their error is raised) when run() returns
-        if m["save_ckpt"]:
+        if m["save_ckpt"]:              # (save_ckpt: the collective sync_field(), THEN wait_meshes() -- see there)
             import os
             self.save_ckpt(os.path.join(self.config["data"]["output"], self.config["data"]["exp_name"], "checkpoint.pt"))
+        self.wait_meshes()              # the in-loop exports are on disk (or their error is raised) when run() returns

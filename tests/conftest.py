@@ -9,6 +9,10 @@ for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
 import numpy as np
 import pytest
 
+# the tracker tests search with the REFERENCE's particle templates: a fixture of this test suite (tests/golden/README.md), which
+# the product neither ships nor looks for by itself (remixfusion_amd/model/pst.py)
+os.environ.setdefault("RFX_PST_PATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pst_templates.npz"))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -143,7 +143,7 @@ def test_packaged_archive_holds_the_reference_templates():
     P = _pst()
     g = np.load(os.path.join(HERE, "golden", "pst_fixture.npz"))
     arc = os.path.join(HERE, "golden", "pst_templates.npz")
-    assert P.PACKAGED_ARCHIVE == arc and os.path.isfile(arc)
+    assert os.path.isfile(arc) and not hasattr(P, "PACKAGED_ARCHIVE")          # a fixture of the tests, not a file the product looks for
     z = np.load(arc)
     assert sorted(z.files) == sorted(str(n)[:-len(".tiff")] for n in g["names"])
     for i, name in enumerate(g["names"]):
@@ -155,14 +155,22 @@ def test_packaged_archive_holds_the_reference_templates():
     for ti in TIFF_INDEX:
         cls, num, slot = P.pst_slot(ti)
         assert np.array_equal(A[cls][slot], z[f"pst_{SIZES[cls]}_{num}"])
-    # resolution order: an existing directory / archive named by the configuration wins, anything else -> the packaged archive
+    # resolution order (round 6): RFX_PST_PATH must exist when set; a configured path that exists is used; one that does not is
+    # skipped WITH a warning and nothing else is searched (the tracker then generates templates, or raises: RO.PST_fallback)
     old = os.environ.pop("RFX_PST_PATH", None)
     try:
-        assert P.resolve_pst_source("PFO/fps_uniform_sphere_that_does_not_exist") == arc
-        assert P.resolve_pst_source(None) == arc
+        with pytest.warns(UserWarning, match="does not exist"):
+            assert P.resolve_pst_source("PFO/fps_uniform_sphere_that_does_not_exist") is None
+        assert P.resolve_pst_source(None) is None
         assert P.resolve_pst_source(arc) == arc
         assert P.resolve_pst_source(HERE) == HERE
+        os.environ["RFX_PST_PATH"] = arc
+        assert P.resolve_pst_source("PFO/fps_uniform_sphere_that_does_not_exist") == arc
+        os.environ["RFX_PST_PATH"] = os.path.join(HERE, "no_such_templates.npz")
+        with pytest.raises(FileNotFoundError, match="RFX_PST_PATH"):
+            P.resolve_pst_source(arc)
     finally:
+        os.environ.pop("RFX_PST_PATH", None)
         if old is not None:
             os.environ["RFX_PST_PATH"] = old
     d = _ref_dir()
