@@ -48,7 +48,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak
 MLP_FLOP_PER_POINT = 2 * (81 * 32 + 32 * 16 + 66 * 32 + 32 * 3)     # 10 624
-PMC_TRAFFIC_FILE, PMC_V1_FILE = "r5_pmc_traffic.json", "r5_pmc_v1_frame25.json"      # written by tools/r5_measure.sh
+PMC_V1_FILE = "r6_pmc_v1_frame25.json"                                  # written by tools/r6_measure.sh (office0, the driver's frame)
+
+
+def pmc_traffic_file(config):
+    """committed rocprofv3 --pmc summary of THIS workload (tools/r6_measure.sh: one per BASELINE config)"""
+    return "r6_pmc_traffic.json" if config == "office0" else f"r6_pmc_traffic_{config}.json"
 
 
 def parse():
@@ -215,13 +220,21 @@ def field_rooflines(summ, cfg, merged_scatter=True):
         nbytes = pts * (12 + 128 + 1024)
         ach = nbytes / (ms * 1e-3) / 1e9
         f64 = cfg["grid"]["hash_size"] <= 17
+        binned = cfg["grid"]["hash_size"] >= 19         # levels of >= 12 segments of 8 192 entries exist (csrc/rfx_field.hip: level_is_binned)
         out["field_backward_scatter"] = {
-            "kernel": f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})", "bound": "hbm", "achieved": round(ach, 1),
+            "kernel": (f"scatter_stage_kernel + grid_scatter_lds_kernel (levels below 12 segments) + bin_sort_kernel + bin_reduce_kernel (the binned levels) ({scat})"
+                       if binned else f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})"),
+            "bound": "hbm", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "points_per_launch": int(pts), "avg_ms": round(ms, 4),
-            "note": "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
-                    "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
-                    "non-zero entry; bound by LDS atomics / index arithmetic, not HBM",
+            "points_per_launch": int(pts), "avg_ms": round(ms, 4), "algorithmic_bytes_per_point": 12 + 128 + 1024,
+            "frac_scatter_bytes_only": round(pts * 1024 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),      # SURVEY 8d's 1 024 B per point alone
+            "note": ("binned levels: one walk over the points sorts 16-byte x-pair records by table segment inside each block's own "
+                     "region (bin_sort), one block per segment adds its runs into 128 KB of LDS (double accumulators) and writes the "
+                     "segment back (bin_reduce): the records -- 64 B per point and level written and read once -- are the traffic, "
+                     "moved at 2.3-3.4 TB/s (profiles/r6_notes.md)" if binned else
+                     "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
+                     "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
+                     "non-zero entry; bound by LDS atomics / index arithmetic, not HBM"),
             # algorithmic adds = points x 16 levels x 8 corners x 2 features, priced against the LDS atomic of the
             # accumulator type this table size uses (tools/micro/lds_atomic.hip: a full-wave ds_add_f64 retires in 19
             # clocks per CU, ds_add_f32 in 169; x 256 CUs x 2.4 GHz)
@@ -822,12 +835,13 @@ def main():
                     "avg_ms_alone": round(v1_alone_ms, 4), "achieved_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9, 1),
                     "frac_alone": round(nbytes / (v1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # HBM traffic per launch: NOT measured by this run (PMC counters need rocprofv3 passes of their own).  The figure is
-    # taken from the committed summary of those passes, profiles/r5_pmc_traffic.json (tools/summarize_pmc.py), which
+    # taken from the committed summary of those passes, profiles/r6_pmc_traffic[_<config>].json (tools/summarize_pmc.py), which
     # carries the digest of the kernel sources the passes ran on (remixfusion_amd.build.sources_digest): when this tree's
     # digest differs -- the binary timed here is not the one the counters saw -- traffic stays null and says so.
     from remixfusion_amd.build import sources_digest
     digest_now = sources_digest()
     try:
+        PMC_TRAFFIC_FILE = pmc_traffic_file(args.config)
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
         pmc, tag = pmc_all.get("kernels", {}), pmc_all.get("measured_at_commit", "unknown")
         stale = pmc_all.get("kernel_sources_digest") != digest_now
@@ -836,7 +850,7 @@ def main():
             for r_ in extra_rooflines.values():
                 r_["traffic_source"] = (f"null: profiles/{PMC_TRAFFIC_FILE} was measured on kernel sources {pmc_all.get('kernel_sources_digest')} "
                                         f"(commit {tag}), this tree is {digest_now}")
-        for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel")),
+        for rk, kns in (("field_backward_scatter", ("rfx::grid_scatter_lds_kernel", "rfx::scatter_stage_kernel", "rfx::bin_sort_kernel", "rfx::bin_reduce_kernel")),
                         ("field_forward", ("rfx::field_forward_kernel<false, 1>",)),
                         ("field_backward_chain", ("rfx::field_backward_kernel<false, true, false, true>",)),
                         ("field_backward_weights", ("rfx::field_dw_recompute_kernel", "rfx::field_dw_reduce_kernel")),
@@ -850,7 +864,7 @@ def main():
     except Exception:
         pass
     # V1: traffic of the SAME frame the algorithmic bytes above were counted on (frame 1 + warmup + steps - 1), when the
-    # committed passes cover it (profiles/r5_pmc_v1_frame25.json: the driver's settings) and ran on these kernel sources
+    # committed passes cover it (profiles/r6_pmc_v1_frame25.json: the driver's settings) and ran on these kernel sources
     try:
         v1p = json.load(open(os.path.join(ROOT, "profiles", PMC_V1_FILE)))
         if "tsdf_integrate" in extra_rooflines and v1p.get("kernel_sources_digest") != digest_now:
@@ -863,7 +877,7 @@ def main():
             extra_rooflines["tsdf_integrate"]["traffic_source"] = (
                 f"profiles/{PMC_V1_FILE}: rocprofv3 --pmc passes of tools/pmc_v1.py at commit {v1p['measured_at_commit']} on frame "
                 f"{v1p['frame']} (this frame; not this run): 2 x FETCH_SIZE + WRITE_SIZE = the bytes the L2s pulled in (every miss is a whole "
-                "128-byte line tallied at 64, calibrated on V1's own access shape: profiles/r5_fetch_calib.txt) -- Infinity-Cache hits "
+                "128-byte line tallied at 64, calibrated on V1's own access shape in round 5: profiles/r5_fetch_calib.txt) -- Infinity-Cache hits "
                 "included: ~80 MB of it are the frame's images fetched once per XCD; traffic_raw_counters = FETCH_SIZE + WRITE_SIZE")
         elif "tsdf_integrate" in extra_rooflines:
             extra_rooflines["tsdf_integrate"]["traffic"] = None         # passes of other frames are not comparable
