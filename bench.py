@@ -409,6 +409,17 @@ def run_one_scene(args, dist, rank, world, device, timer):
     choice = getattr(pipe.mapper, "field_mode_choice", None)
     if choice is not None:
         exchange["auto_choice_estimated_us"] = {k: round(v * 1e6, 1) for k, v in choice["estimated_seconds"].items()}
+    # the time model's prediction beside the measurement (dist.choose_field_mode; constants in dist.py: a MODEL until RCCL ranks
+    # have met): one map iteration on one GPU and on `world`, and the mapper's share of a frame if every iteration cost that
+    from remixfusion_amd.dist import choose_field_mode
+    mdl_t = choose_field_mode(pipe.model.embed_res_fn.desc, n_rays * S, P3, world)
+    mode_now = "levels" if levels else "replicas"
+    per_frame = (m["iters"] + m["BA_iters"]) / m["map_every"]
+    exchange["model"] = {"map_iteration_us_one_gpu": round(mdl_t["iteration_seconds_one_gpu"] * 1e6, 1),
+                         "map_iteration_us_n_gpus": round(mdl_t["iteration_seconds"][mode_now] * 1e6, 1),
+                         "mapper_ms_per_frame_n_gpus_if_every_iteration_cost_that": round(mdl_t["iteration_seconds"][mode_now] * per_frame * 1e3, 3),
+                         "constants": "dist.py: 60 GB/s received per rank under a collective, 30 us per collective, scatter and decoder "
+                                      "rates measured on one GPU"}
     if levels:
         exchange["rays_own"], exchange["k_own"], exchange["n_lattice"] = direct.last_exchange.get("rays_own"), direct.k_own, P3
         exchange["recv_bytes_last_iteration_rank0"] = direct.last_exchange.get("recv_bytes")

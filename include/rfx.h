@@ -34,7 +34,7 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 8
+#define RFX_ABI_VERSION 9
 
 typedef void* rfx_stream;
 
@@ -664,6 +664,13 @@ typedef struct rfx_ba_shard {
 size_t rfx_ba_shard_bytes(void);        /* sizeof(rfx_ba_shard), for foreign bindings */
 /* workspace for all four: the one rfx_ba_forward_backward takes (rfx_ba_workspace_bytes[_for] of the WHOLE batch). */
 int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
+/* rfx_ba_shard_lookup in two launches (ABI 9), for a caller that overlaps the feature all-to-all with what the exchange does
+ * not need: _rays = the ray batch + the own levels' features of its points -> feat_send (start the all-to-all after it);
+ * _tv = the TV lattice with its own-level features + the zero-fill of the own range of d_hash (issue it while the exchange is
+ * in flight; it must precede rfx_ba_shard_render on the stream).  _rays followed by _tv == rfx_ba_shard_lookup, bit for bit.
+ * The reference has no counterpart (single GPU): the iteration is mp_slam/mapper.py:392-423 / :470-505. */
+int rfx_ba_shard_lookup_rays(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
+int rfx_ba_shard_lookup_tv(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_ba_shard_render(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_ba_shard_scatter(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);
 int rfx_ba_shard_pose(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream);

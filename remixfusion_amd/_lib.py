@@ -186,6 +186,8 @@ PROTOTYPES = {
     "rfx_grid_encode_backward_merged": (_i, [C.POINTER(GridDesc), _P, _P, _l, _P, _P, _l, _P, _P, _P, _sz, _P]),
     "rfx_ba_shard_bytes": (C.c_size_t, []),
     "rfx_ba_shard_lookup": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
+    "rfx_ba_shard_lookup_rays": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
+    "rfx_ba_shard_lookup_tv": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
     "rfx_ba_shard_render": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
     "rfx_ba_shard_scatter": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
     "rfx_ba_shard_pose": (_i, [C.POINTER(BaDesc), C.POINTER(BaShard), _P, _sz, _P]),
@@ -217,7 +219,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 8:
+    if lib.rfx_abi_version() != 9:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

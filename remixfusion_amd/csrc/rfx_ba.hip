@@ -270,7 +270,10 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
 // ---- the same iteration on a level-partitioned table (rfx.h: rfx_ba_shard) ------------------------------------------------
 size_t rfx_ba_shard_bytes(void) { return sizeof(rfx_ba_shard); }
 
-int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+// parts: 1 = the ray batch and the own levels' features of its points (what the feature all-to-all sends), 2 = the TV lattice
+// with its own-level lookups and the zero-fill of the own range of d_hash (nothing the exchange needs: the caller issues it
+// while the all-to-all is in flight), 3 = both in one launch (rfx_ba_shard_lookup)
+static int shard_lookup_parts(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream, int parts) {
     ShardCall c;
     RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
     const BaWs& w = c.w;
@@ -285,8 +288,19 @@ int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* works
                         b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, c.P, b->tv_voxel,
                         b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
                         c.map_grads ? b->d_hash + z0 : nullptr, c.map_grads ? z1 - z0 : 0, b->trunc * b->sc_factor, b->depth_trunc,
-                        w.cnt, &n_cnt, stream, &c.g.own));
+                        w.cnt, &n_cnt, stream, &c.g.own, parts));
+    if (!(parts & 1)) return RFX_OK;
     return rfx_grid_encode_forward(&c.g.own, b->field.hash_table, w.x01, c.nS, s->feat_send, stream);
+}
+
+int rfx_ba_shard_lookup(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return shard_lookup_parts(b, s, workspace, workspace_bytes, stream, 3);
+}
+int rfx_ba_shard_lookup_rays(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return shard_lookup_parts(b, s, workspace, workspace_bytes, stream, 1);
+}
+int rfx_ba_shard_lookup_tv(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return shard_lookup_parts(b, s, workspace, workspace_bytes, stream, 2);
 }
 
 int rfx_ba_shard_render(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspace, size_t workspace_bytes, rfx_stream stream) {

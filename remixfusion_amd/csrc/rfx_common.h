@@ -72,7 +72,8 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
                 float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream,
-                const rfx_grid_desc* tv_grid = nullptr);     // (tv_grid: the lattice's lookups use it instead of field->hash)
+                const rfx_grid_desc* tv_grid = nullptr,      // (tv_grid: the lattice's lookups use it instead of field->hash)
+                int parts = 3);                              // 1: the ray batch (+ weight staging); 2: TV lattice + zero-fill; 3: both
 int ba_count_partials(int64_t n_rays);                       // count_partials triples ba_prologue writes for a batch of n_rays
 int composite_loss_grad(const float* raw4, const float* z_vals, const float* target_rgb, const float* target_d, int64_t n_rays, int S,
                         float trunc, float sc_factor, float trunc_loss, float depth_trunc, int rgb_missing_on, float* rgb_map,

@@ -1303,7 +1303,10 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
                 float* d_cam, int32_t* pose_idx, float* z_vals, float* x01, const rfx_field_desc* field, const float* u6, int tv_P,
                 float tv_voxel, float tv_margin, int tv_normalise, float* tv_pts, float* tv_feat, float* zero, int64_t zero_floats,
                 float trunc_loss, float depth_trunc, double* count_partials, int* n_count_partials, rfx_stream stream,
-                const rfx_grid_desc* tv_grid) {
+                const rfx_grid_desc* tv_grid, int parts) {
+    // parts: the launch is made of independent block ranges; a level-partitioned iteration issues the ray batch first (its
+    // features go into the all-to-all) and the lattice + zero-fill while that exchange is in flight (rfx_ba_shard_lookup_tv)
+    if (!(parts & 2)) { tv_pts = nullptr; tv_feat = nullptr; zero = nullptr; zero_floats = 0; }
     if (n_count_partials) *n_count_partials = 0;
     const int64_t n = n_kf_samples + n_cur;
     if (n == 0) return RFX_OK;
@@ -1318,7 +1321,7 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
     FieldK fk = {};
     int nb_stage = 0;
     float* staged = nullptr;
-    if (field && field->staged) {
+    if (field && field->staged && (parts & 1)) {
         rc = make_fieldk(field, &fk);
         if (rc) return rc;
         staged = const_cast<float*>(field->staged);
@@ -1337,14 +1340,15 @@ int ba_prologue(const float* kf_rays, int64_t rays_per_kf, int64_t num_kf, const
         nb_tv = (int)(((int64_t)tv_P * tv_P * tv_P * 16 + 255) / 256);
     }
     const RayOut out = {rays_o, rays_d, target_rgb, target_d, d_cam, pose_idx, z_vals, x01};
-    const int nb_rays = ray_grid(n);
+    const int nb_rays = (parts & 1) ? ray_grid(n) : 0;
     if (zero_floats < 0 || (zero_floats > 0 && !zero)) return RFX_ERR_ARG;
     const int64_t nb_zero = zero ? (zero_floats + PROLOGUE_ZERO - 1) / PROLOGUE_ZERO : 0;
     if (nb_rays + nb_stage + nb_tv + nb_zero > 0x7fffffff) return RFX_ERR_UNSUPPORTED;
+    if (nb_rays + nb_stage + nb_tv + nb_zero == 0) return RFX_OK;
     hipLaunchKernelGGL(ba_prologue_kernel, dim3((unsigned)(nb_rays + nb_stage + nb_tv + nb_zero)), dim3(256), 0, as_stream(stream), g, k,
                        make_box(bbox, bbox_f64), seed_u ? nullptr : u01, seed_u, out, nb_rays, fk, staged, nb_stage, tv, nb_tv, zero,
                        zero_floats, LossCountK{trunc_loss, depth_trunc, count_partials});
-    if (count_partials && n_count_partials) *n_count_partials = nb_rays;
+    if (count_partials && n_count_partials && (parts & 1)) *n_count_partials = nb_rays;
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -42,14 +42,10 @@
 #ifndef MV_XCD_DEAL
 #define MV_XCD_DEAL 1  // mv_chunks_kernel: segments of the queue dealt to the XCDs (see the kernel)
 #endif
-// mv_rows_kernel<FAR_WALK>: far end of a row refined by a walk through the max-depth tiles.  Measured (round 5, office0):
-// 159 k -> 137 k items, 7.26 M -> 6.11 M in-interval lanes, mv_chunks 38.3 -> 37.0 us, mv_rows 14.5 -> 22.6 us (a divergent
-// per-thread loop): a loss where the chunk kernel is short.  Round 6: a RUN-TIME choice by the size of the footprint window
-// (rows x 64-voxel chunks per row >= MV_FAR_WALK_MIN_ITEMS: the chunk kernel then runs for hundreds of microseconds and 14 % of
-// its items are worth more than the walk -- the 1.5e9-voxel apartment volume), see the launch.
-#ifndef MV_FAR_WALK_MIN_ITEMS
-#define MV_FAR_WALK_MIN_ITEMS 6000000ll
-#endif
+// (Round 5 built a far-end walk of every row through the max-depth tiles: -14 % items at office0, mv_chunks -1.3 us, mv_rows
+// +8 us, not kept.  Round 6 tried it as a run-time choice for the 1.5e9-voxel apartment volume, where it cut the call from 0.36 to
+// 0.25 ms -- and found it WRONG there: 1.75 M voxels differed from the unclipped walk after 8 frames (surfaces left at their
+// initial value; caught by tests/test_sharded_configs_gpu.py, whose slabs and whole volume chose differently).  Removed.)
 #ifndef MV_XCD_SEGS
 #define MV_XCD_SEGS 32 // segments per XCD (rounded to a power-of-two segment length); 8 / 32 measured: 40.0 / 38.9 us
 #endif
@@ -533,7 +529,6 @@ __global__ __launch_bounds__(256) void mv_frame_kernel(const float* __restrict__
 }
 
 // ---- rows kernel
-template <bool FAR_WALK>
 __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, const unsigned* __restrict__ dmax_bits,
                                                        unsigned* __restrict__ q_counts, MvItem* __restrict__ queue,
                                                        unsigned q_cap, MvItem* __restrict__ queue_risky, unsigned q_cap_risky,
@@ -541,7 +536,6 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
     // max-depth pyramid over the coarse tiles: level 0 = the tiles, level l+1 = 2x2 maxima of level l.  A row's
     // projection is a straight segment; its bounding box is looked up at the level where it spans at most 2x2 cells.
     __shared__ float pyr[MV_ROWS_LDS_TILES + MV_PYR_FLOATS];
-    __shared__ float dil[FAR_WALK ? MV_ROWS_LDS_TILES : 1];      // max depth over the 3x3 tiles around a tile (the far-end walk below)
     __shared__ int lvl_off[16], lvl_w[16], lvl_h[16];
     const int tw = (P.W + MV_TD - 1) / MV_TD, th = (P.H + MV_TD - 1) / MV_TD;
     const int n_tiles = tw * th;
@@ -559,15 +553,6 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             lvl_off[15] = l + 1;
         }
         __syncthreads();
-        if (FAR_WALK) {
-            for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-                const int y = i / tw, x = i - y * tw;
-                float m = 0.0f;
-                for (int yy = max(y - 1, 0); yy <= min(y + 1, th - 1); ++yy)
-                    for (int xx = max(x - 1, 0); xx <= min(x + 1, tw - 1); ++xx) m = fmaxf(m, pyr[yy * tw + xx]);
-                dil[i] = m;
-            }
-        }
         n_lvl = lvl_off[15];
         for (int l = 1; l < n_lvl; ++l) {
             const int w = lvl_w[l], h = lvl_h[l], pw = lvl_w[l - 1], ph = lvl_h[l - 1];
@@ -651,55 +636,6 @@ __global__ __launch_bounds__(MV_ROWS_THREADS) void mv_rows_kernel(MvParams P, co
             if (tm > 0.0f) {
                 // cam_z <= (deepest pixel + trunc) / (1 - ratio_eps), on the far side
                 clip((tm + P.trunc) / (1.0f - P.ratio_eps) * 1.0001f + 1e-3f - Az, -Bz, eps_z);
-                // Round 5: the box of the whole projection holds the far wall even where this row ends in the floor, so the
-                // clip above left 2.4 M of 7.3 M in-interval lanes per frame behind a surface.  Walk the projection (a
-                // straight, monotonic segment) from its FAR end through the 16 x 16-pixel tiles: the part of the row inside
-                // one tile sees at most the deepest pixel of the 3 x 3 tiles around it (`dil`: the rounding of a pixel and
-                // the approximate edge crossings stay far inside that margin); if even the nearest voxel of that part lies
-                // deeper, the part is untouched and the walk goes on, else the same clip with this tile's depth ends it.
-                if (FAR_WALK && in_lds && !empty && lo <= hi && Bz != 0.0f) {
-                    const bool inc = Bz > 0.0f;                    // cam_z grows with z: the far end is `hi`
-                    float zf = inc ? hi : lo;
-                    const float zn = inc ? lo : hi;
-                    const float du = (Bx * Az - Ax * Bz) * fx * (inc ? -1.0f : 1.0f);     // sign of du along the walk (far -> near)
-                    const float dv = (By * Az - Ay * Bz) * fy * (inc ? -1.0f : 1.0f);
-                    const float kb = 1.0001f / (1.0f - P.ratio_eps);
-                    for (int step = 0; step < 12; ++step) {
-                        const float czf = Az + zf * Bz;
-                        if (!(czf > 1e-6f)) break;
-                        const float r = __builtin_amdgcn_rcpf(czf);
-                        const float u = fx * (Ax + zf * Bx) * r + cx, v = fy * (Ay + zf * By) * r + cy;
-                        const int tu = min(max((int)floorf(u * (1.0f / MV_TD)), 0), tw - 1), tv = min(max((int)floorf(v * (1.0f / MV_TD)), 0), th - 1);
-                        const float D = dil[tv * tw + tu];
-                        // z where the segment leaves this tile towards the near end: u(z) = e  <=>  z = (e' Az - fx Ax) / (fx Bx - e' Bz), e' = e - cx
-                        float z_exit = zn;
-                        {
-                            const float e = (float)((du > 0.0f ? tu + 1 : tu) * MV_TD) - cx, den = fx * Bx - e * Bz;
-                            if (du != 0.0f && fabsf(den) > 1e-12f) {
-                                const float ze = (e * Az - fx * Ax) * __builtin_amdgcn_rcpf(den);
-                                if (inc ? (ze < zf && ze > z_exit) : (ze > zf && ze < z_exit)) z_exit = ze;
-                            }
-                        }
-                        {
-                            const float e = (float)((dv > 0.0f ? tv + 1 : tv) * MV_TD) - cy, den = fy * By - e * Bz;
-                            if (dv != 0.0f && fabsf(den) > 1e-12f) {
-                                const float ze = (e * Az - fy * Ay) * __builtin_amdgcn_rcpf(den);
-                                if (inc ? (ze < zf && ze > z_exit) : (ze > zf && ze < z_exit)) z_exit = ze;
-                            }
-                        }
-                        if (fabsf(z_exit - zf) < 0.5f) z_exit = inc ? fmaxf(zn, zf - 0.5f) : fminf(zn, zf + 0.5f);     // always move on
-                        const float bound = D > 0.0f ? (D + P.trunc) * kb + 1e-3f + eps_z : -1.0f;    // cam_z beyond it: untouched
-                        if (Az + z_exit * Bz > bound) {              // the nearest voxel of this part is beyond: all of it is
-                            zf = z_exit;
-                            if (zf == zn) { empty = true; break; }
-                        } else {
-                            const float zb = (bound - Az) * __builtin_amdgcn_rcpf(Bz);
-                            zf = inc ? fminf(zf, zb) : fmaxf(zf, zb);
-                            break;
-                        }
-                    }
-                    if (inc) hi = zf; else lo = zf;
-                }
                 if (!empty && lo <= hi) {
                     z0 = max(0, (int)floorf(lo) - 1);
                     z1 = min(P.dz, (int)ceilf(hi) + 2);
@@ -1687,17 +1623,8 @@ static int integrate_slab(float* tsdf, float* weight, float* color, int dx, int 
         MvItem* queue_risky = queue + cap + MV_QUEUE_PAD;
         const unsigned q_cap = (unsigned)std::min<size_t>(cap, 0xffffffffu), q_cap_risky = (unsigned)std::min<size_t>(cap_risky, 0xffffffffu);
         const int blocks_main = (int)((rows_main + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS), blocks_risky = (int)((rows_risky + MV_ROWS_THREADS - 1) / MV_ROWS_THREADS);
-        // the far-end walk pays where the chunk kernel is long (see MV_FAR_WALK_MIN_ITEMS); RFX_MV_FAR_WALK=0/1 forces it (A/B runs)
-        static const char* fw_env = getenv("RFX_MV_FAR_WALK");
-        const bool far_walk = fw_env ? fw_env[0] == '1' : rows_main * nch >= MV_FAR_WALK_MIN_ITEMS;
-        static const bool fw_dbg = getenv("RFX_DEBUG_MV") != nullptr;
-        if (fw_dbg) fprintf(stderr, "[mv] rows_main %lld x %d chunks = %lld items bound, far walk %d\n", (long long)rows_main, nch, (long long)(rows_main * nch), (int)far_walk);
-        if (far_walk)
-            hipLaunchKernelGGL(mv_rows_kernel<true>, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
-                               q_cap, queue_risky, q_cap_risky, blocks_main, skip);
-        else
-            hipLaunchKernelGGL(mv_rows_kernel<false>, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
-                               q_cap, queue_risky, q_cap_risky, blocks_main, skip);
+        hipLaunchKernelGGL(mv_rows_kernel, dim3((unsigned)(blocks_main + blocks_risky)), dim3(MV_ROWS_THREADS), 0, st, P, dmax_bits, dmax_bits, queue,
+                           q_cap, queue_risky, q_cap_risky, blocks_main, skip);
         RFX_LAUNCH_CHECK();
         // a grid of RESIDENT blocks pulls from the queue (a second, partial round of blocks would run at a fraction of the
         // chip); small volumes need fewer.  Three instances: the fast body (every mapping frame), the generic one, and

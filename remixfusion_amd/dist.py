@@ -206,16 +206,63 @@ def all_reduce_sum_(dist, tensors) -> None:
 def all_to_all_rows_(dist, out: torch.Tensor, out_splits: List[int], inp: torch.Tensor, in_splits: List[int]) -> None:
     """all-to-all of flat fp32 buffers with per-rank element counts: inp is cut into in_splits (piece q goes to rank q), out
     receives the pieces of ranks 0..world-1 in turn (out_splits).  nccl (RCCL): on the device; gloo: through the host."""
+    all_to_all_rows_start(dist, out, out_splits, inp, in_splits)()
+
+
+def _done():
+    return None
+
+
+def all_to_all_rows_start(dist, out: torch.Tensor, out_splits: List[int], inp: torch.Tensor, in_splits: List[int]):
+    """all_to_all_rows_ in two halves: the exchange is ISSUED here and the returned callable makes the current stream wait for
+    it.  Under nccl (RCCL) the collective runs on the process group's own stream (which first waits for everything already
+    queued on the current stream), so kernels launched between the two halves run WHILE the rows travel -- whatever does not
+    read `out` (round 6: the TV lattice's lookups beside the feature rows).  gloo / a world of one: done on return."""
     if _alone(dist):
         out[:sum(out_splits)].copy_(inp[:sum(in_splits)])
-        return
+        return _done
     o, i = out[:sum(out_splits)], inp[:sum(in_splits)]
     if _host_staged(dist, inp):
         ho = torch.empty(o.shape, dtype=o.dtype)
         dist.all_to_all_single(ho, i.cpu(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
         o.copy_(ho)
-    else:
-        dist.all_to_all_single(o, i, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
+        return _done
+    work = dist.all_to_all_single(o, i, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), async_op=True)
+    return work.wait
+
+
+def all_reduce_sum_start(dist, tensors):
+    """all_reduce_sum_ in two halves (see all_to_all_rows_start): the small tensors' bucket is all-reduced on the process
+    group's stream; the returned callable waits for it and copies the sums back.  What is launched in between must not read
+    the tensors (round 6: the table scatter beside the all-reduce of the decoder gradients and the loss sums, which only
+    the optimizer step / the loss report need)."""
+    if _alone(dist):
+        return _done
+    ts = [t for t in tensors if t is not None]
+    if not ts:
+        return _done
+    if any(_host_staged(dist, t) for t in ts) or any(t.numel() > _BUCKET_MAX_ELEMS for t in ts):
+        all_reduce_sum_(dist, ts)
+        return _done
+    by_dtype = {}
+    for t in ts:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    pending = []
+    for group in by_dtype.values():
+        flat = group[0].view(-1) if len(group) == 1 and group[0].is_contiguous() else torch.cat([t.reshape(-1) for t in group])
+        pending.append((dist.all_reduce(flat, async_op=True), flat, group))
+
+    def finish():
+        for work, flat, group in pending:
+            work.wait()
+            if len(group) == 1 and flat.data_ptr() == group[0].data_ptr():
+                continue
+            o = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view_as(t))
+                o += n
+    return finish
 
 
 # ---- the residual field over N GPUs: the hash table partitioned by LEVEL (mp_slam/sharded.py) -----------------------------

@@ -39,7 +39,8 @@ import torch
 
 from .. import _lib
 from .._lib import check, stream_ptr
-from ..dist import all_reduce_sum_, all_to_all_rows_, broadcast_, level_exchange_splits, level_partition
+from ..dist import (all_reduce_sum_, all_reduce_sum_start, all_to_all_rows_, all_to_all_rows_start, broadcast_, level_exchange_splits,
+                    level_partition)
 from .direct import DirectIterations, _StageBuffers
 
 
@@ -258,16 +259,24 @@ class LevelShardedIterations(DirectIterations):
         X = self._exchange(B, n, S, B.t.u.device)
         sref = C.byref(self._shard)
         ws, wb = B.p.ws, B.ws_bytes
-        check(lib.rfx_ba_shard_lookup(dref, sref, ws, wb, st), "rfx_ba_shard_lookup")
-        all_to_all_rows_(dist, X["feat_recv"], X["feat"][1], X["feat_send"], X["feat"][0])
+        # Issue order (round 6): what an exchange does not need is launched while it is in flight.  Under RCCL a collective
+        # runs on the process group's stream; the compute stream only waits where it reads what was exchanged.
+        #   ray batch + own levels' features  ->  feature all-to-all  ||  TV lattice, its lookups, zero-fill of the own gradient
+        check(lib.rfx_ba_shard_lookup_rays(dref, sref, ws, wb, st), "rfx_ba_shard_lookup_rays")
+        feat_done = all_to_all_rows_start(dist, X["feat_recv"], X["feat"][1], X["feat_send"], X["feat"][0])
+        check(lib.rfx_ba_shard_lookup_tv(dref, sref, ws, wb, st), "rfx_ba_shard_lookup_tv")
+        feat_done()
         check(lib.rfx_ba_shard_render(dref, sref, ws, wb, st), "rfx_ba_shard_render")
-        all_to_all_rows_(dist, X["demb_recv"], X["demb"][1], X["demb_send"], X["demb"][0])
+        #   gradient rows all-to-all, then the all-reduce of the decoder gradients / loss sums (21 KB: needed by the optimizer
+        #   step and the loss report only)  ||  the table scatter, which waits for the rows alone
+        demb_done = all_to_all_rows_start(dist, X["demb_recv"], X["demb"][1], X["demb_send"], X["demb"][0])
         small = [X["sums8"]]
         if map_grads:
             small.append(B.t.dw_flat)
             if self.report_tv:
                 small.append(B.t.tv_acc)
-        all_reduce_sum_(dist, small)
+        small_done = all_reduce_sum_start(dist, small)
+        demb_done()
         check(lib.rfx_ba_shard_scatter(dref, sref, ws, wb, st), "rfx_ba_shard_scatter")
         recv = 4 * (sum(X["feat"][1]) - X["feat"][1][self.rank] + sum(X["demb"][1]) - X["demb"][1][self.rank])      # bytes from OTHER ranks
         if d_poses_ptr:
@@ -277,6 +286,7 @@ class LevelShardedIterations(DirectIterations):
             recv += 4 * (sum(X["dx"][1]) - X["dx"][1][self.rank])
             if rba is not None:
                 check(lib.rfx_rba_backward(C.byref(rba[0]), rba[1], K, d_poses_ptr, rba[2], C.byref(rba[3]), rba[4], st), "rfx_rba_backward")
+        small_done()            # (the sums are whole from here on: the optimizer step follows this call)
         # the four losses of the WHOLE batch (and the coefficients the backward used, re-derived from the summed counts)
         check(lib.rfx_mapping_loss_finalize(X["sums8"].data_ptr(), n, S, B.p.lc, B.p.lc + 16, st), "rfx_mapping_loss_finalize")
         self.last_exchange = {"recv_bytes": recv, "points": n * S, "rays_own": X["m"]}

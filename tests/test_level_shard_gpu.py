@@ -277,6 +277,56 @@ def test_a_world_of_any_size_computes_the_single_gpu_iteration(name, frames, sma
                 assert torch.allclose(dp[:, :3], dp0[:, :3], rtol=5e-3, atol=2e-4 * scale), tag
 
 
+def test_lookup_in_two_launches_is_the_one_launch_bit_for_bit():
+    """ABI 9: rfx_ba_shard_lookup_rays followed by rfx_ba_shard_lookup_tv (the caller starts the feature all-to-all between the
+    two) leaves exactly what rfx_ba_shard_lookup leaves: the rows to send, the whole workspace (ray batch, points, lattice and
+    its features), the zero-filled own range of the gradient -- and nothing outside that range."""
+    from remixfusion_amd import _lib as L
+    from remixfusion_amd.dist import level_partition
+    lib = L.load()
+    cfg, pipe, fr = _pipeline("office0", 21, True)
+    mp, model, slam = pipe.mapper, pipe.model, pipe.slam
+    direct = mp._direct_iterations()
+    m, tr = cfg["mapping"], cfg["training"]
+    S = int(tr["n_range_d"]) + int(tr["n_samples_d"])
+    last = 20
+    b = fr[last]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    n = direct._n_rays()
+    dev = cur.device
+    st = L.stream_ptr(dev)
+    n_kf = len(mp.keyframe.frame_ids)
+    poses = slam.est_c2w_data[0:last + 1:m["keyframe_every"]].clone().float().contiguous()
+    poses_all = torch.cat([poses, slam.est_c2w_data[last:last + 1].float()], 0)[:n_kf + 1].contiguous()
+    K = poses_all.shape[0]
+    enc = model.embed_res_fn
+    for map_grads, pose in ((True, False), (False, True)):
+        B = direct._buffers(n, K, dev)
+        random.seed(5)
+        d = direct._fill(B, cur, poses_all.data_ptr(), K, pose, B.p.dposes if pose else None, map_grads, None)
+        d = type(d).from_buffer_copy(d)
+        world, q = 3, 1
+        cuts = level_partition(enc.desc, world)
+        one, two = (_alloc_rank(lib, L, direct, B, d, q, world, cuts, n, S, K, dev, map_grads, pose) for _ in range(2))
+        for r in (one, two):
+            r["ws"].zero_()
+        call = lambda fn, r: L.check(fn(C.byref(r["desc"]), C.byref(r["shard"]), r["wsp"], B.ws_bytes, st), fn.__name__)
+        call(lib.rfx_ba_shard_lookup, one)
+        call(lib.rfx_ba_shard_lookup_rays, two)
+        feat_after_rays = two["feat_send"].clone()           # complete before the lattice launch: what the all-to-all sends
+        call(lib.rfx_ba_shard_lookup_tv, two)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(one["feat_send"]).all())
+        assert torch.equal(one["feat_send"], two["feat_send"]) and torch.equal(feat_after_rays, one["feat_send"])
+        assert torch.equal(one["ws"], two["ws"])
+        if map_grads:
+            lo = int(enc.desc.offset[cuts[q]]) * 2
+            hi = (int(enc.desc.offset[cuts[q + 1] - 1]) + int(enc.desc.size[cuts[q + 1] - 1])) * 2
+            for r in (one, two):
+                assert float(r["dt"][lo:hi].abs().max()) == 0.0
+                assert bool(torch.isnan(torch.cat([r["dt"][:lo], r["dt"][hi:]])).all())
+
+
 def test_sliced_adam_steps_only_the_own_levels():
     """optim.Adam.slices: elements outside [lo, hi) keep parameter and state; inside they take torch.optim.Adam's step"""
     from remixfusion_amd.optim import Adam
