@@ -485,6 +485,45 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
             // cheap enough that merging runs in registers no longer pays): nearly every corner falls into another
             // segment, so test segment membership first and add only the corners that land here
             // (measured: 1.25-1.6x faster at 128 segments, neutral at 32, slower at 4)
+            if (lv.res <= SEG) {
+                // Round 6.  These blocks are bound by the NUMBER of LDS instructions a wave issues (a ds_add costs the CU ~10
+                // clocks however few lanes are active; round 4: profiles/r4_notes.md), and the per-corner form issues 16 per
+                // point with an eighth of the lanes in each.  The two corners of an x-PAIR always share a segment (x enters the
+                // hash un-multiplied and res <= SEG keeps it below the segment bits inside the unit cube), so a point has 4 candidates, not 8; each
+                // lane then serves its in-segment pairs ONE PER ROUND -- first, second, ... -- and the wave goes round while
+                // any lane has one left: 2.4 rounds x 4 instructions on average instead of 16.  The contributions are the
+                // per-corner form's, bit for bit (same weight products in the same order); only the order of the adds changes.
+                const unsigned msk = lv.size - 1u;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float2 gv = gvb[j];
+                    const Cell c = locate(lv, xb[j]);
+                    const unsigned y0 = c.g[1] * 2654435761u, y1 = y0 + 2654435761u;
+                    const unsigned z0 = c.g[2] * 805459861u, z1 = z0 + 805459861u;
+                    unsigned i0[4] = {(c.g[0] ^ y0 ^ z0) & msk, (c.g[0] ^ y1 ^ z0) & msk, (c.g[0] ^ y0 ^ z1) & msk, (c.g[0] ^ y1 ^ z1) & msk};
+                    const unsigned xx = (c.g[0] ^ (c.g[0] + 1u)) & msk;            // partner index = i0 ^ xx
+                    unsigned m = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m |= (((i0[k] - base) < cnt || ((i0[k] ^ xx) - base) < cnt) ? 1u : 0u) << k;
+                    if (gv.x == 0.f && gv.y == 0.f) m = 0;
+                    const float fx0 = 1.0f - c.f[0], fx1 = c.f[0];
+                    while (__ballot(m != 0u)) {                                    // wave-uniform
+                        const int k = __ffs((int)m) - 1;
+                        const unsigned ia = (k & 1) ? ((k & 2) ? i0[3] : i0[1]) : ((k & 2) ? i0[2] : i0[0]);
+                        const float wy = (k & 1) ? c.f[1] : 1.0f - c.f[1], wz = (k & 2) ? c.f[2] : 1.0f - c.f[2];
+                        if (m) {
+                            const unsigned ra = ia - base, rb = (ia ^ xx) - base;
+                            const float wa = (fx0 * wy) * wz, wb = (fx1 * wy) * wz;   // corner_weight()'s products, in its order
+                            // (a pair straddles two segments only where x + 1 crosses a multiple of SEG: a point far outside the
+                            // unit cube; each segment's block then adds its own corner)
+                            if (ra < cnt) { atomicAdd(&acc[2 * ra], (ACC)(wa * gv.x)); atomicAdd(&acc[2 * ra + 1], (ACC)(wa * gv.y)); }
+                            if (rb < cnt) { atomicAdd(&acc[2 * rb], (ACC)(wb * gv.x)); atomicAdd(&acc[2 * rb + 1], (ACC)(wb * gv.y)); }
+                        }
+                        m &= m - 1u;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const float2 gv = gvb[j];
@@ -495,11 +534,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const unsigned r = idx8[k] - base;
-#if defined(SCATTER_DBG) && SCATTER_DBG == 4
-                    if (r == 0x7fffffffu) {
-#else
                     if (r < cnt) {
-#endif
                         const float w = corner_weight(c, k);
                         atomicAdd(&acc[2 * lds_slot(r, pm)], (ACC)(w * gv.x));
                         atomicAdd(&acc[2 * lds_slot(r, pm) + 1], (ACC)(w * gv.y));
