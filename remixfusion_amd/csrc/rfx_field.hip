@@ -306,7 +306,7 @@ static size_t scatter_scratch_floats(int64_t n, int n_levels) {
     const size_t slots = (size_t)n + (size_t)((n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS + 1) * SCATTER_THREADS;
     const size_t sweep = slots * (size_t)(2 * n_levels + 3);
     if (n < SCATTER_MIN_POINTS) return sweep;              // below it nothing is staged or binned (direct atomics)
-    const size_t n_blk = (size_t)((n + 4 * 1024 - 1) / (4 * 1024));         // BIN_THREADS * BIN_PPT points per sort block
+    const size_t n_blk = (size_t)((n + 2 * 1024 - 1) / (2 * 1024));         // BIN_THREADS * BIN_PPT_DENSE points per sort block (a hashed level's take twice as many)
     const size_t one_binned = n_blk * (4 * 1024 * 8) * 4 + n_blk * (1024 + 1) + 8;           // BIN_BLOCK_RECS 16-byte records; SCATTER_BIN_MAX_SEGMENTS = 1024
     return std::max(sweep, one_binned);
 }
@@ -708,6 +708,7 @@ struct BinLevels {
     Level lv[RFX_MAX_LEVELS];
     int level[RFX_MAX_LEVELS];               // index of the level in the grid (its column pair in dfeat)
     int n_seg[RFX_MAX_LEVELS];
+    int n_blk[RFX_MAX_LEVELS];               // sort blocks of the level (a dense level's blocks take BIN_PPT_DENSE points per thread)
     int parts[RFX_MAX_LEVELS];               // reduce blocks per segment: each takes a contiguous share of the sort blocks
     int blk_base[RFX_MAX_LEVELS + 1];        // first reduce block of each level (n_seg * parts blocks per level)
     unsigned* excl[RFX_MAX_LEVELS];          // [n_blk][n_seg + 1]: where each segment's run starts inside a sort block's region
@@ -811,12 +812,118 @@ __device__ __forceinline__ void bin_sort_body(const BinLevels& B, int g, const S
     }
 }
 
+// DENSE levels.  Neighbouring points share grid cells there (a ray crosses a cell of a coarse level with a run of consecutive
+// samples -- 48 of a ray's 59 samples sit within half a metre of the surface --, the TV lattice's z-neighbours likewise), and one
+// record per point and pair means runs of records for ONE table slot: the reduce kernel's double atomics then serialise on a
+// single LDS address, lane after lane (measured, round 6: a dense level cost 70-97 us against 45 for a hashed one, with the
+// ray samples ALONE costing as much as rays + lattice).  So the lanes of a wave -- consecutive points -- first merge: a
+// segmented scan over the runs of lanes that share a cell (and have a gradient) sums the four corner contributions of every
+// x-pair, and only the LAST lane of a run ranks and writes records: two one-corner records per pair and run instead of one
+// pair record per pair and point.  Same contributions as the per-point form (corner_weight()'s products in its order), added
+// first along the run in fp32 (the sweep kernel of the small levels merges its runs the same way).
+constexpr int BIN_PPT_DENSE = 2;      // points per thread: the run sums (16 per point) have to stay in registers across the block's scan
+__device__ __forceinline__ void bin_sort_dense(const BinLevels& B, int g, const ScatterSrc& a, const ScatterSrc& b, unsigned* h, unsigned* wsum) {
+    constexpr int PPT = BIN_PPT_DENSE;
+    const Level lv = B.lv[g];
+    const int n_seg = B.n_seg[g], level = B.level[g];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < n_seg) h[t] = 0u;
+    __syncthreads();
+    unsigned ia[PPT][4], ib[PPT][4], rank[PPT][4];
+    float sum[PPT][4][4];
+    bool emit[PPT];
+    {
+        float xq[PPT][3];
+        float2 gv[PPT];
+        bool act[PPT];
+        bin_load<PPT>(a, b, (int64_t)blockIdx.x * PPT * BIN_THREADS + t, BIN_THREADS, level, xq, gv, act);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const Cell c = locate(lv, xq[q]);
+            unsigned idx[8];
+            corner_indices(lv, c, idx);
+            // runs: lanes in a row with the same cell, all with a gradient
+            const unsigned p0 = __shfl_up(c.g[0], 1), p1 = __shfl_up(c.g[1], 1), p2 = __shfl_up(c.g[2], 1);
+            const int pact = __shfl_up((int)act[q], 1);
+            const bool head = lane == 0 || !act[q] || !pact || p0 != c.g[0] || p1 != c.g[1] || p2 != c.g[2];
+            const unsigned long long heads = __ballot(head);
+            const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+            const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+            int run = lane - start + 1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) run = max(run, __shfl_xor(run, o));      // longest run of the wave
+            emit[q] = tail && act[q];
+            const float fx0 = 1.0f - c.f[0], fx1 = c.f[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float wy = (k & 1) ? c.f[1] : 1.0f - c.f[1], wz = (k >> 1) ? c.f[2] : 1.0f - c.f[2];
+                const float w0 = (fx0 * wy) * wz, w1 = (fx1 * wy) * wz;
+                float v[4] = {w0 * gv[q].x, w0 * gv[q].y, w1 * gv[q].x, w1 * gv[q].y};
+                for (int d = 1; d < run; d <<= 1) {                                    // wave-uniform trip count
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float u = __shfl_up(v[i], d);
+                        if (lane - d >= start) v[i] += u;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum[q][k][i] = v[i];
+                ia[q][k] = idx[2 * k]; ib[q][k] = idx[2 * k + 1];
+                const unsigned r0 = bin_take<true>(h, idx[2 * k] >> BIN_SEG_SHIFT, emit[q]);
+                const unsigned r1 = bin_take<true>(h, idx[2 * k + 1] >> BIN_SEG_SHIFT, emit[q]);
+                rank[q][k] = r0 | r1 << 16;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned v = t < n_seg ? h[t] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        const unsigned w = lane < BIN_THREADS / 64 ? wsum[lane] : 0u;
+        unsigned wi = w;
+#pragma unroll
+        for (int d = 1; d < BIN_THREADS / 64; d <<= 1) {
+            const unsigned u = __shfl_up(wi, d);
+            if (lane >= d) wi += u;
+        }
+        if (lane < BIN_THREADS / 64) wsum[lane] = wi - w;
+    }
+    __syncthreads();
+    const unsigned excl = incl - v + wsum[wv];
+    unsigned* __restrict__ eo = B.excl[g] + (size_t)blockIdx.x * (n_seg + 1);
+    if (t < n_seg) { h[t] = excl; eo[t] = excl; }
+    if (t == n_seg - 1) eo[n_seg] = excl + v;
+    __syncthreads();
+    BinRec* __restrict__ rec = B.rec[g] + (size_t)blockIdx.x * BIN_BLOCK_RECS;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (!emit[q]) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            BinRec r;
+            r.fx = 0.f;
+            r.slots = ia[q][k] & (BIN_SEG - 1u); r.a = sum[q][k][0]; r.b = sum[q][k][1];
+            rec[h[ia[q][k] >> BIN_SEG_SHIFT] + (rank[q][k] & 0xffffu)] = r;
+            r.slots = ib[q][k] & (BIN_SEG - 1u); r.a = sum[q][k][2]; r.b = sum[q][k][3];
+            rec[h[ib[q][k] >> BIN_SEG_SHIFT] + (rank[q][k] >> 16)] = r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void bin_sort_kernel(BinLevels B, ScatterSrc a, ScatterSrc b) {
     __shared__ unsigned h[BIN_MAX_SEGS + 1];
     __shared__ unsigned wsum[BIN_THREADS / 64];
     const int g = blockIdx.y;
+    if ((int)blockIdx.x >= B.n_blk[g]) return;                          // (the grid is as wide as the level with the most sort blocks)
     if (B.lv[g].hashed) bin_sort_body<false>(B, g, a, b, h, wsum);      // block-uniform
-    else bin_sort_body<true>(B, g, a, b, h, wsum);
+    else bin_sort_dense(B, g, a, b, h, wsum);
 }
 
 #ifndef BIN_RUNS_N
@@ -844,13 +951,13 @@ __device__ __forceinline__ void bin_add(double* acc, const BinRec& q) {
 // Wave w takes the sort blocks b0 + w, b0 + w + 16, ...: a lane per block fetches the run's bounds up front (no dependent
 // round trip per run), then the runs are read BIN_RUNS at a time, 128 records of each, before any of them is added (a block's time is a chain of
 // round trips: 16 waves, one block per CU).
-__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable, int n_blk) {
+__global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     double* acc = reinterpret_cast<double*>(acc_raw);
     int g = 0;
     while (g + 1 < B.n && (int)blockIdx.x >= B.blk_base[g + 1]) ++g;
     const Level lv = B.lv[g];
-    const int n_seg = B.n_seg[g], parts = B.parts[g];
+    const int n_seg = B.n_seg[g], parts = B.parts[g], n_blk = B.n_blk[g];
     const unsigned local = blockIdx.x - (unsigned)B.blk_base[g];
     const unsigned seg = local / (unsigned)parts, part = local % (unsigned)parts;
     const int b0 = (int)((int64_t)part * n_blk / parts), b1 = (int)((int64_t)(part + 1) * n_blk / parts);
@@ -949,12 +1056,15 @@ static bool level_is_binned(const rfx_grid_desc& g, int l) {
     return segs >= (unsigned)SCATTER_BIN_MIN_SEGMENTS && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
 }
 
-static inline size_t bin_sort_blocks(int64_t n_all) { return (size_t)((n_all + BIN_THREADS * BIN_PPT - 1) / (BIN_THREADS * BIN_PPT)); }
+static inline size_t bin_sort_blocks(int64_t n_all, bool hashed) {
+    const int64_t per = (int64_t)BIN_THREADS * (hashed ? BIN_PPT : BIN_PPT_DENSE);
+    return (size_t)((n_all + per - 1) / per);
+}
 
 // scratch one binned level needs: the sort blocks' record regions + their exclusive offsets [n_blk][n_seg + 1]
 static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) {
     const size_t n_seg = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
-    const size_t n_blk = bin_sort_blocks(n_all);
+    const size_t n_blk = bin_sort_blocks(n_all, g.hashed[l] != 0);
     return n_blk * BIN_BLOCK_RECS * BIN_REC_FLOATS + ((n_blk * (n_seg + 1) + 3) & ~(size_t)3) + 4;      // (records stay 16-byte aligned; + 4: the alignment slack)
 }
 
@@ -964,7 +1074,6 @@ static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) 
 static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n_lv, const ScatterSrc& a, const ScatterSrc& b,
                                 float* dtable, float* scratch, size_t scratch_floats, hipStream_t st) {
     const int64_t n_all = a.n + b.n;
-    const int n_blk = (int)bin_sort_blocks(n_all);
     const size_t lds = (size_t)BIN_SEG * 2 * sizeof(double);
     {   // records are 16-byte accesses, the caller's workspace is 8-byte aligned: binned_level_floats() carries the slack
         const size_t skip = (size_t)((16 - ((uintptr_t)scratch & 15)) & 15) / sizeof(float);
@@ -985,18 +1094,23 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
         B.n = 0;
         B.blk_base[0] = 0;
         size_t used = 0;
+        int max_blk = 0;
         while (i < n_lv && B.n < RFX_MAX_LEVELS) {
             const int l = levels[i];
             const size_t need = (binned_level_floats(g, l, n_all) + 3) & ~(size_t)3;
             if (used + need > scratch_floats) break;
             const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
+            const int n_blk = (int)bin_sort_blocks(n_all, g.hashed[l] != 0);
             const int k = B.n++;
+            B.n_blk[k] = n_blk;
+            max_blk = std::max(max_blk, n_blk);
             B.lv[k].scale = g.scale[l]; B.lv[k].res = g.res[l]; B.lv[k].size = g.size[l]; B.lv[k].offset = g.offset[l]; B.lv[k].hashed = g.hashed[l];
             B.level[k] = l; B.n_seg[k] = n_seg;
             // reduce blocks per segment: ~BIN_CHUNK records each.  A hashed level spreads its 4 n_all pairs evenly over the
             // segments; a dense level's segments are slabs of space of which a scene (and the TV lattice, a small cube) fills
             // a fraction: priced as if a quarter of them held everything
-            const double per_seg = (double)n_all * 4.0 * (g.hashed[l] ? 1.0 : BIN_DENSE_FACTOR) / n_seg;
+            // (a dense level's runs are merged before they become records: two per pair and run, priced at half a pair record per point)
+            const double per_seg = (double)n_all * 4.0 * (g.hashed[l] ? 1.0 : 0.5 * BIN_DENSE_FACTOR) / n_seg;
             B.parts[k] = std::max(1, std::min(n_blk, (int)(per_seg / BIN_CHUNK + 0.5)));
             B.blk_base[k + 1] = B.blk_base[k] + n_seg * B.parts[k];
             float* base = scratch + used;
@@ -1008,8 +1122,9 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
         if (debug) fprintf(stderr, "[bins] group of %d levels (%d of %d done), %zu of %zu floats, %lld points\n", B.n, i, n_lv, used, scratch_floats, (long long)n_all);
         if (B.n == 0) return RFX_ERR_WORKSPACE;
         for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.blk_base[k] = B.blk_base[B.n];
-        hipLaunchKernelGGL(bin_sort_kernel, dim3(n_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b);
-        hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable, n_blk);
+        for (int k = B.n; k < RFX_MAX_LEVELS; ++k) B.n_blk[k] = 0;
+        hipLaunchKernelGGL(bin_sort_kernel, dim3(max_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b);
+        hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable);
         RFX_LAUNCH_CHECK();
     }
     return RFX_OK;

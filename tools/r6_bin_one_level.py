@@ -17,7 +17,8 @@ d = pipe.mapper._direct_iterations(); d.stagewise_every = 1
 for i in range(26, 32): pipe.step(i, frames[i])
 torch.cuda.synchronize()
 B = [v for k, v in d._cache.items() if k[0] == "stage"][0]
-x = torch.cat([B.t.x01.clone(), B.t.pts.clone()]).contiguous()
+src = os.environ.get("SRC", "both")           # both | rays | lattice
+x = (B.t.x01.clone() if src == "rays" else B.t.pts.clone() if src == "lattice" else torch.cat([B.t.x01.clone(), B.t.pts.clone()])).contiguous()
 n = x.shape[0]
 lib = L.load(); enc = pipe.model.embed_res_fn; st = L.stream_ptr(x.device)
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -25,7 +26,7 @@ sizes = list(enc.desc.size)[:16]
 binned = [l for l in range(16) if -(-sizes[l] // 8192) >= 12]
 sel = os.environ.get("LEVELS", "")
 levels = [] if sel == "all" else [int(v) for v in sel.split(",")] if sel else binned
-print(name, "points", n, "(ray samples", B.t.x01.shape[0], "+ lattice", B.t.pts.shape[0], ")")
+print(name, "source", src, "points", n, "(ray samples", B.t.x01.shape[0], "+ lattice", B.t.pts.shape[0], ")")
 df = torch.randn((n, 2), device="cuda", generator=g)
 dt = torch.zeros_like(enc.params)
 for l in levels:
