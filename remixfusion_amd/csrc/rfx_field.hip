@@ -1976,7 +1976,9 @@ size_t rfx_grid_encode_backward_workspace_bytes_for(const rfx_grid_desc* g, int6
     if (n >= SCATTER_MIN_POINTS)
         for (int l = 0; l < g->n_levels; ++l)
             if (level_is_binned(*g, l)) all += (binned_level_floats(*g, l, n) + 3) & ~(size_t)3;
-    return std::max(need, all) * sizeof(float);
+    // (+ 128 floats: the callers that carve this region out of a larger workspace round it down to whole 256-byte units, and the
+    //  record base is aligned up to 16 bytes: without the margin the last level missed the group by a few floats -- round 6)
+    return (std::max(need, all) + 128) * sizeof(float);
 }
 
 int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const float* x01, int64_t n,
@@ -2309,8 +2311,11 @@ int rfx_field_backward_scatter(const rfx_field_desc* f, const float* x01, int64_
     if (!workspace || workspace_bytes < rfx_field_backward_workspace_bytes(n)) return RFX_ERR_WORKSPACE;
     BwdWs ws = carve(workspace, n);
     if (d_hash) {
+        // the scatter's region is the last of the workspace: whatever the caller hands over beyond the minimum lets more binned
+        // levels (T >= 2^19) share a group of launches (rfx_grid_encode_backward_workspace_bytes_for says how much all of them need)
+        const size_t avail = (workspace_bytes - (size_t)((char*)ws.demb_t - (char*)workspace)) / sizeof(float);
         rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, ws.demb_t, as_stream(stream), nullptr, nullptr, 0, 0,
-                                 sel_on(n) ? ws.perm : nullptr, sel_on(n) ? ws.sel_hdr : nullptr);
+                                 sel_on(n) ? ws.perm : nullptr, sel_on(n) ? ws.sel_hdr : nullptr, nullptr, nullptr, avail);
         if (rc) return rc;
         RFX_LAUNCH_CHECK();
     }

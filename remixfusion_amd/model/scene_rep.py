@@ -64,7 +64,7 @@ class _FieldFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need[0] else None
         dt = torch.zeros_like(table) if need[1] else None
         dws = [torch.zeros_like(w) if nd else None for w, nd in zip((w1, w2, w3, w4), need[2:6])]
-        ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n), x.device)
+        ws = model._workspace(model._backward_workspace_bytes(n), x.device)
         desc = model._field_desc(ctx.clamp)
         _field_backward_staged(lib, desc, x, n, draw.contiguous(), dt, dws, dx, ws, stream_ptr(x.device))
         return dx, dt, dws[0], dws[1], dws[2], dws[3], None, None
@@ -199,7 +199,7 @@ class _MappingFn(torch.autograd.Function):
         dx = torch.empty_like(x01) if want_dx else None
         dt = torch.zeros_like(table) if need[4] else None
         dws = [torch.zeros_like(w) if nd else None for w, nd in zip((w1, w2, w3, w4), need[5:9])]
-        ws = model._workspace(lib.rfx_field_backward_workspace_bytes(n * S), dev)
+        ws = model._workspace(model._backward_workspace_bytes(n * S), dev)
         desc = model._field_desc(ctx.clamp)
         _field_backward_staged(lib, desc, x01, n * S, d_raw, dt, dws, dx, ws, st)
         go = gd = None
@@ -312,6 +312,15 @@ class JointEncoding(nn.Module):
         s.near, s.far, s.range_d = float(cam["near"]), float(cam["far"]), float(tr["range_d"])
         s.n_range_d, s.n_samples_d, s.perturb = int(tr["n_range_d"]), int(tr["n_samples_d"]), float(tr["perturb"])
         return s
+
+    def _backward_workspace_bytes(self, n: int) -> int:
+        """workspace of the field backward for n points: the library's minimum + what lets the table scatter (its last region)
+        keep ALL binned levels of a large table (T >= 2^19) in one group of launches (the first-frame mapping's 500-1000
+        iterations ran them one level at a time until round 6); equal to the minimum for small tables"""
+        lib = _lib.load()
+        enc = self.embed_res_fn
+        extra = int(lib.rfx_grid_encode_backward_workspace_bytes_for(C.byref(enc.desc), n)) - int(lib.rfx_grid_encode_backward_workspace_bytes(n, int(enc.desc.n_levels)))
+        return int(lib.rfx_field_backward_workspace_bytes(n)) + max(extra, 0)
 
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
         n = (nbytes + 3) // 4
