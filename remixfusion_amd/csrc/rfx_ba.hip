@@ -146,6 +146,13 @@ static int shard_call(const rfx_ba_desc* b, const rfx_ba_shard* s, void* workspa
     return RFX_OK;
 }
 
+// level of the own sub-grid from which rfx_ba_shard_scatter writes the gradient (and rfx_ba_shard_lookup[_tv] skips the zero-fill):
+// both calls see the same descriptor, so both get the same answer
+static int shard_overwrite_level(const rfx_ba_desc* b, const ShardCall& c) {
+    if (!c.map_grads || b->d_poses16) return c.g.k;
+    return scatter_overwrite_from_level(c.g.own, c.nS + c.nt, true, b->d_hash);
+}
+
 }  // namespace rfx
 
 using namespace rfx;
@@ -206,12 +213,16 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const bool tv_on = map_grads || b->tv_sum;
     if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
     const float trunc_loss = b->trunc * b->sc_factor;
+    // map phase: the trailing hashed levels of a large table are WRITTEN by the scatter (one block per segment), so their part of
+    // d_hash is neither zero-filled here nor read back there (round 6: 300 MB per iteration at T = 2^21)
+    const int ow_level = (map_grads && !b->d_poses16) ? scatter_overwrite_from_level(b->field.hash, nS + nt, true, b->d_hash) : L;
+    const int64_t zero_floats = !map_grads ? 0 : ow_level < L ? (int64_t)b->field.hash.offset[ow_level] * F : (int64_t)b->hash_entries * F;
     int n_cnt = 0;
     RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                         b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
                         b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, P, b->tv_voxel,
                         b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
-                        map_grads ? b->d_hash : nullptr, map_grads ? (int64_t)b->hash_entries * F : 0, trunc_loss, b->depth_trunc,
+                        map_grads ? b->d_hash : nullptr, zero_floats, trunc_loss, b->depth_trunc,
                         w.cnt, &n_cnt, stream));            // ... and counts what the loss coefficients are made of
     // ---- forward
     // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
@@ -236,7 +247,7 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     float* dw4 = dw1 ? dw3 + 32 * 66 : nullptr;
     if (map_grads && !b->d_poses16) {     // map phase: weight gradients and table scatter back to back (they share a launch)
         return field_backward_weights_scatter(&b->field, w.x01, nS, w.d_raw, dw1, dw2, dw3, dw4, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws,
-                                              w.bwd_bytes, w.scat_ws, w.scat_bytes, stream);
+                                              w.bwd_bytes, w.scat_ws, w.scat_bytes, stream, ow_level < L ? ow_level : RFX_MAX_LEVELS + 1);
     }
     if (map_grads) RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
     if (b->d_poses16) {
@@ -281,7 +292,10 @@ static int shard_lookup_parts(const rfx_ba_desc* b, const rfx_ba_shard* s, void*
     if (!b->seed_u && tv_on && !b->u6) return RFX_ERR_ARG;
     // the part of the gradient buffer that belongs to the own levels (a contiguous range of levels: one contiguous range)
     const int64_t z0 = (int64_t)c.g.own.offset[0] * c.F;
-    const int64_t z1 = ((int64_t)c.g.own.offset[c.g.k - 1] + c.g.own.size[c.g.k - 1]) * c.F;
+    int64_t z1 = ((int64_t)c.g.own.offset[c.g.k - 1] + c.g.own.size[c.g.k - 1]) * c.F;
+    // (map phase: the scatter writes the trailing hashed levels of the own range itself -- see rfx_ba_forward_backward)
+    const int ow_level = shard_overwrite_level(b, c);
+    if (ow_level < c.g.k) z1 = (int64_t)c.g.own.offset[ow_level] * c.F;
     int n_cnt = 0;
     RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                         b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
@@ -345,9 +359,11 @@ int rfx_ba_shard_scatter(const rfx_ba_desc* b, const rfx_ba_shard* s, void* work
     ShardCall c;
     RFX_TRY(shard_call(b, s, workspace, workspace_bytes, &c));
     const BaWs& w = c.w;
-    if (c.map_grads)
-        RFX_TRY(rfx_grid_encode_backward_merged(&c.g.own, b->field.hash_table, w.x01, c.nS, s->demb_recv, w.pts, c.nt, w.dfeat,
-                                                b->d_hash, w.scat_ws, w.scat_bytes, stream));
+    if (c.map_grads) {
+        const int ow_level = shard_overwrite_level(b, c);
+        RFX_TRY(grid_encode_backward_merged_from(&c.g.own, b->field.hash_table, w.x01, c.nS, s->demb_recv, w.pts, c.nt, w.dfeat,
+                                                 b->d_hash, w.scat_ws, w.scat_bytes, stream, ow_level < c.g.k ? ow_level : RFX_MAX_LEVELS + 1));
+    }
     if (b->d_poses16)
         RFX_TRY(rfx_grid_encode_backward(&c.g.own, b->field.hash_table, w.x01, c.nS, s->demb_recv, nullptr, s->dx_send, nullptr, 0,
                                          stream));

@@ -710,6 +710,8 @@ struct BinLevels {
     int n_seg[RFX_MAX_LEVELS];
     int n_blk[RFX_MAX_LEVELS];               // sort blocks of the level (a dense level's blocks take BIN_PPT_DENSE points per thread)
     int parts[RFX_MAX_LEVELS];               // reduce blocks per segment: each takes a contiguous share of the sort blocks
+    int overwrite[RFX_MAX_LEVELS];           // 1: the level's part of dtable is WRITTEN (every segment by its one block, zeros included),
+                                             //    not added to: the caller skipped its zero-fill (scatter_overwrite_from_level)
     int blk_base[RFX_MAX_LEVELS + 1];        // first reduce block of each level (n_seg * parts blocks per level)
     unsigned* excl[RFX_MAX_LEVELS];          // [n_blk][n_seg + 1]: where each segment's run starts inside a sort block's region
     BinRec* rec[RFX_MAX_LEVELS];             // [n_blk][BIN_BLOCK_RECS]
@@ -1018,12 +1020,18 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, fl
             }
         }
     }
-    if (!zeroed) return;                                  // block-uniform
+    float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
+    if (!zeroed) {                                        // block-uniform: no record for this (segment, share)
+        if (B.overwrite[g]) {                             // ... but the segment is this block's to define
+            float4* __restrict__ o4 = reinterpret_cast<float4*>(out);
+            for (unsigned i = threadIdx.x; i < cnt / 2; i += BIN_THREADS) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
 #if defined(BIN_DBG) && (BIN_DBG & 2)
     if (cnt != 12345u) return;
 #endif
     __syncthreads();
-    float* __restrict__ out = dtable + ((size_t)lv.offset + base) * 2;
     #ifndef BIN_FLUSH_ATOMIC
     if (parts == 1 && (cnt & 1u) == 0u && ((uintptr_t)out & 15) == 0) {
         // this block is the segment's only writer in the launch (and the other kernels of a scatter touch other levels): a plain
@@ -1031,6 +1039,16 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, fl
         // per level of 2^21 entries were most of the kernel (round 6: 254 us for 12 levels with them)
         float4* __restrict__ o4 = reinterpret_cast<float4*>(out);
         constexpr int NV = BIN_SEG / 2 / BIN_THREADS;       // 4: all of a thread's loads are issued before the first add
+        if (B.overwrite[g]) {
+            // the caller left this level's part of the gradient buffer UNINITIALISED (no zero-fill: 16.8 MB per level of 2^21
+            // entries not written, and not read back here): the sums are stored, zeros included
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const unsigned i = threadIdx.x + k * BIN_THREADS;
+                if (i < cnt / 2) o4[i] = make_float4((float)acc[4 * i], (float)acc[4 * i + 1], (float)acc[4 * i + 2], (float)acc[4 * i + 3]);
+            }
+            return;
+        }
         float4 v[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = o4[min(threadIdx.x + k * BIN_THREADS, cnt / 2 - 1u)];          // unconditional: see bin_load
@@ -1071,8 +1089,19 @@ static size_t binned_level_floats(const rfx_grid_desc& g, int l, int64_t n_all) 
 // the binned levels `levels[0..n_lv)` through the two kernels above, as many levels per group of launches as the scratch
 // holds (at least one: the caller's minimum, rfx_grid_encode_backward_workspace_bytes = scatter_scratch_floats, covers one
 // level of any admissible segment count for every n_levels)
+static int bin_parts(const rfx_grid_desc& g, int l, int64_t n_all) {
+    const int n_seg = (int)((g.size[l] + BIN_SEG - 1) / BIN_SEG);
+    const int n_blk = (int)bin_sort_blocks(n_all, g.hashed[l] != 0);
+    // reduce blocks per segment: ~BIN_CHUNK records each.  A hashed level spreads its 4 n_all pairs evenly over the
+    // segments; a dense level's segments are slabs of space of which a scene (and the TV lattice, a small cube) fills
+    // a fraction: priced as if a quarter of them held everything
+    // (a dense level's runs are merged before they become records: two per pair and run, priced at half a pair record per point)
+    const double per_seg = (double)n_all * 4.0 * (g.hashed[l] ? 1.0 : 0.5 * BIN_DENSE_FACTOR) / n_seg;
+    return std::max(1, std::min(n_blk, (int)(per_seg / BIN_CHUNK + 0.5)));
+}
+
 static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n_lv, const ScatterSrc& a, const ScatterSrc& b,
-                                float* dtable, float* scratch, size_t scratch_floats, hipStream_t st) {
+                                float* dtable, float* scratch, size_t scratch_floats, hipStream_t st, int overwrite_from_level) {
     const int64_t n_all = a.n + b.n;
     const size_t lds = (size_t)BIN_SEG * 2 * sizeof(double);
     {   // records are 16-byte accesses, the caller's workspace is 8-byte aligned: binned_level_floats() carries the slack
@@ -1106,12 +1135,9 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
             max_blk = std::max(max_blk, n_blk);
             B.lv[k].scale = g.scale[l]; B.lv[k].res = g.res[l]; B.lv[k].size = g.size[l]; B.lv[k].offset = g.offset[l]; B.lv[k].hashed = g.hashed[l];
             B.level[k] = l; B.n_seg[k] = n_seg;
-            // reduce blocks per segment: ~BIN_CHUNK records each.  A hashed level spreads its 4 n_all pairs evenly over the
-            // segments; a dense level's segments are slabs of space of which a scene (and the TV lattice, a small cube) fills
-            // a fraction: priced as if a quarter of them held everything
-            // (a dense level's runs are merged before they become records: two per pair and run, priced at half a pair record per point)
-            const double per_seg = (double)n_all * 4.0 * (g.hashed[l] ? 1.0 : 0.5 * BIN_DENSE_FACTOR) / n_seg;
-            B.parts[k] = std::max(1, std::min(n_blk, (int)(per_seg / BIN_CHUNK + 0.5)));
+            B.parts[k] = bin_parts(g, l, n_all);
+            B.overwrite[k] = l >= overwrite_from_level ? 1 : 0;
+            if (B.overwrite[k] && (!g.hashed[l] || B.parts[k] != 1 || ((uintptr_t)dtable & 15))) return RFX_ERR_ARG;      // (scatter_overwrite_from_level's promise)
             B.blk_base[k + 1] = B.blk_base[k] + n_seg * B.parts[k];
             float* base = scratch + used;
             B.rec[k] = reinterpret_cast<BinRec*>(base);
@@ -1122,7 +1148,7 @@ static int launch_binned_levels(const rfx_grid_desc& g, const int* levels, int n
         if (debug) fprintf(stderr, "[bins] group of %d levels (%d of %d done), %zu of %zu floats, %lld points\n", B.n, i, n_lv, used, scratch_floats, (long long)n_all);
         if (B.n == 0) return RFX_ERR_WORKSPACE;
         for (int k = B.n + 1; k <= RFX_MAX_LEVELS; ++k) B.blk_base[k] = B.blk_base[B.n];
-        for (int k = B.n; k < RFX_MAX_LEVELS; ++k) B.n_blk[k] = 0;
+        for (int k = B.n; k < RFX_MAX_LEVELS; ++k) { B.n_blk[k] = 0; B.overwrite[k] = 0; }
         hipLaunchKernelGGL(bin_sort_kernel, dim3(max_blk, B.n), dim3(BIN_THREADS), 0, st, B, a, b);
         hipLaunchKernelGGL(bin_reduce_kernel, dim3(B.blk_base[B.n]), dim3(BIN_THREADS), lds, st, B, dtable);
         RFX_LAUNCH_CHECK();
@@ -1136,7 +1162,7 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
                                int ld, float* dtable, float* scratch, hipStream_t st, const float* x01_b = nullptr,
                                const float* dfeat_b = nullptr, int ld_b = 0, int64_t n_b = 0, const int* perm = nullptr,
                                const int* n_sel = nullptr, const DwJob* dw = nullptr, bool* dw_taken = nullptr,
-                               size_t scratch_avail_floats = 0) {
+                               size_t scratch_avail_floats = 0, int overwrite_from_level = RFX_MAX_LEVELS + 1) {
     ScatterPlan plan;
     if (dw_taken) *dw_taken = false;
     const int64_t n_all = n + n_b;
@@ -1157,6 +1183,7 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     }
     for (int l = g.n_levels; l <= RFX_MAX_LEVELS; ++l) plan.seg_start[l] = total;
     if (!staged_ok || total > SCATTER_MAX_SEGMENTS) {
+        if (overwrite_from_level < g.n_levels) return RFX_ERR_ARG;          // (never promised on this path: scatter_overwrite_from_level)
         if (n > 0)
             hipLaunchKernelGGL(grid_encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, table, x01, n,
                                dfeat, ld, dtable, (float*)nullptr, 0, perm, n_sel);
@@ -1204,10 +1231,31 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     int bl[RFX_MAX_LEVELS], n_bl = 0;
     for (int l = 0; l < g.n_levels; ++l) if (binned[l]) bl[n_bl++] = l;
     if (n_bl > 0) {       // (after the sweep: the records re-use the staging buffer)
-        const int rc = launch_binned_levels(g, bl, n_bl, a, b, dtable, scratch, std::max(scratch_floats, scratch_avail_floats), st);
+        const int rc = launch_binned_levels(g, bl, n_bl, a, b, dtable, scratch, std::max(scratch_floats, scratch_avail_floats), st, overwrite_from_level);
         if (rc) return rc;
     }
     return RFX_OK;
+}
+
+// First level from which the scatter of n_all points into `dtable` WRITES the levels' gradient instead of adding to it -- so the
+// caller need not zero that part first: the trailing levels that are hashed, binned and reduced by exactly one block per segment
+// (the levels of 2^19-2^21 entries: 8 B per entry of zero-fill and 8 B of read-back saved, 300 MB per iteration at T = 2^21).
+// g.n_levels when there is none (small tables, the direct-atomics fallback, a misaligned buffer).  launch_grid_scatter() takes
+// the same number and refuses a promise it cannot keep.
+int scatter_overwrite_from_level(const rfx_grid_desc& g, int64_t n_all, bool have_scratch, const float* dtable) {
+    if (!have_scratch || n_all < SCATTER_MIN_POINTS || ((uintptr_t)dtable & 15)) return g.n_levels;
+    unsigned largest = 0;
+    for (int l = 0; l < g.n_levels; ++l) if (!level_is_binned(g, l)) largest = std::max(largest, g.size[l]);
+    const unsigned seg_entries = largest < 16u * SCATTER_SEG ? SCATTER_SEG / 2 : SCATTER_SEG;
+    int total = 0;
+    for (int l = 0; l < g.n_levels; ++l) if (!level_is_binned(g, l)) total += (int)((g.size[l] + seg_entries - 1) / seg_entries);
+    if (total > SCATTER_MAX_SEGMENTS) return g.n_levels;
+    int from = g.n_levels;
+    for (int l = g.n_levels - 1; l >= 0; --l) {
+        if (!(level_is_binned(g, l) && g.hashed[l] && bin_parts(g, l, n_all) == 1 && (g.size[l] & 1u) == 0 && (g.offset[l] & 1u) == 0)) break;
+        from = l;
+    }
+    return from;
 }
 
 __global__ __launch_bounds__(256) void oneblob_forward_kernel(const float* __restrict__ x01, int64_t n, int fp16,
@@ -2153,6 +2201,16 @@ int rfx_field_backward_demb_rows(int64_t n, const rfx_level_rows* rows, const do
 int rfx_grid_encode_backward_merged(const rfx_grid_desc* g, const float* table, const float* x01_a, int64_t n_a,
                                     const float* dfeat_a, const float* x01_b, int64_t n_b, const float* dfeat_b, float* dtable,
                                     void* workspace, size_t workspace_bytes, rfx_stream stream) {
+    return grid_encode_backward_merged_from(g, table, x01_a, n_a, dfeat_a, x01_b, n_b, dfeat_b, dtable, workspace, workspace_bytes, stream,
+                                            RFX_MAX_LEVELS + 1);
+}
+
+}  // extern "C"
+
+namespace rfx {
+int grid_encode_backward_merged_from(const rfx_grid_desc* g, const float* table, const float* x01_a, int64_t n_a,
+                                     const float* dfeat_a, const float* x01_b, int64_t n_b, const float* dfeat_b, float* dtable,
+                                     void* workspace, size_t workspace_bytes, rfx_stream stream, int overwrite_from_level) {
     if (n_a < 0 || n_b < 0) return RFX_ERR_ARG;
     if (n_a + n_b == 0) return RFX_OK;
     if (!g || !table || !dtable || (n_a > 0 && (!x01_a || !dfeat_a)) || (n_b > 0 && (!x01_b || !dfeat_b))) return RFX_ERR_ARG;
@@ -2163,12 +2221,15 @@ int rfx_grid_encode_backward_merged(const rfx_grid_desc* g, const float* table, 
     if (n_a == 0) {           // the first source carries the selection in the fused callers: keep it the non-empty one
         return launch_grid_scatter(*g, table, x01_b, n_b, dfeat_b, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
                                    as_stream(stream), nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr,
-                                   workspace ? workspace_bytes / sizeof(float) : 0);
+                                   workspace ? workspace_bytes / sizeof(float) : 0, overwrite_from_level);
     }
     return launch_grid_scatter(*g, table, x01_a, n_a, dfeat_a, g->n_levels * 2, dtable, reinterpret_cast<float*>(workspace),
                                as_stream(stream), x01_b, dfeat_b, g->n_levels * 2, n_b, nullptr, nullptr, nullptr, nullptr,
-                               workspace ? workspace_bytes / sizeof(float) : 0);
+                               workspace ? workspace_bytes / sizeof(float) : 0, overwrite_from_level);
 }
+}  // namespace rfx
+
+extern "C" {
 
 static int launch_backward_chain(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, void* workspace,
                                  size_t workspace_bytes, rfx_stream stream, bool rows, bool dxfull, bool stashed = false,
@@ -2384,8 +2445,9 @@ namespace rfx {
 int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
                                    float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
-                                   rfx_stream stream) {
+                                   rfx_stream stream, int overwrite_from_level) {
     if (!d_hash || (n == 0 && extra_n == 0)) {
+        if (d_hash && overwrite_from_level <= RFX_MAX_LEVELS) return RFX_ERR_ARG;
         int rc = launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true);
         if (rc) return rc;
         return rfx_field_backward_scatter_merged(f, x01, n, extra_x01, extra_dfeat, extra_n, d_hash, workspace, workspace_bytes, scatter_ws,
@@ -2407,7 +2469,7 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
     rc = launch_grid_scatter(k.hash, k.table, x01, n, ws.dx1, LD_DX1, d_hash, reinterpret_cast<float*>(scatter_ws), as_stream(stream),
                              extra_x01, extra_dfeat, k.hash.n_levels * 2, extra_n, sel_on(n) ? ws.perm : nullptr,
                              sel_on(n) ? ws.sel_hdr : nullptr, job.partial ? &job : nullptr, &taken,
-                             scatter_ws ? scatter_bytes / sizeof(float) : 0);
+                             scatter_ws ? scatter_bytes / sizeof(float) : 0, overwrite_from_level);
     if (rc) return rc;
     if (job.partial && !taken) {          // no staging launch on this path: the stand-alone second stage
         hipLaunchKernelGGL(field_dw_reduce_kernel<true>, dim3((DW_TOTAL + 63) / 64), dim3(1024), 0, as_stream(stream), job.partial,
