@@ -274,8 +274,9 @@ _BIN_SEG, _BIN_MIN_SEGMENTS = 8192, 12       # csrc/rfx_field.hip: levels of >= 
 # step, 7 arrays streamed over its 2.1e6 entries.  The costs are not exactly additive (grouped launches, bandwidth shared
 # between phases); these three numbers reproduce the best partitions found by measurement at N = 2, 4 and 8.
 _SMALL_LEVEL_COST, _BINNED_DENSE_COST, _BINNED_HASHED_COST = 1.0, 2.0, 2.6
-_SWEEP_UNITS_BINNED = 3.6                    # the TIME model's units (choose_field_mode): a binned level's scatter against a small
-                                             # level's, single GPU (profiles/r3_notes.md: 62 us against 17 us per merged scatter)
+_SWEEP_UNITS_BINNED = 3.1                    # the TIME model's units (choose_field_mode): a binned level's scatter against a small
+                                             # level's, single GPU (round 6, profiles/r6_scatter_16_levels.txt: cafeteria's 494 us =
+                                             # 4 small levels at 12 us + 12 binned ones at 37 us; round 3: 62 us against 17 us = 3.6)
 
 
 def _binned(desc, l: int) -> bool:
