@@ -567,8 +567,8 @@ def _free_port():
 def launch_ranks(args):
     """`python bench.py --gpus N` without an external launcher: start the N ranks as FRESH child processes (torch.distributed.run,
     rendezvous on 127.0.0.1) and leave with their status.  This parent has not touched the GPU (no HIP call, no
-    torch.cuda.is_available()) and never does; nothing is exec'ed over a running process.  The children's stdout / stderr are
-    this process's own, so rank 0's JSON line streams through unchanged."""
+    torch.cuda.is_available()) and never does; nothing is exec'ed over a running process.  The children's stderr is this
+    process's own; of their stdout the JSON line passes through unchanged (see below)."""
     import subprocess
     port = os.environ.get("RFX_BENCH_MASTER_PORT") or str(_free_port())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -576,8 +576,21 @@ def launch_ranks(args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", RFX_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    # the children's stdout is filtered: ONE JSON line is the contract, and libraries of the ranks write there too (gloo's
+    # "[Gloo] Rank 0 is connected to ..." notices): only lines that are JSON objects pass, the rest goes to stderr
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
     try:
+        for line in child.stdout:
+            t = line.strip()
+            is_json = False
+            if t.startswith("{") and t.endswith("}"):
+                try:
+                    json.loads(t)
+                    is_json = True
+                except ValueError:
+                    pass
+            (sys.stdout if is_json else sys.stderr).write(line)
+            (sys.stdout if is_json else sys.stderr).flush()
         rc = child.wait()
     except KeyboardInterrupt:
         child.terminate()              # the exact child we started, never a pattern
