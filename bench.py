@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--config", default="office0", help="N = 1 workload (and the rooms of --rooms)")
     ap.add_argument("--first-iters", type=int, default=None, help="override mapping.first_iters (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="N = 1, office0: skip the short runs of BASELINE configs 3-5 at their one-GPU sizes (scene0000, cafeteria, apartment) "
+                         "whose frames/s and binned-scatter roofline the line carries as `other_configs`")
+    ap.add_argument("--side-steps", type=int, default=20, help="timed frames of each side-config run (after 10 warm-up frames)")
     ap.add_argument("--render-frames", type=int, default=3)
     ap.add_argument("--frame-times", action="store_true", help="print host and GPU time per timed frame to stderr")
     ap.add_argument("--no-process-warmup", action="store_true", help="skip the throwaway pipeline that loads kernels / primes the allocator")
@@ -188,6 +192,36 @@ def cpu_baseline(cfg, frame, model_points: int):
                       f"{upd} voxels updated; median of 3) + torch-CPU oracle field fwd+bwd on {sample} of {n_pts_iter} points/iter "
                       f"on {cores} cores ({t_iter_sample:.2f} s, median of 5), {iters_per_frame:g} iters/frame",
             "v1_seconds": round(t_v1, 3), "field_iter_seconds_scaled": round(t_iter, 2)}
+
+
+def side_configs(args):
+    """BASELINE configs 3-5 at their one-GPU sizes, each as a short run of this script in a CHILD process (a fresh pipeline, its
+    own allocator; this process keeps the GPU initialised and starts a child, it never exec's): frames/s and the roofline of the
+    E1 backward scatter, whose binned form (tables of 2^19-2^21 entries) the office0 workload never runs.  Measured live, like
+    everything else in the line; `traffic` from the committed PMC passes of each config (profiles/r6_pmc_traffic_<config>.json)."""
+    import subprocess
+    out = {}
+    for name in ("scene0000", "cafeteria", "apartment"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", name, "--steps", str(args.side_steps), "--warmup", "10",
+               "--no-cpu-baseline", "--render-frames", "0", "--no-side-configs"]
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+            lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            if res.returncode != 0 or not lines:
+                out[name] = {"error": (res.stderr or "no output")[-300:]}
+                continue
+            d = json.loads(lines[-1])
+            sc = d["rooflines"].get("field_backward_scatter", {})
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                         "metric": d["metric"], "workload": d["config"]["workload"], "dominant_call": d["dominant_call"],
+                         "field_backward_scatter": {k: sc.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_scatter_bytes_only",
+                                                                           "traffic", "points_per_launch", "avg_ms")},
+                         "calls_timed": {k: v["calls_timed"] for k, v in d["kernels"].items() if "scatter" in k},
+                         "seconds": round(time.perf_counter() - t0, 1)}
+        except Exception as e:        # noqa: BLE001 -- a side figure must not cost the headline line
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def field_rooflines(summ, cfg, merged_scatter=True):
@@ -924,6 +958,16 @@ def main():
         tv_pts = (tr["smooth_pts"] - 1) ** 3
         base = cpu_baseline(cfg, frames[n_frames - 1], n_rays * S + tv_pts)
 
+    vol_dim_str = "x".join(str(int(v)) for v in pipe.mv.vol_dim)
+    streams_str = "V1 on its own HIP stream, concurrent with the mapper" if getattr(pipe, "mv_stream", None) is not None else "one stream"
+    other = None
+    if world == 1 and args.config == "office0" and not args.no_side_configs:
+        del pipe, frames
+        import gc as _gc
+        _gc.collect()
+        torch.cuda.empty_cache()
+        other = side_configs(args)
+
     fps = args.steps * world / elapsed
     out = {
         "metric": metric_name(cfg), "value": round(fps, 2), "unit": "frames/s",
@@ -931,11 +975,11 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (OneBlob columns rounded to fp16: --pos-fp16 opt-in)" if args.pos_fp16 else "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {cam['W']}x{cam['H']} RGB-D, moving TSDF volume "
-                               f"{'x'.join(str(int(v)) for v in pipe.mv.vol_dim)} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
+                               f"{vol_dim_str} @ {cfg['volume']['voxel_size']} m, GBV 200^3, "
                                f"hash 2^{cfg['grid']['hash_size']} x16 levels, {S} samples/ray, "
                                f"{cfg['mapping']['iters']} map + {cfg['mapping']['BA_iters']} pose iters every {cfg['mapping']['map_every']} frames, poses initialised from the ground-truth trajectory and refined by the RBA pose MLP",
                    "unused_gradients": bool(args.unused_gradients), "pos_fp16_opt_in": bool(args.pos_fp16),
-                   "streams": "V1 on its own HIP stream, concurrent with the mapper" if getattr(pipe, "mv_stream", None) is not None else "one stream",
+                   "streams": streams_str,
                    "note": "pose iterations step only the pose MLP (reference mapper.py:494-499); the map gradients its backward also "
                            "produces and zeroes are computed only with --unused-gradients (same parameters and poses either way)",
                    "partition": "single volume"},
@@ -943,6 +987,7 @@ def main():
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,
         "iterations_timed": iters,
         "cpu_baseline": base,
+        "other_configs": other,
     }
     print(json.dumps(out), flush=True)
 

@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r6; mkdir -p $O; v=$1
 for w in $v new $v new; do
   if [ $w = new ]; then unset RFX_LIB_PATH; else export RFX_LIB_PATH=$R/build/variants/librfx_$w.so; fi
   ONLY16=1 timeout -k 10 300 python3 $R/tools/time_scatter_real.py office0 2>/dev/null | grep "both" | sed "s/^/$w /"
-  timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --render-frames 0 2>/dev/null | python3 -c "
+  timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --render-frames 0 2>/dev/null | python3 -c "
 import json,sys;d=json.loads(sys.stdin.read());print('$w bench', d['value'], d['ms_per_step'], d['kernels'].get('rfx_field_backward_scatter_merged'))"
 done
