@@ -122,6 +122,45 @@ def test_collective_helpers_world2(tmp_path):
         assert torch.equal(c["big"], torch.arange(70000, dtype=torch.float32) * 3)
 
 
+def _worker_async_collectives(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from remixfusion_amd.dist import all_reduce_sum_start, all_to_all_rows_start
+    # the two-half forms of round 6: issue, do something that does not read the buffers, then join
+    sums = torch.full((8,), 0.25 * (rank + 1), dtype=torch.float64)
+    dw = torch.arange(5312, dtype=torch.float32) * (rank + 1)
+    tv = torch.full((1,), float(rank + 1), dtype=torch.float64)
+    finish = all_reduce_sum_start(dist, [sums, None, dw, tv])         # two dtype buckets: (sums, tv) concatenated, dw alone
+    inp = torch.arange(10, dtype=torch.float32) + 100 * rank          # 3 + 7 (rank 0) / 6 + 4 (rank 1) elements to ranks 0 / 1
+    in_splits = [3, 7] if rank == 0 else [6, 4]
+    out_splits = [3, 6] if rank == 0 else [7, 4]
+    out = torch.full((16,), -1.0)
+    done = all_to_all_rows_start(dist, out, out_splits, inp, in_splits)
+    unrelated = torch.ones(4).sum()                                    # (what the caller launches in between)
+    done()
+    finish()
+    torch.save({"sums": sums, "dw": dw, "tv": tv, "out": out, "unrelated": unrelated}, os.path.join(out_dir, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_half_collectives_world2(tmp_path):
+    """dist.all_reduce_sum_start / all_to_all_rows_start (mp_slam/sharded.py issues its exchanges with them): same results as the
+    blocking helpers, the small tensors of several dtypes bucketed and copied back after the wait"""
+    world = 2
+    mp.spawn(_worker_async_collectives, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a0, a1 = (torch.load(os.path.join(tmp_path, f"a{r}.pt")) for r in range(2))
+    for a in (a0, a1):
+        assert torch.equal(a["sums"], torch.full((8,), 0.75, dtype=torch.float64))
+        assert torch.equal(a["dw"], torch.arange(5312, dtype=torch.float32) * 3)
+        assert torch.equal(a["tv"], torch.full((1,), 3.0, dtype=torch.float64))
+    r0 = torch.arange(10, dtype=torch.float32)
+    r1 = r0 + 100
+    assert torch.equal(a0["out"][:9], torch.cat([r0[:3], r1[:6]])) and torch.equal(a0["out"][9:], torch.full((7,), -1.0))
+    assert torch.equal(a1["out"][:11], torch.cat([r0[3:], r1[6:]])) and torch.equal(a1["out"][11:], torch.full((5,), -1.0))
+
+
 # ---- the hash table partitioned by level (mp_slam/sharded.py::LevelShardedIterations): host logic and the exchange protocol
 def _hash_desc(name):
     from remixfusion_amd.config import synthetic_config
