@@ -191,6 +191,62 @@ def test_one_call_ba_iteration_matches_oracle_at_bench_size(name, frames):
     assert float(got_dp[:, 3, :].abs().max()) == 0.0
 
 
+def test_map_phase_defines_every_entry_of_a_large_table_without_a_zero_fill():
+    """Round 6, T = 2^21 (cafeteria sizes: 166 MB, nine hashed levels of 2^21 entries): in the map phase the one-call iteration
+    skips the zero-fill of the trailing hashed levels and lets the scatter's reduce WRITE them (one block per segment, zeros
+    included).  The gradient buffer is poisoned with NaN before the call: every entry must come out defined, and equal -- per
+    level, to within what two runs of the float-atomic levels differ by -- to the stage-by-stage issue, which zero-fills the
+    whole buffer and adds (same seeds: the same ray batch and lattice)."""
+    cfg, pipe, fr = _pipeline("cafeteria", 11)
+    mp, model, slam = pipe.mapper, pipe.model, pipe.slam
+    direct = mp._direct_iterations()
+    tr, m = cfg["training"], cfg["mapping"]
+    enc = model.embed_res_fn
+    assert int(cfg["grid"]["hash_size"]) == 21 and sum(int(enc.desc.hashed[l]) for l in range(16)) >= 8
+    last = 10
+    b = fr[last]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    n_kf = len(mp.keyframe.frame_ids)
+    poses = slam.est_c2w_data[0:last + 1:m["keyframe_every"]].clone().float().contiguous()
+    poses_all = torch.cat([poses, slam.est_c2w_data[last:last + 1].float()], 0)[:n_kf + 1].contiguous()
+    dev = poses_all.device
+    params = [enc.params] + list(model.decoder_res.fused_weights())
+    n = direct._n_rays()
+
+    def run(stagewise, seed):
+        for p_ in params:
+            p_.grad = None
+        direct.stagewise_every = 1 if stagewise else 0
+        direct._count = 0
+        if not stagewise:
+            direct._buffers(n, 0, dev).t.dt.fill_(float("nan"))          # the one-call form must define ALL of it
+        random.seed(seed); torch.manual_seed(seed)
+        lc = direct.map_gradients(cur, poses_all).clone()
+        torch.cuda.synchronize()
+        return enc.params.grad.detach().clone(), [w.grad.detach().clone() for w in params[1:]], lc
+
+    one_a, dw_a, lc_a = run(False, 21)
+    one_b, _, _ = run(False, 21)
+    stg, dw_s, lc_s = run(True, 21)
+    direct.stagewise_every = 0
+    assert bool(torch.isfinite(one_a).all()) and bool(torch.isfinite(stg).all())
+    assert torch.allclose(lc_a[:4], lc_s[:4], rtol=1e-5, atol=0)
+    for a_, s_ in zip(dw_a, dw_s):
+        assert torch.allclose(a_, s_, rtol=2e-3, atol=2e-5 * float(s_.pow(2).mean().sqrt()))
+    touched = 0
+    for l in range(16):
+        lo, hi = int(enc.desc.offset[l]) * 2, (int(enc.desc.offset[l]) + int(enc.desc.size[l])) * 2
+        ref, got, again = stg[lo:hi], one_a[lo:hi], one_b[lo:hi]
+        scale = float(ref.abs().max())
+        assert scale > 0, l
+        noise = float((again - got).abs().max())                           # run-to-run difference of the same call
+        err = float((got - ref).abs().max())
+        assert err <= 4 * noise + 4e-6 * scale, (l, err, noise, scale)
+        assert torch.equal(got == 0, ref == 0) or float(((got == 0) != (ref == 0)).float().mean()) < 1e-4, l      # the same entries untouched
+        touched += int((got != 0).sum())
+    assert touched > 1e6
+
+
 @pytest.mark.parametrize("stashed", [False, True])
 def test_backward_with_selection_matches_oracle_above_the_threshold(stashed):
     """n >= 16 384 with ~40 % of the d_raw rows exactly zero: the stable partition + stash + LDS sweep against the oracle
