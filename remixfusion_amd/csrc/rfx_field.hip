@@ -30,15 +30,30 @@ namespace rfx {
 // backward chain of the same iteration, which then needs no hash lookups of its own.
 // EMB (mlp_forward_123): 0 look the hash features up, 1 look them up and stash them, 2 read them from the stash (the table is not
 // touched: a level-partitioned table's features arrive from the ranks that own the levels, rfx_field_stash_put).
+// n_full: the points taken in 64-point passes (all of them unless the host deals the tail out in halves); n_half: number of
+// 32-point half passes behind them, one per wave with index < n_half (mlp_forward_123_half in rfx_field_mlp.h)
 template <bool POS16, int EMB>
 __global__ __launch_bounds__(256, FWD_WAVES) void field_forward_kernel(FieldK f, const float* __restrict__ x01, int64_t n,
-                                                            float* __restrict__ raw4, float* __restrict__ emb) {
+                                                            float* __restrict__ raw4, float* __restrict__ emb, int64_t n_full,
+                                                            int n_half) {
     __shared__ __attribute__((aligned(16))) float wl[FWD_SLOTS * 64];
     stage_weights(f, wl, FWD_SLOTS);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t base = wave * 64; base < n; base += n_waves * 64) {
+    if (!POS16 && EMB != 2 && wave < n_half) {          // wave-uniform
+        const int64_t p = n_full + wave * 32 + (lane & 31);
+        float x[3];
+        load_point(x01, p, n, x);
+        Enc e;
+        encode_point(f, x, e);
+        MlpH m;
+        mlp_forward_123_half<EMB>(f, x, wl, lane, e, m, EMB ? emb + (p >> 6) * (8 * ROW_PIECE) + (p & 63) * 4 : nullptr, p < n);
+        float raw[4];
+        mlp_forward_4_half(wl, lane, e, m, raw);
+        if (p < n && lane < 32) reinterpret_cast<float4*>(raw4)[p] = make_float4(raw[0], raw[1], raw[2], raw[3]);
+    }
+    for (int64_t base = wave * 64; base < n_full; base += n_waves * 64) {
         const int64_t p = base + lane;
         float x[3];
         load_point(x01, p, n, x);
@@ -1969,6 +1984,8 @@ __global__ __launch_bounds__(256) void stage_weights_kernel(FieldK f, float* __r
     if (i < ALL_SLOTS * 64) out[i] = staged_weight(f, i >> 6, i & 63);
 }
 
+constexpr int FWD_RESIDENT_BLOCKS = 256 * FWD_WAVES;      // blocks of 4 waves the chip holds at FWD_WAVES waves per SIMD (256 CUs)
+
 static inline int wave_grid(int64_t n, int max_blocks) {
     int64_t b = (n + 255) / 256;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
@@ -2078,17 +2095,34 @@ static int launch_forward(const rfx_field_desc* f, const float* x01, int64_t n, 
     int rc = make_fieldk(f, &k);
     if (rc) return rc;
     if (!x01 || !raw4 || n < 0 || (from_stash && !emb)) return RFX_ERR_ARG;
-    const dim3 grid(wave_grid(n, 256 * 4));
+    dim3 grid(wave_grid(n, 256 * 4));
+    // The tail in HALF passes (round 6).  The kernel holds FWD_WAVES waves per SIMD: FWD_SLOTS_RESIDENT wave slots on the chip.
+    // With more 64-point passes than slots, the passes behind the last full round used to be a third wave-pass on some SIMDs
+    // (2 124 passes: 55.7 us against 43.9 us for 1 888); they go out as 32-point half passes instead, one per wave of the first
+    // blocks (one per SIMD while there are at most 4 x CUs of them).  fp32 OneBlob, table lookups (not the stash-fed form) only.
+    int64_t n_full = n;
+    int n_half = 0;
+    static const bool half_off = getenv("RFX_NO_HALF_PASS") != nullptr;          // (A/B runs)
+    if (!half_off && !k.pos_fp16 && !from_stash) {
+        constexpr int64_t slots = (int64_t)FWD_RESIDENT_BLOCKS * 4;
+        const int64_t passes = (n + 63) / 64, rounds = passes / slots;
+        const int64_t rest = n - rounds * slots * 64;                              // points behind the last full round
+        const int64_t halves = (rest + 31) / 32;
+        if (rounds >= 1 && rest > 0 && halves <= FWD_RESIDENT_BLOCKS * 2) {        // one half per SIMD: 4 waves of the first half of the blocks
+            n_full = rounds * slots * 64; n_half = (int)halves;
+            grid = dim3(FWD_RESIDENT_BLOCKS);
+        }
+    }
     hipStream_t st = as_stream(stream);
     if (from_stash) {
-        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
-        else hipLaunchKernelGGL((field_forward_kernel<false, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 2>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
     } else if (emb) {
-        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
-        else hipLaunchKernelGGL((field_forward_kernel<false, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 1>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
     } else {
-        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
-        else hipLaunchKernelGGL((field_forward_kernel<false, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb);
+        if (k.pos_fp16) hipLaunchKernelGGL((field_forward_kernel<true, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
+        else hipLaunchKernelGGL((field_forward_kernel<false, 0>), grid, dim3(256), 0, st, k, x01, n, raw4, emb, n_full, n_half);
     }
     RFX_LAUNCH_CHECK();
     return RFX_OK;

@@ -546,6 +546,156 @@ __device__ __forceinline__ void mlp_forward_4(const float* __restrict__ wl, int 
     raw[3] = a + e.tres;
 }
 
+// ---------------------------------------------------------------- the HALF pass: 32 points per wave (round 6)
+// A launch of P 64-point passes on S wave slots costs ceil(P / S) pass-times on the SIMDs that take an extra wave-pass
+// (profiles/r5_notes.md: 2 124 passes on 2 048 slots: 55.7 us against 43.9 us for 1 888).  The passes beyond the last full round
+// are therefore dealt out as HALF passes, one per SIMD: 32 points, for which BOTH halves of the wave work -- lane l and lane
+// l + 32 serve point l.  The lower half looks up hash levels 0-7, the upper half levels 8-15, in the same instructions
+// (level constants selected per lane); after v_permlane32_swap the pair (a, b) is the tile-0 operand of level s and of level
+// s + 8: two k-steps into ONE accumulator tile.  The OneBlob columns are split 5 + 4 the same way and the two partial sums
+// meet in the swap that turns the 32 own-point sums into the D layout.  Half the gathers, half the column products and half the
+// MFMAs of a pass per lane; the GBV lookup is done by both halves.  fp32 OneBlob only (the reference's precision); results are
+// the full pass's up to the order of the fp32 additions of one point (levels interleave s, s + 8 instead of ascending).
+struct MlpH { f32x16 h1, h2, h3; };
+
+__device__ __forceinline__ Level select_level(const Level& a, const Level& b, bool hi) {
+    Level L;
+    L.scale = hi ? b.scale : a.scale; L.res = hi ? b.res : a.res; L.size = hi ? b.size : a.size;
+    L.offset = hi ? b.offset : a.offset; L.hashed = hi ? b.hashed : a.hashed;
+    return L;
+}
+
+// (t) += W[:, pos cols] . OneBlob(x): lane half `hi` multiplies columns j = 5 hi .. 5 hi + 4 (the upper half's fifth is empty);
+// the two halves' sums for the same point are added by the swap
+__device__ __forceinline__ void sparse_pos_tile_half(const float* __restrict__ wp, const PosBins& pb, bool extra, bool hi, f32x16& t) {
+    float acc[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) acc[a] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int col = hi ? (i < 4 ? pb.c[5 + i] : 0) : pb.c[i];
+        const float v = hi ? (i < 4 ? pb.v[5 + i] : 0.f) : pb.v[i];
+        sparse_col_fma(wp, col, v, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (extra) {                      // wave-uniform: some lane's point lies far outside the bound (see sparse_pos_tiles)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sparse_col_fma(wp, 16 * d + 15, hi ? 0.f : pb.rest[d], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = acc[r], b = acc[16 + r];
+        swap32(a, b);           // lower lane: a = own rows half 0, b = the partner's rows half 0; upper lane: a = the partner's rows half 1, b = own
+        t[r] += a + b;
+    }
+}
+
+template <int EMB>
+__device__ __forceinline__ void mlp_forward_123_half(const FieldK& f, const float x[3], const float* __restrict__ wl, int lane, Enc& e,
+                                                     MlpH& m, float* emb_row, bool valid) {
+    const bool hi = lane >= 32;
+    m.h1 = zero16();
+    constexpr int HG = HASH_GROUP;
+    static_assert(8 % HG == 0, "HASH_GROUP must divide the 8 level pairs of a half pass");
+    const float2* __restrict__ t2 = reinterpret_cast<const float2*>(f.table);
+#pragma unroll 1
+    for (int s0 = 0; s0 < 8; s0 += HG) {
+        Cell cell[HG];
+        unsigned idx[HG][8];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            const Level L = select_level(get_level(f.hash, s0 + g), get_level(f.hash, s0 + g + 8), hi);
+            cell[g] = locate(L, x);
+            corner_indices(L, cell[g], idx[g]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) idx[g][k] += L.offset;          // (the table is below 4 GiB: a 32-bit element index, at32)
+        }
+        float2 cv[HG][8];
+#pragma unroll
+        for (int g = 0; g < HG; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[g][k] = at32(t2, idx[g][k]);
+        float2 v[HG];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = corner_weight(cell[g], k);
+                acc.x = fmaf(w, cv[g][k].x, acc.x);
+                acc.y = fmaf(w, cv[g][k].y, acc.y);
+            }
+            v[g] = acc;
+        }
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            const int s = s0 + g;
+            if (EMB == 1 && valid) {          // the stash row of the point: this lane's level (s or s + 8)
+                float* dst = row_piece(emb_row, 2 * (s + (hi ? 8 : 0)));
+                if (HG % 2 == 0) {
+                    if (g % 2 == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[g].x, v[g].y, v[(g + 1) % HG].x, v[(g + 1) % HG].y);
+                } else {
+                    *reinterpret_cast<float2*>(dst) = v[g];
+                }
+            }
+            float a = v[g].x, b = v[g].y;
+            swap32(a, b);                     // a: (x, y) of level s for point l; b: (x, y) of level s + 8 for point l
+            m.h1 = mfma32(wl[(OFF1 + s) * 64 + lane], a, m.h1);
+            m.h1 = mfma32(wl[(OFF1 + s + 8) * 64 + lane], b, m.h1);
+        }
+    }
+    PosBins pb;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oneblob_dim_sparse(x[d], d, pb);
+    const bool extra = __any(pb.rest[0] != 0.0f || pb.rest[1] != 0.0f || pb.rest[2] != 0.0f) != 0;
+    sparse_pos_tile_half(wl + (OFF1 + 16) * 64, pb, extra, hi, m.h1);
+    {
+        float a = e.cin, b = 0.f;
+        swap32(a, b);
+        m.h1 = mfma32(wl[(OFF1 + 16 + NPOS_SLOTS) * 64 + lane], a, m.h1);
+    }
+    m.h2 = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m.h2 = mfma32(wl[(OFF2 + r) * 64 + lane], fmaxf(m.h1[r], 0.f), m.h2);
+    m.h3 = zero16();
+    sparse_pos_tile_half(wl + OFF3 * 64, pb, extra, hi, m.h3);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m.h3 = mfma32(wl[(OFF3 + NPOS_SLOTS + r) * 64 + lane], m.h2[r], m.h3);
+    {
+        float a = e.ex[1], b = e.ex[2];
+        swap32(a, b);
+        m.h3 = mfma32(wl[(OFF3 + NPOS_SLOTS + 8) * 64 + lane], a, m.h3);
+        a = e.ex[3]; b = 0.f;
+        swap32(a, b);
+        m.h3 = mfma32(wl[(OFF3 + NPOS_SLOTS + 9) * 64 + lane], a, m.h3);
+    }
+}
+
+// layer 4 + residual add of a half pass: valid in the LOWER lanes (point = lane)
+__device__ __forceinline__ void mlp_forward_4_half(const float* __restrict__ wl, int lane, const Enc& e, const MlpH& m, float raw[4]) {
+    const float* __restrict__ w4 = wl + OFF4 * 64;
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float a0 = fmaxf(m.h3[r], 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p0[c] = fmaf(a0, w4[(c * 16 + r) * 2 + h], p0[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = p0[c], b = p0[c];
+        swap32(a, b);                 // lower lane: a = own partial (rows half 0), b = the partner's (rows half 1)
+        raw[c] = (a + b) + e.ex[c + 1];
+    }
+    float a = m.h2[0], b = m.h2[0];
+    swap32(a, b);
+    raw[3] = a + e.tres;
+}
+
 __device__ __forceinline__ void load_point(const float* __restrict__ x01, int64_t p, int64_t n, float x[3]) {
     if (p < n) { x[0] = x01[p * 3]; x[1] = x01[p * 3 + 1]; x[2] = x01[p * 3 + 2]; }
     else { x[0] = x[1] = x[2] = 0.5f; }
