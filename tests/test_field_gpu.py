@@ -618,6 +618,57 @@ def test_prestaged_weight_image_equals_in_kernel_staging():
     assert torch.equal(after, raw)
 
 
+def test_half_passes_of_the_forward_tail_equal_full_passes():
+    """Round 6: with more 64-point passes than the 2 048 wave slots the forward deals the passes behind the last full round out as
+    32-point HALF passes (lane l and lane l + 32 serve one point: levels 0-7 / 8-15, OneBlob columns 5 + 4, one MFMA tile;
+    csrc/rfx_field_mlp.h::mlp_forward_123_half).  Here: 131 072 + 4 827 points (151 half passes, the last one ragged) in ONE call
+    against the same points in two calls that fit the slots (full passes only): raw to fp32 rounding of another summation order,
+    the stashed hash features bit for bit (each level is looked up by one lane either way) -- and the oracle on a sample."""
+    import ctypes as C
+    from remixfusion_amd import _lib as L
+    lib = L.load()
+    cfg, m = _model(hash_scale=0.5)
+    n0, n = 2048 * 64, 2048 * 64 + 4827
+    x = _points(n, seed=9, lo=0.02, hi=0.98).cuda().contiguous()
+    x[n0 + 5] = torch.tensor([1.7, -0.4, 0.5])                      # a point far outside the bound inside a half pass (OneBlob's wrap column)
+    desc = m._field_desc(False)
+    assert not bool(desc.pos_fp16)
+    st = L.stream_ptr(x.device)
+
+    def forward(xx, stash):
+        k = xx.shape[0]
+        raw = torch.full((k, 4), float("nan"), device="cuda")
+        if not stash:
+            L.check(lib.rfx_field_forward(C.byref(desc), L.ptr(xx), k, L.ptr(raw), st), "forward")
+            return raw, None
+        nb = int(lib.rfx_field_backward_workspace_bytes(k))
+        ws = torch.full((nb // 4 + 16,), float("nan"), device="cuda")
+        wsp = (ws.data_ptr() + 15) // 16 * 16
+        L.check(lib.rfx_field_forward_stash(C.byref(desc), L.ptr(xx), k, L.ptr(raw), wsp, nb, st), "forward_stash")
+        torch.cuda.synchronize()
+        o = (wsp - ws.data_ptr()) // 4
+        tiles = (k + 63) // 64
+        emb = ws[o:o + tiles * 8 * 256].view(tiles, 8, 64, 4).permute(0, 2, 1, 3).reshape(tiles * 64, 32)[:k].clone()     # piece-major tiles -> rows
+        return raw, emb
+
+    for stash in (False, True):
+        raw_all, emb_all = forward(x, stash)                          # tail in half passes
+        raw_a, emb_a = forward(x[:n0].contiguous(), stash)            # 2 048 passes: every wave one full pass
+        raw_b, emb_b = forward(x[n0:].contiguous(), stash)            # 76 passes
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(raw_all).all())
+        assert torch.equal(raw_all[:n0], raw_a)                       # the full rounds are untouched
+        ref = raw_b
+        err = (raw_all[n0:] - ref).abs()
+        assert float((err / (ref.abs() + 1e-3)).max()) < 2e-5, float((err / (ref.abs() + 1e-3)).max())
+        if stash:
+            assert torch.equal(emb_all[:n0], emb_a) and torch.equal(emb_all[n0:], emb_b)
+    fp = _oracle_params(cfg, m)
+    sel = torch.cat([torch.arange(n0, n0 + 300), torch.arange(n - 40, n)])
+    want = FO.query_color_sdf(fp, x[sel].cpu())
+    _close(raw_all[sel].cpu(), want, 1e-4, 2e-5, "half-pass raw vs oracle")
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_stashed_forward_and_chains_are_bit_identical_to_the_recomputing_ones(fp16):
     """rfx_field_forward_stash leaves the hash features in the workspace and the three _stashed chains read them instead
