@@ -28,6 +28,7 @@ the launch stream) and `cpu_baseline` (the C / torch CPU oracle timed on this ho
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -81,6 +82,9 @@ def parse():
                     help="N>1: hash table partitioned by level (per-point rows exchanged) or replicated (dense gradient all-reduced)")
     ap.add_argument("--no-n1", action="store_true", help="N>1: skip the one-GPU run of the same scene (n1_same_workload)")
     ap.add_argument("--no-mv-stream", action="store_true", help="V1 on the mapper's stream instead of a stream of its own (A/B)")
+    ap.add_argument("--stage-events-every", type=int, default=5,
+                    help="N = 1: every k-th BA iteration of the timed region records HIP events at its stage boundaries INSIDE the "
+                         "one-call iteration (rfx_ba_desc.stage_events): the live per-stage times behind `roofline`; 0 = none")
     ap.add_argument("--stagewise-every", type=int, default=-1,
                     help="issue every k-th BA iteration stage by stage so that HIP events see the individual entry points (0: never; "
                          "default: about three such iterations in the timed region, spaced so that both phases are sampled)")
@@ -128,6 +132,87 @@ class KernelTimer:
             out[name] = (len(ms), float(np.mean(ms[keep])), evs)     # among 50 of 0.1 ms) would otherwise own the mean
             self.spread[name] = (med, float(np.max(ms)), int((~keep).sum()))
         return out
+
+
+class StageTimer:
+    """HIP events recorded INSIDE rfx_ba_forward_backward at its stage boundaries (rfx_ba_desc.stage_events, ABI 10), on the
+    stream the iteration is launched on: the device time of every stage of the very launches the frame loop runs -- fused
+    prologue, shared launches and all -- for every k-th iteration of the timed region.  (Rounds 2-6 issued a few iterations
+    stage by stage instead, one foreign call per entry point with events around each: ~0.15 ms more per such iteration, 3.5 % of
+    the driver's 20-frame window against ~1 % for this: tools/r6_ab_stagewise.sh.)  A stage is reported under the name of the
+    entry point that runs the same launches when called alone."""
+    ORDER = {"map": ("start", "prologue", "forward", "loss", "chain", "weights", "scatter"),
+             "pose": ("start", "prologue", "forward", "loss", "chain", "dx_table", "dx", "pose"),
+             "pose+map": ("start", "prologue", "forward", "loss", "chain", "weights", "dx_table", "dx", "pose", "scatter")}
+    NAMES = {("map", "chain"): "rfx_field_backward_chain_weights", ("pose", "chain"): "rfx_field_backward_chain_inputs",
+             ("pose+map", "chain"): "rfx_field_backward_chain", "prologue": "ba_prologue", "forward": "rfx_field_forward",
+             "loss": "ba_composite_loss_grad", "weights": "rfx_field_backward_weights", "scatter": "rfx_field_backward_scatter_merged",
+             "dx_table": "rfx_field_backward_scatter", "dx": "rfx_field_backward_dx", "pose": "ba_pose_chain"}
+
+    def __init__(self, lib, every, S, n_lattice, unused_gradients=False, pool=0):
+        from remixfusion_amd import _lib
+        self._lib_mod, self.lib, self.every, self.S, self.n_lattice = _lib, lib, int(every), int(S), int(n_lattice)
+        self.unused = bool(unused_gradients)
+        self.enabled, self.count, self.samples, self.pool, self.spread = False, 0, [], [], {}
+        for _ in range(pool):                      # created before the timed region: hipEventCreate is host time
+            self.pool.append(self._new_set())
+
+    def _new_set(self):
+        arr = (C.c_void_p * self._lib_mod.BA_STAGE_EVENTS)()
+        for i in range(self._lib_mod.BA_STAGE_EVENTS):
+            ev = C.c_void_p()
+            self._lib_mod.check(self.lib.rfx_event_create(C.byref(ev)), "rfx_event_create")
+            arr[i] = ev.value
+        return arr
+
+    def __call__(self, phase, n_rays):             # DirectIterations.stage_events
+        # An event costs the loop ~2.7 us (tools/r6_ab_stagewise.sh: every iteration timed = 300 events in the driver's 20-frame
+        # window = -6 %), so one iteration in `every` is timed: the third, eighth, ... of the timed region -- with the reference's
+        # 5 map + 5 pose iterations per mapper step and every = 5 that is the third map and the third pose iteration of each step.
+        if not self.enabled or self.every <= 0:
+            return None
+        self.count += 1
+        if self.count % self.every != 3 % self.every:
+            return None
+        arr = self.pool.pop() if self.pool else self._new_set()
+        self.samples.append(("pose+map" if phase == "pose" and self.unused else phase, int(n_rays), arr))
+        return C.addressof(arr)
+
+    def summary(self):
+        """name -> (samples, mean ms, [(None, None, {"points": ...})]) like KernelTimer.summary(); fills self.spread"""
+        ev_i = self._lib_mod.BA_EV
+        per = {}
+        for phase, n, arr in self.samples:
+            order = self.ORDER[phase]
+            for a, b in zip(order[:-1], order[1:]):
+                ms = C.c_float()
+                if self.lib.rfx_event_elapsed_ms(arr[ev_i[a]], arr[ev_i[b]], C.byref(ms)) != 0:
+                    continue                       # an event this iteration did not record
+                name = self.NAMES.get((phase, b)) or self.NAMES[b]
+                pts = n * self.S + (self.n_lattice if b == "scatter" else 0)
+                per.setdefault(name, []).append((float(ms.value), {"points": pts, "phase": phase}))
+        out, self.spread = {}, {}
+        for name, rows in per.items():
+            ms = np.array([r[0] for r in rows])
+            med = float(np.median(ms))
+            keep = ms <= 5.0 * med
+            out[name] = (len(ms), float(np.mean(ms[keep])), [(None, None, r[1]) for r in rows])
+            self.spread[name] = (med, float(np.max(ms)), int((~keep).sum()))
+        return out
+
+    def close(self):
+        for _, _, arr in self.samples:
+            self.pool.append(arr)
+        for arr in self.pool:
+            for i in range(len(arr)):
+                if arr[i]:
+                    self.lib.rfx_event_destroy(arr[i])
+        self.pool, self.samples = [], []
+
+
+def _points(e, index):
+    """points of one timed sample: KernelTimer keeps the call's arguments, StageTimer the count itself"""
+    return e[2]["points"] if isinstance(e[2], dict) else e[2][index]
 
 
 def cpu_baseline(cfg, frame, model_points: int):
@@ -230,7 +315,7 @@ def field_rooflines(summ, cfg, merged_scatter=True):
 
     def mfma_roofline(name, flop_per_point, point_arg_index):
         cnt, ms, evs = summ[name]
-        pts = float(np.mean([e[2][point_arg_index] for e in evs]))
+        pts = float(np.mean([_points(e, point_arg_index) for e in evs]))
         ach = flop_per_point * pts / (ms * 1e-3) / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "points_per_launch": int(pts),
@@ -250,7 +335,7 @@ def field_rooflines(summ, cfg, merged_scatter=True):
         # algorithmic bytes per point: 12 (x) + 128 (dfeat) read, 16 levels x 8 corners x 8 B scattered;
         # the merged call scatters the ray samples AND the TV lattice points in one sweep
         cnt, ms, evs = summ[scat]
-        pts = float(np.mean([e[2][2] + (e[2][5] if scat.endswith("merged") else 0) for e in evs]))
+        pts = float(np.mean([e[2]["points"] if isinstance(e[2], dict) else e[2][2] + (e[2][5] if scat.endswith("merged") else 0) for e in evs]))
         nbytes = pts * (12 + 128 + 1024)
         ach = nbytes / (ms * 1e-3) / 1e9
         f64 = cfg["grid"]["hash_size"] <= 17
@@ -721,19 +806,22 @@ def main():
                         # first-frame mapping (tens of ms of GPU work) still to come: a pause of that length right before the
                         # timed region -- or before the few warm-up frames -- lets the GPU idle and read 3-7 % lower
     pipe.start(frames[0])
-    # The BA iterations are normally issued by one library call each (rfx_ba_forward_backward); every 8th one is issued
-    # stage by stage instead (same kernels, same order) so that the HIP events of KernelTimer see the individual calls.
+    # The BA iterations are issued by one library call each (rfx_ba_forward_backward).  Every `--stage-events-every`-th one of
+    # the timed region records HIP events at its stage boundaries inside that call (StageTimer): the per-stage device times of
+    # the launches the loop runs.  `--stagewise-every k` (k > 0) issues every k-th iteration stage by stage instead -- one
+    # foreign call per entry point with KernelTimer's events around each, ~0.15 ms more per such iteration (rounds 2-6's way).
     direct = pipe.mapper._direct_iterations() if pipe.mapper is not None else None
+    stages = None
     if direct is not None:
-        # An instrumented iteration costs ~0.15 ms more than the one-call form (a score of Python-level calls, event records
-        # and the wait for V1's stream), so only about three of them fall into the timed region: the spacing is a third of the
-        # region's iterations (2 per frame), made = 3 mod 10, which walks through the 5 map + 5 pose phases of the mapper's
-        # schedule so that any three consecutive samples contain both a map and a pose iteration.
-        n_it = 2 * args.steps
-        auto = (n_it // 3) // 10 * 10 + 3 if n_it >= 39 else max(1, n_it // 3)
-        direct.stagewise_every = auto if args.stagewise_every < 0 else args.stagewise_every
-        direct.before_stagewise = pipe.sync_volume      # time the entry points without V1 running on the other stream
-        timer.every = 1
+        if args.stagewise_every > 0:
+            direct.stagewise_every = args.stagewise_every
+            direct.before_stagewise = pipe.sync_volume      # time the entry points without V1 running on the other stream
+            timer.every = 1
+        elif args.stage_events_every > 0 and hasattr(direct, "stage_events"):
+            tr_ = cfg["training"]
+            stages = StageTimer(lib, args.stage_events_every, tr_["n_range_d"] + tr_["n_samples_d"], (int(tr_["smooth_pts"]) - 1) ** 3,
+                                unused_gradients=args.unused_gradients, pool=2 * args.steps // args.stage_events_every + 2)
+            direct.stage_events = stages
     for i in range(1, 1 + args.warmup):
         pipe.step(i, frames[i])
 
@@ -745,6 +833,8 @@ def main():
 
     barrier()
     timer.enabled = True
+    if stages is not None:
+        stages.enabled = True
     it0 = dict(direct.iterations) if direct is not None else None
     t0 = time.perf_counter()
     frame_marks = []
@@ -768,6 +858,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if stages is not None:
+        stages.enabled = False
     if args.frame_times and rank == 0:
         gc.callbacks.remove(_gc_cb)
         for g, dur, at in gc_log:
@@ -823,10 +915,15 @@ def main():
 
     # ---- roofline of the dominant kernel (by summed device time over the timed region)
     summ = timer.summary()
+    spread = dict(timer.spread)
+    if stages is not None:
+        summ.update(stages.summary())
+        spread.update(stages.spread)
+        stages.close()
     cam, tr = cfg["cam"], cfg["training"]
     S = tr["n_range_d"] + tr["n_samples_d"]
-    per_kernel = {k: {"calls_timed": c, "avg_ms": round(ms, 4), "median_ms": round(timer.spread[k][0], 4), "max_ms": round(timer.spread[k][1], 4),
-                      "outliers_dropped": timer.spread[k][2]}
+    per_kernel = {k: {"calls_timed": c, "avg_ms": round(ms, 4), "median_ms": round(spread[k][0], 4), "max_ms": round(spread[k][1], 4),
+                      "outliers_dropped": spread[k][2]}
                   for k, (c, ms, _) in summ.items()}
     step_kernels = {k: v for k, v in summ.items() if k != "rfx_render_rays"}
     # device time per entry point over the timed region = avg x number of launches; the BA-iteration stages were only
@@ -836,7 +933,7 @@ def main():
     per_frame = ("rfx_tsdf_integrate", "rfx_gbv_integrate", "rfx_render_rays")
     map_only = ("rfx_field_backward_chain_weights", "rfx_field_backward_weights", "rfx_field_backward_scatter_merged", "rfx_tv_forward",
                 "rfx_tv_backward", "rfx_grid_encode_forward")
-    pose_only = ("rfx_field_backward_chain_inputs", "rfx_field_backward_scatter", "rfx_field_backward_dx")
+    pose_only = ("rfx_field_backward_chain_inputs", "rfx_field_backward_scatter", "rfx_field_backward_dx", "ba_pose_chain")
     if args.unused_gradients:                      # the pose phase then runs the map-gradient stages as well (on the full chain)
         map_only, pose_only = ("rfx_field_backward_chain_weights",), pose_only + ("rfx_field_backward_chain",)
     launches = {}
@@ -986,6 +1083,12 @@ def main():
         "render_rays_per_s": round(render, 1) if render else None,
         "roofline": roofline, "rooflines": extra_rooflines, "kernels": per_kernel, "dominant_call": dominant,
         "iterations_timed": iters,
+        "kernel_timing": (f"HIP events recorded at the stage boundaries INSIDE the one-call iteration (rfx_ba_desc.stage_events), every "
+                          f"{args.stage_events_every}th BA iteration of the timed region, on the launch stream, V1 running beside "
+                          "them on its own stream as in the loop; V1 / G1 / render: events around their entry points"
+                          if stages is not None else
+                          f"stage-by-stage issue of every {args.stagewise_every}th BA iteration with HIP events around each entry point"
+                          if args.stagewise_every > 0 else "V1 / G1 / render only"),
         "cpu_baseline": base,
         "other_configs": other,
     }

@@ -34,13 +34,23 @@ extern "C" {
 #define RFX_ERR_UNSUPPORTED -3   /* configuration outside what the kernels implement        */
 #define RFX_ERR_WORKSPACE   -4   /* workspace pointer null or too small                     */
 
-#define RFX_ABI_VERSION 9
+#define RFX_ABI_VERSION 10
 
 typedef void* rfx_stream;
 
 int rfx_abi_version(void);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */
 int rfx_last_hip_error(void);
+
+/* Timing events for a caller without a HIP binding of its own (ABI 10; bench.py's live roofline): hipEventCreateWithFlags
+ * (hipEventDisableSystemFence: for timing only -- waiting on such an event does NOT make device memory visible to the host) /
+ * hipEventDestroy / hipEventSynchronize + hipEventElapsedTime (ms between two RECORDED events; RFX_ERR_HIP when either was
+ * never recorded, and the runtime's sticky error is cleared).  The handles are plain hipEvent_t: a caller that has HIP may
+ * pass its own. */
+typedef void* rfx_event;
+int rfx_event_create(rfx_event* out);
+int rfx_event_destroy(rfx_event ev);
+int rfx_event_elapsed_ms(rfx_event start, rfx_event stop, float* ms);
 
 /* ======================================================================================
  * Moving TSDF volume (MV).  Layout: three fp32 arrays of dx*dy*dz voxels, z fastest
@@ -614,7 +624,25 @@ typedef struct rfx_ba_desc {
     float         rba_scale;
     const struct rfx_rba_grads* rba_grads;
     float*        rba_ws;               /* dev, rfx_rba_grads_floats(K)                                      */
+    /* optional (ABI 10): host array of RFX_BA_STAGE_EVENTS events (rfx_event_create / hipEventCreate), or NULL.  The call
+     * records entry [i] on `stream` BEHIND the last launch of stage i (RFX_BA_EV_*), so the time between two consecutive
+     * recorded entries is that stage's device time inside the one-call iteration -- the same launches, nothing un-fused,
+     * no host round trip (bench.py's roofline; the stage-by-stage issue costs an iteration ~0.15 ms).  Stages a phase does
+     * not run record nothing; a NULL entry is skipped. */
+    const rfx_event* stage_events;
 } rfx_ba_desc;
+#define RFX_BA_EV_START     0   /* in front of the first launch                                                        */
+#define RFX_BA_EV_PROLOGUE  1   /* ray batch, S1, points (+ weight staging, TV lattice and lookups, zero-fill)          */
+#define RFX_BA_EV_FORWARD   2   /* rfx_field_forward_stash                                                             */
+#define RFX_BA_EV_LOSS      3   /* R1 + L1 forward / backward, TV backward (+ the TV value, if asked)                  */
+#define RFX_BA_EV_CHAIN     4   /* row selection + backward chain (+ loss finalize)                                    */
+#define RFX_BA_EV_WEIGHTS   5   /* decoder weight gradients (map gradients only; in the map phase their second stage   */
+                                /* rides in the scatter's staging launch: counted there)                               */
+#define RFX_BA_EV_SCATTER   6   /* table scatter of ray samples + TV lattice (map gradients only)                      */
+#define RFX_BA_EV_DX_TABLE  7   /* pose phase: d loss / d x01 through the table                                        */
+#define RFX_BA_EV_DX        8   /* pose phase: + OneBlob / GBV part                                                    */
+#define RFX_BA_EV_POSE      9   /* pose phase: ray reduction, pose gradient, pose-MLP backward                         */
+#define RFX_BA_STAGE_EVENTS 10
 size_t rfx_ba_desc_bytes(void);          /* sizeof(rfx_ba_desc): lets a foreign binding verify its mirror of the struct */
 size_t rfx_ba_workspace_bytes(int64_t n_rays, int S, int tv_P, int n_feat_total, int n_levels);
 /* the same with the scatter's share sized by rfx_grid_encode_backward_workspace_bytes_for(hash, points): whatever lies behind

@@ -44,6 +44,9 @@ class AdamTensor(C.Structure):
 
 ADAM_MAX_TENSORS = 16
 LOSS_WS_DOUBLES = 2048      # RFX_LOSS_WS_DOUBLES
+# rfx_ba_desc.stage_events (RFX_BA_EV_*): entry i is recorded behind the last launch of stage i
+BA_STAGE_EVENTS = 10
+BA_EV = {"start": 0, "prologue": 1, "forward": 2, "loss": 3, "chain": 4, "weights": 5, "scatter": 6, "dx_table": 7, "dx": 8, "pose": 9}
 
 
 class BaDesc(C.Structure):
@@ -56,7 +59,8 @@ class BaDesc(C.Structure):
                 ("seed_cur", C.c_uint64), ("poses16", C.c_void_p), ("K", C.c_int32), ("u_z", C.c_void_p), ("u6", C.c_void_p),
                 ("seed_u", C.c_uint64), ("hash_entries", C.c_int64), ("d_hash", C.c_void_p), ("d_w", C.c_void_p), ("d_poses16", C.c_void_p),
                 ("losses8", C.c_void_p), ("tv_sum", C.c_void_p), ("rba", C.c_void_p), ("rba_acts", C.c_void_p),
-                ("rba_scale", C.c_float), ("rba_grads", C.c_void_p), ("rba_ws", C.c_void_p)]
+                ("rba_scale", C.c_float), ("rba_grads", C.c_void_p), ("rba_ws", C.c_void_p),
+                ("stage_events", C.c_void_p)]
 
 
 class LevelRows(C.Structure):
@@ -105,6 +109,9 @@ _i, _f, _l, _sz = C.c_int, C.c_float, C.c_int64, C.c_size_t
 PROTOTYPES = {
     "rfx_abi_version": (_i, []),
     "rfx_last_hip_error": (_i, []),
+    "rfx_event_create": (_i, [C.POINTER(C.c_void_p)]),
+    "rfx_event_destroy": (_i, [_P]),
+    "rfx_event_elapsed_ms": (_i, [_P, _P, C.POINTER(C.c_float)]),
     "rfx_tsdf_integrate_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "rfx_tsdf_integrate": (_i, [_P, _P, _P, _i, _i, _i, _F3, _f, _F9, _F16, _P, _P, _i, _i, _f, _f, _i, _i, _F6,
                                 _i, _P, _sz, _P]),
@@ -219,7 +226,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.rfx_abi_version() != 9:
+    if lib.rfx_abi_version() != 10:
         raise RfxError("librfx.so ABI version mismatch")
     if lib.rfx_adam_tensor_bytes() != C.sizeof(AdamTensor):
         raise RfxError("rfx_adam_tensor layout mismatch between librfx.so and _lib.AdamTensor")

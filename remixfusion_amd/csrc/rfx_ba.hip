@@ -189,6 +189,13 @@ int rfx_ba_workspace_layout(int64_t n_rays, int S, int tv_P, int n_feat, int n_l
         if (_rc) return _rc;     \
     } while (0)
 
+// rfx_ba_desc.stage_events: entry i recorded behind the last launch of stage i
+#define RFX_MARK(i)                                                                                          \
+    do {                                                                                                     \
+        if (b->stage_events && b->stage_events[i])                                                           \
+            RFX_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(b->stage_events[i]), st));               \
+    } while (0)
+
 int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t workspace_bytes, rfx_stream stream) {
     if (!b || !workspace) return RFX_ERR_ARG;
     const int64_t n = b->n_kf_samples + b->n_cur;
@@ -218,15 +225,18 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
     const int ow_level = (map_grads && !b->d_poses16) ? scatter_overwrite_from_level(b->field.hash, nS + nt, true, b->d_hash) : L;
     const int64_t zero_floats = !map_grads ? 0 : ow_level < L ? (int64_t)b->field.hash.offset[ow_level] * F : (int64_t)b->hash_entries * F;
     int n_cnt = 0;
+    RFX_MARK(RFX_BA_EV_START);
     RFX_TRY(ba_prologue(b->kf_rays, b->rays_per_kf, b->num_kf, b->kf_frame_ids, b->keyframe_every, b->cur_rays, b->cur_population,
                         b->n_kf_samples, b->n_cur, b->seed_kf, b->seed_cur, b->poses16, b->K, &b->sampler, b->u_z, b->seed_u, b->bbox,
                         b->bbox_f64, w.o, w.d, w.tgt, w.td, w.d_cam, w.pidx, w.z, w.x01, &b->field, b->u6, P, b->tv_voxel,
                         b->tv_margin, b->tv_normalise, tv_on ? w.pts : nullptr, tv_on ? w.feat : nullptr,
                         map_grads ? b->d_hash : nullptr, zero_floats, trunc_loss, b->depth_trunc,
                         w.cnt, &n_cnt, stream));            // ... and counts what the loss coefficients are made of
+    RFX_MARK(RFX_BA_EV_PROLOGUE);
     // ---- forward
     // ... which leaves its hash features in the backward workspace: the chain below does not look the table up again
     RFX_TRY(rfx_field_forward_stash(&b->field, w.x01, nS, w.raw, w.bwd_ws, w.bwd_bytes, stream));
+    RFX_MARK(RFX_BA_EV_FORWARD);
     float* lc = b->losses8 ? b->losses8 : w.lc;       // out: the four losses, then their coefficients
     // ---- R1 + L1 forward and L1 backward in one launch (the coefficients come from the prologue's counts), TV1 backward beside
     //      them; leaves the loss partial sums, the rows with a gradient per ray and d_raw
@@ -236,6 +246,7 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
                                 map_grads ? w.feat : nullptr, P, L * F, b->tv_scale, map_grads ? w.dfeat : nullptr, stream));
     // the TV term depends on the hash table only: without map gradients it is evaluated just for its value, if asked
     if (b->tv_sum) RFX_TRY(rfx_tv_forward(w.feat, P, L * F, b->tv_sum, stream));      // (its features: the prologue's)
+    RFX_MARK(RFX_BA_EV_LOSS);
     // ---- backward: the chain variant that produces exactly what the following stages read; its selection launch also
     //      finishes the losses
     int finalized = 0;
@@ -243,16 +254,25 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
                                                  map_grads && b->d_poses16 ? 0 : map_grads ? 2 : 1, w.ray_cnt, S, w.lsum, n_partials, lc,
                                                  &finalized, stream));
     if (!finalized) RFX_TRY(loss_finalize_launch(w.lsum, n_partials, n, S, lc, stream));
+    RFX_MARK(RFX_BA_EV_CHAIN);
     float* dw1 = b->d_w; float* dw2 = dw1 ? dw1 + 32 * 81 : nullptr; float* dw3 = dw1 ? dw2 + 16 * 32 : nullptr;
     float* dw4 = dw1 ? dw3 + 32 * 66 : nullptr;
     if (map_grads && !b->d_poses16) {     // map phase: weight gradients and table scatter back to back (they share a launch)
-        return field_backward_weights_scatter(&b->field, w.x01, nS, w.d_raw, dw1, dw2, dw3, dw4, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws,
-                                              w.bwd_bytes, w.scat_ws, w.scat_bytes, stream, ow_level < L ? ow_level : RFX_MAX_LEVELS + 1);
+        RFX_TRY(field_backward_weights_scatter(&b->field, w.x01, nS, w.d_raw, dw1, dw2, dw3, dw4, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws,
+                                               w.bwd_bytes, w.scat_ws, w.scat_bytes, stream, ow_level < L ? ow_level : RFX_MAX_LEVELS + 1,
+                                               b->stage_events ? b->stage_events[RFX_BA_EV_WEIGHTS] : nullptr));
+        RFX_MARK(RFX_BA_EV_SCATTER);
+        return RFX_OK;
     }
-    if (map_grads) RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+    if (map_grads) {
+        RFX_TRY(field_backward_weights_overwrite(nS, w.d_raw, dw1, dw2, dw3, dw4, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_MARK(RFX_BA_EV_WEIGHTS);
+    }
     if (b->d_poses16) {
         RFX_TRY(rfx_field_backward_scatter(&b->field, w.x01, nS, nullptr, w.dx, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_MARK(RFX_BA_EV_DX_TABLE);
         RFX_TRY(rfx_field_backward_dx(&b->field, w.x01, nS, w.d_raw, w.dx, w.bwd_ws, w.bwd_bytes, stream));
+        RFX_MARK(RFX_BA_EV_DX);
         int chained = 0;      // d rays -> d poses -> pose-MLP backward in one launch, when the caller hands the MLP over
         if (b->rba) {
             if (!b->rba_acts || !b->rba_grads || !b->rba_ws) return RFX_ERR_ARG;
@@ -270,10 +290,12 @@ int rfx_ba_forward_backward(const rfx_ba_desc* b, void* workspace, size_t worksp
             RFX_TRY(rfx_pose_grad(w.go, w.gd, w.d_cam, w.pidx, n, b->K, b->d_poses16, stream));
             if (b->rba) RFX_TRY(rfx_rba_backward(b->rba, b->rba_acts, b->K, b->d_poses16, b->rba_scale, b->rba_grads, b->rba_ws, stream));
         }
+        RFX_MARK(RFX_BA_EV_POSE);
     }
     if (map_grads) {
         RFX_TRY(rfx_field_backward_scatter_merged(&b->field, w.x01, nS, w.pts, w.dfeat, nt, b->d_hash, w.bwd_ws, w.bwd_bytes, w.scat_ws,
                                                   w.scat_bytes, stream));
+        RFX_MARK(RFX_BA_EV_SCATTER);
     }
     return RFX_OK;
 }

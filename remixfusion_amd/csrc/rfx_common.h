@@ -89,7 +89,8 @@ int pose_chain_backward(const float* dx01, const float* z_vals, const float* d_c
 int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
                                    float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
-                                   rfx_stream stream, int overwrite_from_level = RFX_MAX_LEVELS + 1);   // rfx_field.hip
+                                   rfx_stream stream, int overwrite_from_level = RFX_MAX_LEVELS + 1,
+                                   void* weights_done_event = nullptr);   // rfx_field.hip
 // the scatter WRITES (not adds) the gradient of the levels from the returned one on: the caller skips their zero-fill (rfx_field.hip)
 int scatter_overwrite_from_level(const rfx_grid_desc& g, int64_t n_all, bool have_scratch, const float* dtable);
 int grid_encode_backward_merged_from(const rfx_grid_desc* g, const float* table, const float* x01_a, int64_t n_a,

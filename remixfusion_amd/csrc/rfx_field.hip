@@ -2479,11 +2479,14 @@ namespace rfx {
 int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, int64_t n, const float* draw4, float* dw1, float* dw2,
                                    float* dw3, float* dw4, const float* extra_x01, const float* extra_dfeat, int64_t extra_n,
                                    float* d_hash, void* workspace, size_t workspace_bytes, void* scatter_ws, size_t scatter_bytes,
-                                   rfx_stream stream, int overwrite_from_level) {
+                                   rfx_stream stream, int overwrite_from_level, void* weights_done_event) {
+    // weights_done_event (optional, a hipEvent_t): recorded between the weight-gradient launch and the scatter's launches
+    // (rfx_ba_desc.stage_events[RFX_BA_EV_WEIGHTS])
     if (!d_hash || (n == 0 && extra_n == 0)) {
         if (d_hash && overwrite_from_level <= RFX_MAX_LEVELS) return RFX_ERR_ARG;
         int rc = launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true);
         if (rc) return rc;
+        if (weights_done_event) RFX_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(weights_done_event), as_stream(stream)));
         return rfx_field_backward_scatter_merged(f, x01, n, extra_x01, extra_dfeat, extra_n, d_hash, workspace, workspace_bytes, scatter_ws,
                                                  scatter_bytes, stream);
     }
@@ -2497,6 +2500,7 @@ int field_backward_weights_scatter(const rfx_field_desc* f, const float* x01, in
     DwJob job;
     rc = launch_backward_weights(n, draw4, dw1, dw2, dw3, dw4, workspace, workspace_bytes, stream, true, &job);
     if (rc) return rc;
+    if (weights_done_event) RFX_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(weights_done_event), as_stream(stream)));
     BwdWs ws{};
     if (n > 0) ws = carve(workspace, n);
     bool taken = false;

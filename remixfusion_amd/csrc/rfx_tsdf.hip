@@ -1486,6 +1486,34 @@ int rfx_debug_mv_times(unsigned long long* out, int n_waves) {
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 int rfx_last_hip_error(void) { return g_last_hip_error; }
 
+// timing events for a caller without a HIP binding (include/rfx.h, ABI 10)
+int rfx_event_create(rfx_event* out) {
+    if (!out) return RFX_ERR_ARG;
+    hipEvent_t e = nullptr;
+    // timing only: no system-scope fence (cache write-back + invalidate) when the event completes -- the fence is what an
+    // event costs the work behind it, and nothing here reads device memory from the host after waiting on these events
+    RFX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+    *out = e;
+    return RFX_OK;
+}
+int rfx_event_destroy(rfx_event ev) {
+    if (!ev) return RFX_ERR_ARG;
+    RFX_HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+    return RFX_OK;
+}
+int rfx_event_elapsed_ms(rfx_event start, rfx_event stop, float* ms) {
+    if (!start || !stop || !ms) return RFX_ERR_ARG;
+    // an event that was never recorded is an expected answer here (a stage the phase does not run), not a fault of the process:
+    // the runtime's sticky last-error is cleared, or the caller's next unrelated HIP call (torch's) would report it
+    hipError_t e = hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop));
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return ::rfx::hip_fail(e);
+    }
+    return RFX_OK;
+}
+
 // workspace = [queue counters + coarse max-depth tiles | A: 8 B per pixel | B: 16 B per pixel | work queue | queue of the rows
 // next to x-slab boundaries].  Queue form: A = the {F, G} classification image, B = the exact path's image {depth, 1/lambda,
 // packed colour, 0}.  Tile form: A = {depth, 1/lambda}, B = the packed colour (when the caller hands over rgb).  The queue

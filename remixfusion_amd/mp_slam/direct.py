@@ -134,6 +134,10 @@ class DirectIterations:
         self.stagewise_every = 0        # bench.py: issue every k-th iteration stage by stage (timed per entry point)
         self.before_stagewise = None    # bench.py: callable run first in such an iteration (waits for the volume's stream, so
                                         # that the per-call timings are not stretched by V1 running beside them)
+        # bench.py: callable(phase, n_rays) -> address of a host array of _lib.BA_STAGE_EVENTS event handles, or None.  The
+        # one-call iteration records them at its stage boundaries (rfx_ba_desc.stage_events): per-stage device times of the
+        # very launches the loop runs, without the stage-by-stage issue's extra calls and un-fused kernels
+        self.stage_events = None
         # mapping.unused_gradients: also compute, in the pose phase, the map gradients that no optimizer consumes
         # (what the reference's loss.backward() does); off by default, results are identical either way
         self.unused_gradients = bool(mapper.config["mapping"].get("unused_gradients", False))
@@ -252,6 +256,7 @@ class DirectIterations:
             d.d_hash, d.d_w, d.tv_sum = p.dt, p.dw_flat, (p.tv_acc if self.report_tv else None)
         else:                           # pose phase: only the ray/pose gradients (the u6 draw above keeps the random stream)
             d.d_hash = d.d_w = d.tv_sum = None
+        d.stage_events = self.stage_events("pose" if d_poses_ptr else "map", n) if self.stage_events is not None else None
         return d
 
     # ------------------------------------------------------------------ stage-by-stage issue (instrumentation / cross-check)

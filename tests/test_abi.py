@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, fn), f"{fn} declared in include/rfx.h but not exported"
         assert fn in _lib.PROTOTYPES, f"{fn} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == declared
-    assert lib.rfx_abi_version() == 9
+    assert lib.rfx_abi_version() == 10
 
 
 def test_struct_layouts_match_header():

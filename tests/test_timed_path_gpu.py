@@ -326,3 +326,92 @@ def test_full_frame_fused_render_matches_oracle_on_random_rays():
     _close(rgb.cpu()[sel], ref["rgb_res_map"], 1e-4, 2e-5, "full-frame fused rgb")
     _close(dep.cpu()[sel], ref["depth_res_map"], 1e-4, 2e-5, "full-frame fused depth")
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(dep).all())
+
+
+def test_stage_events_time_the_one_call_iteration_without_changing_it():
+    """ABI 10: rfx_ba_desc.stage_events.  The one-call iteration records the caller's events at its stage boundaries (what
+    bench.py's roofline is made of): with and without them the same gradients (same seeds: the decoder gradients bit for bit, the
+    table gradient to within the float-atomic flush's own run-to-run difference), the stages that ran have positive times that
+    add up to no more than the whole call, and the stages of the OTHER phase record nothing."""
+    from remixfusion_amd import _lib
+    cfg, pipe, fr = _pipeline("office0", 11)
+    mp, model, slam = pipe.mapper, pipe.model, pipe.slam
+    direct = mp._direct_iterations()
+    m = cfg["mapping"]
+    enc = model.embed_res_fn
+    last = 10
+    b = fr[last]
+    cur = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], dim=-1).reshape(-1, 7).contiguous()
+    n_kf = len(mp.keyframe.frame_ids)
+    poses = slam.est_c2w_data[0:last + 1:m["keyframe_every"]].clone().float().contiguous()
+    poses_all = torch.cat([poses, slam.est_c2w_data[last:last + 1].float()], 0)[:n_kf + 1].contiguous()
+    lib = _lib.load()
+    params = [enc.params] + list(model.decoder_res.fused_weights())
+    direct.stagewise_every = 0
+
+    def new_set():
+        arr = (C.c_void_p * _lib.BA_STAGE_EVENTS)()
+        for i in range(_lib.BA_STAGE_EVENTS):
+            ev = C.c_void_p()
+            _lib.check(lib.rfx_event_create(C.byref(ev)), "rfx_event_create")
+            arr[i] = ev.value
+        return arr
+
+    handed = []
+
+    def provider(phase, n):
+        arr = new_set()
+        handed.append((phase, n, arr))
+        return C.addressof(arr)
+
+    def run_map(with_events, seed):
+        for p_ in params:
+            p_.grad = None
+        direct.stage_events = provider if with_events else None
+        random.seed(seed); torch.manual_seed(seed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lc = direct.map_gradients(cur, poses_all).clone()
+        e1.record()
+        torch.cuda.synchronize()
+        return enc.params.grad.detach().clone(), [w.grad.detach().clone() for w in params[1:]], lc, e0.elapsed_time(e1)
+
+    try:
+        plain, dw_p, lc_p, _ = run_map(False, 5)
+        again, _, _, _ = run_map(False, 5)
+        timed, dw_t, lc_t, whole_ms = run_map(True, 5)
+        assert torch.equal(lc_p, lc_t)
+        for a_, t_ in zip(dw_p, dw_t):
+            assert torch.equal(a_, t_)
+        noise = float((again - plain).abs().max())
+        assert float((timed - plain).abs().max()) <= 4 * noise + 4e-6 * float(plain.abs().max())
+        assert len(handed) == 1 and handed[0][0] == "map" and handed[0][1] == direct._n_rays()
+        arr = handed[0][2]
+        ev = _lib.BA_EV
+        order = ("start", "prologue", "forward", "loss", "chain", "weights", "scatter")
+        total = 0.0
+        for a_, b_ in zip(order[:-1], order[1:]):
+            ms = C.c_float()
+            assert lib.rfx_event_elapsed_ms(arr[ev[a_]], arr[ev[b_]], C.byref(ms)) == 0, (a_, b_)
+            assert 0.0 < ms.value < 5.0, (b_, ms.value)
+            total += ms.value
+        assert total <= whole_ms * 1.05 + 0.02, (total, whole_ms)
+        ms = C.c_float()
+        for name in ("dx_table", "dx", "pose"):          # never recorded in the map phase: no elapsed time to be had
+            assert lib.rfx_event_elapsed_ms(arr[ev["scatter"]], arr[ev[name]], C.byref(ms)) != 0, name
+        # the pose phase records its own stages
+        idx = torch.arange(0, poses_all.shape[0], device=poses_all.device)        # as Mapper.global_pose forms it
+        direct.stage_events = provider
+        random.seed(6); torch.manual_seed(6)
+        direct.pose_gradients(cur, idx, map_grads=False)
+        torch.cuda.synchronize()
+        assert len(handed) == 2 and handed[1][0] == "pose"
+        arr = handed[1][2]
+        for a_, b_ in zip(("start", "prologue", "forward", "loss", "chain", "dx_table", "dx"), ("prologue", "forward", "loss", "chain", "dx_table", "dx", "pose")):
+            assert lib.rfx_event_elapsed_ms(arr[ev[a_]], arr[ev[b_]], C.byref(ms)) == 0 and ms.value > 0.0, (a_, b_)
+        assert lib.rfx_event_elapsed_ms(arr[ev["chain"]], arr[ev["weights"]], C.byref(ms)) != 0
+    finally:
+        direct.stage_events = None
+        for _, _, arr in handed:
+            for i in range(len(arr)):
+                lib.rfx_event_destroy(arr[i])
