@@ -22,6 +22,11 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace rfx {
 
@@ -275,9 +280,18 @@ constexpr int64_t SCATTER_MIN_POINTS = 4096;
 
 struct ScatterPlan {
     int seg_start[RFX_MAX_LEVELS + 1];
-    int chunks;          // slices of the point list
+    int chunks;          // slices of the point list (1 since round 6: the sweep's blocks take ROW ranges, see pos_*)
     int K;               // points per thread and chunk; a chunk covers K * SCATTER_THREADS points
     int64_t slots;       // chunks * K * SCATTER_THREADS
+    // Dispatch order of the sweep (round 6).  The grid is one-dimensional; position k holds the blocks of level pos_level[k]:
+    // (segments of the level) x pos_parts[k] blocks, block = (segment, part), and a part is a range of the K staged rows (a row =
+    // one point of each of the 1 024 threads).  The positions are ordered by the cost of one of their blocks, dearest first,
+    // and the parts are chosen per level class so that the whole sweep is ONE round of blocks on the chip where it can be
+    // (sweep_plan() below).
+    int n_pos;
+    int pos_level[RFX_MAX_LEVELS];
+    int pos_parts[RFX_MAX_LEVELS];
+    int pos_start[RFX_MAX_LEVELS + 1];
     // The first source may be shorter on the device than on the host (the field backward puts the points with a non-zero
     // loss gradient first and counts them, n_sel): the kernels then deal out min(n_a, *n_sel) points, K_eff <= K per thread.
     int64_t n_a, n_b;
@@ -294,26 +308,132 @@ __device__ __forceinline__ ScatterShare scatter_share(const ScatterPlan& p) {
     return s;
 }
 
-// How many slices to cut the point list into.  One block per CU (128 KB of LDS), so the launch runs in
-// ceil(segments * chunks / 256) rounds of blocks that each cost (points / chunks) * t_point + t_fixed (zeroing and
-// flushing the segment).  Pick the chunk count that minimises rounds * block cost: it keeps the last round from
-// running nearly empty (317 segments at T = 2^19 would otherwise take two full-length rounds).
-static void scatter_shape(int64_t n, int total_segments, int* chunks, int* K) {
-    const int64_t max_chunks = std::max<int64_t>(1, std::min<int64_t>(64, (n + SCATTER_MIN_POINTS - 1) / SCATTER_MIN_POINTS));
-    const double t_point = 6.4e-3, t_fixed = 12.0;      // microseconds; measured on MI355X (only the ratio matters)
-    int best = 1;
-    double best_t = 1e300;
-    for (int c = 1; c <= (int)max_chunks; ++c) {
-        const int rounds = (total_segments * c + 255) / 256;
-        const double t = rounds * ((double)n / c * t_point + t_fixed);
-        if (t < best_t * 0.97) { best_t = t; best = c; }          // prefer fewer chunks unless clearly better
-    }
-    const int64_t per = (n + best - 1) / best;
-    *chunks = best;
-    *K = (int)((per + SCATTER_THREADS - 1) / SCATTER_THREADS);
+// The sweep's schedule (round 6; rounds 2-5 cut the point list into `chunks` slices and launched segments x chunks equal-looking
+// blocks, picked by a two-parameter model whose fixed cost was a tenth of the measured one: 510 blocks at office0, two rounds on
+// 256 CUs, the dear blocks of the small dense levels starting at 43 us of a 120 us launch -- tools/scatter_prof.py).
+// One block per CU (128 KB of LDS) and a block costs fixed(level) + points * per_point(level):
+//   fixed      zeroing and flushing the segment's accumulators: ~12 us for a full 8 192-entry segment
+//   per_point  a hashed level cut into >= 8 segments (membership test first, few corners land): 0.65 ns;
+//              the other levels (every corner lands, same-cell runs merged in registers, same-address atomics): 1.2-1.4 ns
+// (measured with -DSCATTER_PROF on office0's 201 k points).  A block takes a RANGE OF ROWS of the staged points (row i = point
+// t K + i of every thread t: any range has the sources' mix), `parts` ranges per segment -- chosen per level class, the pair that
+// gives the shortest greedy longest-first schedule on the chip's CUs: at office0 2 parts for the 88 segments of the cut
+// levels + 5 for the 14 of the dense ones = 246 blocks, one round, the dearest first.
+struct SweepCost { double fixed, per_point; bool cut; };
+static SweepCost sweep_cost(const rfx_grid_desc& g, int l, unsigned seg_entries, bool f64) {
+    SweepCost c;
+    const unsigned n_seg = (g.size[l] + seg_entries - 1) / seg_entries;
+    c.cut = g.hashed[l] && g.size[l] >= (f64 ? 8u : 16u) * seg_entries;
+    const double fill = (double)std::min(g.size[l], seg_entries) / seg_entries;
+    c.fixed = 2.0 + 10.0 * fill;
+    c.per_point = (c.cut ? 0.65e-3 : n_seg == 1 ? 1.4e-3 : 1.2e-3) * (f64 ? 1.0 : 3.0);      // (ds_add_f32: tools/micro/lds_atomic)
+    return c;
 }
 
-// upper bound of staged slots for any plan of scatter_shape(): each chunk pads to a multiple of 1024 points.  The same
+static double sweep_makespan(const double* cost, const int* count, int n_kinds, int cus, std::vector<double>& heap) {
+    // greedy list schedule, kinds in the given (dearest-first) order; heap = the CUs' finish times (min-heap)
+    heap.assign((size_t)cus, 0.0);
+    double span = 0.0;
+    for (int k = 0; k < n_kinds; ++k)
+        for (int i = 0; i < count[k]; ++i) {
+            std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+            const double e = heap.back() + cost[k];
+            heap.back() = e;
+            std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+            span = std::max(span, e);
+        }
+    return span;
+}
+
+struct SweepPlanKey { int64_t n_bucket; unsigned sizes[RFX_MAX_LEVELS]; unsigned hashed_mask, binned_mask; int n_levels, cus, f64, K; };
+struct SweepPlanVal { int n_pos, pos_level[RFX_MAX_LEVELS], pos_parts[RFX_MAX_LEVELS]; };
+
+// fills plan->n_pos / pos_level / pos_parts / pos_start for the non-binned levels; returns the number of blocks
+static int sweep_plan(const rfx_grid_desc& g, const bool* binned, unsigned seg_entries, bool f64, int64_t n_est, int K, int cus,
+                      ScatterPlan* plan) {
+    static std::mutex mu;
+    static std::vector<std::pair<SweepPlanKey, SweepPlanVal>> memo;
+    SweepPlanKey key;
+    memset(&key, 0, sizeof(key));
+    key.n_bucket = n_est >> 13; key.n_levels = g.n_levels; key.cus = cus; key.f64 = f64 ? 1 : 0; key.K = std::min(K, 64);
+    for (int l = 0; l < g.n_levels; ++l) {
+        key.sizes[l] = g.size[l];
+        if (g.hashed[l]) key.hashed_mask |= 1u << l;
+        if (binned[l]) key.binned_mask |= 1u << l;
+    }
+    SweepPlanVal val;
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const auto& kv : memo)
+            if (!memcmp(&kv.first, &key, sizeof(key))) { val = kv.second; found = true; break; }
+    }
+    if (!found) {
+        int lv[RFX_MAX_LEVELS], n_lv = 0;
+        SweepCost sc[RFX_MAX_LEVELS];
+        int segs[RFX_MAX_LEVELS];
+        for (int l = 0; l < g.n_levels; ++l)
+            if (!binned[l]) {
+                lv[n_lv] = l; sc[n_lv] = sweep_cost(g, l, seg_entries, f64);
+                segs[n_lv] = (int)((g.size[l] + seg_entries - 1) / seg_entries);
+                ++n_lv;
+            }
+        const int max_cut = std::max(1, std::min(8, K)), max_other = std::max(1, std::min(16, K));
+        double best = 1e300;
+        int best_blocks = 0, best_cut = 1, best_other = 1;
+        std::vector<double> heap;
+        int order[RFX_MAX_LEVELS];
+        double cost[RFX_MAX_LEVELS];
+        int count[RFX_MAX_LEVELS];
+        for (int pc = 1; pc <= max_cut; ++pc)
+            for (int po = 1; po <= max_other; ++po) {
+                double c_l[RFX_MAX_LEVELS];
+                int blocks = 0;
+                for (int i = 0; i < n_lv; ++i) {
+                    const int parts = sc[i].cut ? pc : po;
+                    c_l[i] = sc[i].fixed + (double)n_est / parts * sc[i].per_point;
+                    blocks += segs[i] * parts;
+                    order[i] = i;
+                }
+                std::stable_sort(order, order + n_lv, [&](int x, int y) { return c_l[x] > c_l[y]; });
+                for (int i = 0; i < n_lv; ++i) { cost[i] = c_l[order[i]]; count[i] = segs[order[i]] * (sc[order[i]].cut ? pc : po); }
+                const double span = sweep_makespan(cost, count, n_lv, cus, heap);
+                if (span < best * 0.98 || (span < best * 1.02 && blocks < best_blocks)) {
+                    best = std::min(best, span); best_blocks = blocks; best_cut = pc; best_other = po;
+                }
+            }
+        double c_l[RFX_MAX_LEVELS];
+        for (int i = 0; i < n_lv; ++i) {
+            c_l[i] = sc[i].fixed + (double)n_est / (sc[i].cut ? best_cut : best_other) * sc[i].per_point;
+            order[i] = i;
+        }
+        std::stable_sort(order, order + n_lv, [&](int x, int y) { return c_l[x] > c_l[y]; });
+        val.n_pos = n_lv;
+        for (int i = 0; i < n_lv; ++i) { val.pos_level[i] = lv[order[i]]; val.pos_parts[i] = sc[order[i]].cut ? best_cut : best_other; }
+        static const bool debug = getenv("RFX_DEBUG_SWEEP") != nullptr;
+        if (debug) fprintf(stderr, "[sweep] %lld points, %d rows, %d CUs: %d parts for the cut levels, %d for the others, %d blocks, modelled %.1f us\n",
+                           (long long)n_est, K, cus, best_cut, best_other, best_blocks, best);
+        std::lock_guard<std::mutex> lock(mu);
+        if (memo.size() < 256) memo.emplace_back(key, val);
+    }
+    plan->n_pos = val.n_pos;
+    int total = 0;
+    for (int k = 0; k < RFX_MAX_LEVELS; ++k) {
+        plan->pos_start[k] = total;
+        if (k < val.n_pos) {
+            const int l = val.pos_level[k];
+            plan->pos_level[k] = l; plan->pos_parts[k] = val.pos_parts[k];
+            total += (int)((g.size[l] + seg_entries - 1) / seg_entries) * val.pos_parts[k];
+        } else {
+            plan->pos_level[k] = 0; plan->pos_parts[k] = 1;
+        }
+    }
+    plan->pos_start[RFX_MAX_LEVELS] = total;
+    return total;
+}
+
+// upper bound of the staged slots (one chunk since round 6: n rounded up to whole rows of 1 024; the bound still covers the
+// chunked layouts of rounds 2-5).  The same
 // buffer holds the records of the binned levels afterwards, one level at a time when it is no larger than this minimum:
 // 24 floats per point + the [blk][seg] counters of the level with the most segments the binned path accepts -- more than
 // the sweep's (2 L + 3) floats per point when the grid has 8 levels or fewer (a sub-grid of a level-partitioned table).
@@ -434,12 +554,14 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     ACC* acc = reinterpret_cast<ACC*>(acc_raw);
 #ifdef SCATTER_PROF
-    const unsigned pid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned pid = blockIdx.x;
     if (threadIdx.x == 0 && pid < 8192) g_scatter_prof[2 * pid] = wall_clock64();
 #endif
-    int l = 0;
-    while (l + 1 < g.n_levels && (int)blockIdx.x >= plan.seg_start[l + 1]) ++l;
-    const int seg = blockIdx.x - plan.seg_start[l], chunk = blockIdx.y;
+    int pos = 0;
+    while (pos + 1 < plan.n_pos && (int)blockIdx.x >= plan.pos_start[pos + 1]) ++pos;
+    const int l = plan.pos_level[pos];
+    const int n_seg = plan.seg_start[l + 1] - plan.seg_start[l];
+    const int seg = ((int)blockIdx.x - plan.pos_start[pos]) % n_seg, part = ((int)blockIdx.x - plan.pos_start[pos]) / n_seg;
     const Level lv = get_level(g, l);
     const unsigned pm = lv.hashed ? 0u : 15u;
     const unsigned base = (unsigned)seg * SEG;
@@ -449,8 +571,12 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
     const int64_t slots = plan.slots;
     const float2* __restrict__ gvp = reinterpret_cast<const float2*>(scratch) + (int64_t)l * slots;
     const float* __restrict__ xs = scratch + (size_t)slots * 2 * n_levels;
-    int64_t s = (int64_t)chunk * plan.K * SCATTER_THREADS + threadIdx.x;
-    const int K_eff = scatter_share(plan).K;         // <= plan.K (the slot stride): see ScatterPlan
+    // this block's rows [r0, r0 + K_eff) of the K_all staged ones (K_all <= plan.K: see ScatterPlan)
+    const int K_all = scatter_share(plan).K;
+    const int rows_per = (K_all + plan.pos_parts[pos] - 1) / plan.pos_parts[pos];
+    const int r0 = min(part * rows_per, K_all);
+    const int K_eff = min(rows_per, K_all - r0);
+    int64_t s = (int64_t)r0 * SCATTER_THREADS + threadIdx.x;
 
     Cell cur;                       // cell of the running register accumulation
     bool open = false;
@@ -1212,10 +1338,22 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     plan.n_a = n; plan.n_b = n_b; plan.n_sel = n_sel;
     const size_t scratch_floats = scatter_scratch_floats(n_all, g.n_levels);
     if (total > 0) {
-        scatter_shape(n_all, total, &plan.chunks, &plan.K);
-        const int64_t per_a = (n + plan.chunks - 1) / plan.chunks, per_b = (n_b + plan.chunks - 1) / plan.chunks;
-        plan.K = (int)((per_a + per_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
-        plan.slots = (int64_t)plan.chunks * plan.K * SCATTER_THREADS;
+        plan.chunks = 1;
+        plan.K = (int)((n + n_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
+        plan.slots = (int64_t)plan.K * SCATTER_THREADS;
+        static int cus_of[64] = {};          // per device
+        int dev = 0;
+        RFX_HIP_TRY(hipGetDevice(&dev));
+        int cus = dev >= 0 && dev < 64 ? cus_of[dev] : 0;
+        if (cus <= 0) {
+            RFX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            cus = std::max(cus, 1);
+            if (dev >= 0 && dev < 64) cus_of[dev] = cus;
+        }
+        // the field backward hands over the rows with a gradient only (n_sel, counted on the device): ~0.65 of the batch in a BA
+        // iteration -- the plan is made for that many (the costs' RATIO is what it depends on)
+        const int64_t n_est = n_b + (n_sel ? (int64_t)(0.65 * (double)n) : n);
+        const int n_blocks = sweep_plan(g, binned, seg_entries, f64, std::max<int64_t>(n_est, 1), plan.K, cus, &plan);
         if ((size_t)plan.slots * (2 * g.n_levels + 3) > scratch_floats) return RFX_ERR_WORKSPACE;
         const int nb_stage = (int)((plan.slots + 255) / 256);
         hipLaunchKernelGGL(scatter_stage_kernel, dim3((unsigned)(nb_stage + (dw ? DW_JOB_BLOCKS : 0))), dim3(256), 0, st, a, b, plan,
@@ -1224,8 +1362,6 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
         if (dw && dw_taken) *dw_taken = true;
         const size_t lds = (size_t)SCATTER_SEG * 2 * sizeof(float);
         static bool attr_set[64] = {};       // the attribute is per device
-        int dev = 0;
-        RFX_HIP_TRY(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
             RFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_lds_kernel<float, SCATTER_SEG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1236,10 +1372,10 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
         // (an XCD-aware block order -- all segments of one (level, chunk) on one XCD's L2 -- was measured: no gain at
         // T = 2^16 / 2^19 and a loss at 2^21, the levels' costs differ too much to be dealt out per XCD)
         if (f64)
-            hipLaunchKernelGGL((grid_scatter_lds_kernel<double, SCATTER_SEG / 2>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g,
+            hipLaunchKernelGGL((grid_scatter_lds_kernel<double, SCATTER_SEG / 2>), dim3(n_blocks), dim3(SCATTER_THREADS), lds, st, g,
                                plan, g.n_levels, scratch, dtable);
         else
-            hipLaunchKernelGGL((grid_scatter_lds_kernel<float, SCATTER_SEG>), dim3(total, plan.chunks), dim3(SCATTER_THREADS), lds, st, g, plan,
+            hipLaunchKernelGGL((grid_scatter_lds_kernel<float, SCATTER_SEG>), dim3(n_blocks), dim3(SCATTER_THREADS), lds, st, g, plan,
                                g.n_levels, scratch, dtable);
         RFX_LAUNCH_CHECK();
     }

@@ -33,3 +33,21 @@ for n, s, e in win:
     a = agg.setdefault(n, [0, 0]); a[0] += 1; a[1] += e - s
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"  {k[:90]:90s} {v[0]:5d} x {v[1] / v[0] / 1e3:8.1f} us = {v[1] / 1e6:7.3f} ms")
+# everything that is not a librfx kernel (torch glue of the frame loop and of the mapper step), by total time
+other = {k: v for k, v in agg.items() if 'rfx::' not in k}
+tot = sum(v[1] for v in other.values())
+print(f"non-librfx kernels in the window: {sum(v[0] for v in other.values())} launches, {tot / 1e6:.3f} ms in total")
+for k, v in sorted(other.items(), key=lambda kv: -kv[1][1])[:25]:
+    short = k.replace('at::native::', '').replace('void ', '')[:110]
+    print(f"  {short:110s} {v[0]:5d} x {v[1] / v[0] / 1e3:7.1f} us = {v[1] / 1e6:7.3f} ms")
+# the launches of ONE mapper step's glue: from the end of a step's last rba kernel to the next step's first ba_prologue
+if len(sys.argv) > 3:
+    pro = [i for i, r in enumerate(win) if 'ba_prologue_kernel' in r[0]]
+    # first prologue of the third mapper step in the window (prologues come in runs of 10)
+    k = pro[20] if len(pro) > 20 else pro[-10]
+    j = k - 1
+    while j > 0 and 'adam_step_kernel' not in win[j][0]:
+        j -= 1
+    print(f"launches between the previous step's last optimizer step and this step's first iteration ({(win[k][1] - win[j][2]) / 1e3:.1f} us):")
+    for n, s, e in win[j:k + 1]:
+        print(f"   +{(s - win[j][1]) / 1e3:9.1f} us {(e - s) / 1e3:7.1f} us  {n.replace('at::native::', '')[:100]}")

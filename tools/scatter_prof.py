@@ -30,23 +30,14 @@ buf = (C.c_ulonglong * (2 * 8192))()
 assert raw.rfx_debug_scatter_prof(buf, 2 * 8192) == 0
 a = np.array(buf[:], dtype=np.uint64).reshape(-1, 2)
 sizes = list(enc.desc.size)[:16]
-segs = [(s + 8191) // 8192 for s in sizes]
-total = sum(segs)
-chunks = int((a[:, 1] > 0).sum()) // total
-print("segments per level", segs, "total", total, "chunks", chunks)
-nb = total * chunks
+# round 6: one-dimensional grid, blocks in dispatch order (dearest level first; RFX_DEBUG_SWEEP=1 prints the parts per class)
+nb = int((a[:, 1] > 0).sum())
 t0 = a[:nb, 0].min()
-lin = np.arange(nb)
-seg_lin, chunk = lin % total, lin // total              # blockIdx.x = segment, blockIdx.y = chunk
 start = (a[:nb, 0] - t0) / 100.0                        # 100 MHz wall clock -> us
 dur = (a[:nb, 1] - a[:nb, 0]) / 100.0
-o = 0
-for l, s_ in enumerate(segs):
-    m = (seg_lin >= o) & (seg_lin < o + s_)
-    print(f"level {l:2d} ({sizes[l]:6d} entries, {s_} segs): block duration mean {dur[m].mean():6.1f} max {dur[m].max():6.1f} us; start mean {start[m].mean():6.1f} max {start[m].max():6.1f}")
-    o += s_
-print("launch span", (a[:nb, 1].max() - t0) / 100.0, "us; blocks", nb)
-order = np.argsort(start)
-print("start time of the k-th block to start:", " ".join(f"{k}:{start[order[k]]:.0f}" for k in range(0, nb, 32)))
 end = start + dur
+print("blocks", nb, "launch span", float(end.max()), "us; sum of block times", float(dur.sum()), "us =", float(dur.sum() / 256), "per CU")
+for lo in range(0, nb, 32):
+    m = slice(lo, min(nb, lo + 32))
+    print(f"blocks {lo:4d}..: duration mean {dur[m].mean():6.1f} max {dur[m].max():6.1f}; start mean {start[m].mean():6.1f} max {start[m].max():6.1f}")
 print("blocks running at t =", " ".join(f"{t}us:{int(((start <= t) & (end > t)).sum())}" for t in range(0, 130, 10)))
