@@ -22,11 +22,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
-#include <functional>
-#include <mutex>
-#include <utility>
-#include <vector>
 
 namespace rfx {
 
@@ -288,6 +285,8 @@ struct ScatterPlan {
     // one point of each of the 1 024 threads).  The positions are ordered by the cost of one of their blocks, dearest first,
     // and the parts are chosen per level class so that the whole sweep is ONE round of blocks on the chip where it can be
     // (sweep_plan() below).
+    unsigned swept;      // bit l: level l goes through the sweep -- the only planes the staging pass writes (a binned level's sort
+                         // reads the gradient rows themselves: at T >= 2^19 two thirds of the staging traffic went unread)
     int n_pos;
     int pos_level[RFX_MAX_LEVELS];
     int pos_parts[RFX_MAX_LEVELS];
@@ -314,11 +313,10 @@ __device__ __forceinline__ ScatterShare scatter_share(const ScatterPlan& p) {
 // One block per CU (128 KB of LDS) and a block costs fixed(level) + points * per_point(level):
 //   fixed      zeroing and flushing the segment's accumulators: ~12 us for a full 8 192-entry segment
 //   per_point  a hashed level cut into >= 8 segments (membership test first, few corners land): 0.65 ns;
-//              the other levels (every corner lands, same-cell runs merged in registers, same-address atomics): 1.2-1.4 ns
+//              the other levels (every corner lands, same-cell runs merged in registers, same-address atomics): 1.2-1.6 ns
 // (measured with -DSCATTER_PROF on office0's 201 k points).  A block takes a RANGE OF ROWS of the staged points (row i = point
-// t K + i of every thread t: any range has the sources' mix), `parts` ranges per segment -- chosen per level class, the pair that
-// gives the shortest greedy longest-first schedule on the chip's CUs: at office0 2 parts for the 88 segments of the cut
-// levels + 5 for the 14 of the dense ones = 246 blocks, one round, the dearest first.
+// t K + i of every thread t: any range has the sources' mix), `parts` ranges per segment of its level -- at office0 2 parts for the
+// 88 segments of the cut levels and 4-5 for the 14 of the dense ones: ~240 blocks, ONE round, the dearest first.
 struct SweepCost { double fixed, per_point; bool cut; };
 static SweepCost sweep_cost(const rfx_grid_desc& g, int l, unsigned seg_entries, bool f64) {
     SweepCost c;
@@ -326,109 +324,77 @@ static SweepCost sweep_cost(const rfx_grid_desc& g, int l, unsigned seg_entries,
     c.cut = g.hashed[l] && g.size[l] >= (f64 ? 8u : 16u) * seg_entries;
     const double fill = (double)std::min(g.size[l], seg_entries) / seg_entries;
     c.fixed = 2.0 + 10.0 * fill;
-    c.per_point = (c.cut ? 0.65e-3 : n_seg == 1 ? 1.4e-3 : 1.2e-3) * (f64 ? 1.0 : 3.0);      // (ds_add_f32: tools/micro/lds_atomic)
+    c.per_point = (c.cut ? 0.65e-3 : n_seg == 1 ? 1.6e-3 : 1.2e-3) * (f64 ? 1.0 : 3.0);      // (ds_add_f32: tools/micro/lds_atomic)
     return c;
 }
 
-static double sweep_makespan(const double* cost, const int* count, int n_kinds, int cus, std::vector<double>& heap) {
-    // greedy list schedule, kinds in the given (dearest-first) order; heap = the CUs' finish times (min-heap)
-    heap.assign((size_t)cus, 0.0);
-    double span = 0.0;
-    for (int k = 0; k < n_kinds; ++k)
-        for (int i = 0; i < count[k]; ++i) {
-            std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
-            const double e = heap.back() + cost[k];
-            heap.back() = e;
-            std::push_heap(heap.begin(), heap.end(), std::greater<double>());
-            span = std::max(span, e);
-        }
-    return span;
-}
-
-struct SweepPlanKey { int64_t n_bucket; unsigned sizes[RFX_MAX_LEVELS]; unsigned hashed_mask, binned_mask; int n_levels, cus, f64, K; };
-struct SweepPlanVal { int n_pos, pos_level[RFX_MAX_LEVELS], pos_parts[RFX_MAX_LEVELS]; };
-
-// fills plan->n_pos / pos_level / pos_parts / pos_start for the non-binned levels; returns the number of blocks
+// fills plan->n_pos / pos_level / pos_parts / pos_start for the non-binned levels; returns the number of blocks.
+// parts of a level = the fewest that bring its block under T, T = the smallest block time for which all blocks fit on the chip
+// at once (bisection: the block count falls as T rises); then the levels in the order of their block cost, dearest first.
+// When no T fits one round (more segments than CUs) every level gets one part: blocks of the table's size are then many and
+// short, and the dispatcher's order does the rest.
 static int sweep_plan(const rfx_grid_desc& g, const bool* binned, unsigned seg_entries, bool f64, int64_t n_est, int K, int cus,
                       ScatterPlan* plan) {
-    static std::mutex mu;
-    static std::vector<std::pair<SweepPlanKey, SweepPlanVal>> memo;
-    SweepPlanKey key;
-    memset(&key, 0, sizeof(key));
-    key.n_bucket = n_est >> 13; key.n_levels = g.n_levels; key.cus = cus; key.f64 = f64 ? 1 : 0; key.K = std::min(K, 64);
-    for (int l = 0; l < g.n_levels; ++l) {
-        key.sizes[l] = g.size[l];
-        if (g.hashed[l]) key.hashed_mask |= 1u << l;
-        if (binned[l]) key.binned_mask |= 1u << l;
-    }
-    SweepPlanVal val;
-    bool found = false;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        for (const auto& kv : memo)
-            if (!memcmp(&kv.first, &key, sizeof(key))) { val = kv.second; found = true; break; }
-    }
-    if (!found) {
-        int lv[RFX_MAX_LEVELS], n_lv = 0;
-        SweepCost sc[RFX_MAX_LEVELS];
-        int segs[RFX_MAX_LEVELS];
-        for (int l = 0; l < g.n_levels; ++l)
-            if (!binned[l]) {
-                lv[n_lv] = l; sc[n_lv] = sweep_cost(g, l, seg_entries, f64);
-                segs[n_lv] = (int)((g.size[l] + seg_entries - 1) / seg_entries);
-                ++n_lv;
-            }
-        const int max_cut = std::max(1, std::min(8, K)), max_other = std::max(1, std::min(16, K));
-        double best = 1e300;
-        int best_blocks = 0, best_cut = 1, best_other = 1;
-        std::vector<double> heap;
-        int order[RFX_MAX_LEVELS];
-        double cost[RFX_MAX_LEVELS];
-        int count[RFX_MAX_LEVELS];
-        for (int pc = 1; pc <= max_cut; ++pc)
-            for (int po = 1; po <= max_other; ++po) {
-                double c_l[RFX_MAX_LEVELS];
-                int blocks = 0;
-                for (int i = 0; i < n_lv; ++i) {
-                    const int parts = sc[i].cut ? pc : po;
-                    c_l[i] = sc[i].fixed + (double)n_est / parts * sc[i].per_point;
-                    blocks += segs[i] * parts;
-                    order[i] = i;
-                }
-                std::stable_sort(order, order + n_lv, [&](int x, int y) { return c_l[x] > c_l[y]; });
-                for (int i = 0; i < n_lv; ++i) { cost[i] = c_l[order[i]]; count[i] = segs[order[i]] * (sc[order[i]].cut ? pc : po); }
-                const double span = sweep_makespan(cost, count, n_lv, cus, heap);
-                if (span < best * 0.98 || (span < best * 1.02 && blocks < best_blocks)) {
-                    best = std::min(best, span); best_blocks = blocks; best_cut = pc; best_other = po;
-                }
-            }
-        double c_l[RFX_MAX_LEVELS];
-        for (int i = 0; i < n_lv; ++i) {
-            c_l[i] = sc[i].fixed + (double)n_est / (sc[i].cut ? best_cut : best_other) * sc[i].per_point;
-            order[i] = i;
+    int lv[RFX_MAX_LEVELS], segs[RFX_MAX_LEVELS], parts[RFX_MAX_LEVELS], n_lv = 0;
+    SweepCost sc[RFX_MAX_LEVELS];
+    double walk[RFX_MAX_LEVELS];
+    const int cap = std::max(1, std::min(K, 128));
+    int min_blocks = 0;
+    double t_hi = 0.0, t_lo = 0.0;
+    for (int l = 0; l < g.n_levels; ++l)
+        if (!binned[l]) {
+            lv[n_lv] = l; sc[n_lv] = sweep_cost(g, l, seg_entries, f64);
+            segs[n_lv] = (int)((g.size[l] + seg_entries - 1) / seg_entries);
+            walk[n_lv] = (double)n_est * sc[n_lv].per_point;
+            min_blocks += segs[n_lv];
+            t_hi = std::max(t_hi, sc[n_lv].fixed + walk[n_lv]);
+            t_lo = std::max(t_lo, sc[n_lv].fixed + walk[n_lv] / cap);
+            ++n_lv;
         }
-        std::stable_sort(order, order + n_lv, [&](int x, int y) { return c_l[x] > c_l[y]; });
-        val.n_pos = n_lv;
-        for (int i = 0; i < n_lv; ++i) { val.pos_level[i] = lv[order[i]]; val.pos_parts[i] = sc[order[i]].cut ? best_cut : best_other; }
-        static const bool debug = getenv("RFX_DEBUG_SWEEP") != nullptr;
-        if (debug) fprintf(stderr, "[sweep] %lld points, %d rows, %d CUs: %d parts for the cut levels, %d for the others, %d blocks, modelled %.1f us\n",
-                           (long long)n_est, K, cus, best_cut, best_other, best_blocks, best);
-        std::lock_guard<std::mutex> lock(mu);
-        if (memo.size() < 256) memo.emplace_back(key, val);
+    auto blocks_at = [&](double T, int* out) {
+        int total = 0;
+        for (int i = 0; i < n_lv; ++i) {
+            const double room = T - sc[i].fixed;
+            int p = room > 0 ? (int)std::ceil(walk[i] / room - 1e-9) : cap;
+            p = std::max(1, std::min(cap, p));
+            if (out) out[i] = p;
+            total += segs[i] * p;
+        }
+        return total;
+    };
+    if (min_blocks > cus || n_lv == 0) {
+        for (int i = 0; i < n_lv; ++i) parts[i] = 1;
+    } else {
+        double lo = t_lo, hi = t_hi;           // blocks_at(hi) = min_blocks <= cus
+        if (blocks_at(lo, nullptr) <= cus) hi = lo;
+        for (int it = 0; it < 40 && hi - lo > 0.05; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (blocks_at(mid, nullptr) <= cus) hi = mid; else lo = mid;
+        }
+        blocks_at(hi, parts);
     }
-    plan->n_pos = val.n_pos;
+    int order[RFX_MAX_LEVELS];
+    double c_l[RFX_MAX_LEVELS];
+    for (int i = 0; i < n_lv; ++i) { c_l[i] = sc[i].fixed + walk[i] / parts[i]; order[i] = i; }
+    std::stable_sort(order, order + n_lv, [&](int x, int y) { return c_l[x] > c_l[y]; });
+    plan->n_pos = n_lv;
     int total = 0;
     for (int k = 0; k < RFX_MAX_LEVELS; ++k) {
         plan->pos_start[k] = total;
-        if (k < val.n_pos) {
-            const int l = val.pos_level[k];
-            plan->pos_level[k] = l; plan->pos_parts[k] = val.pos_parts[k];
-            total += (int)((g.size[l] + seg_entries - 1) / seg_entries) * val.pos_parts[k];
+        if (k < n_lv) {
+            plan->pos_level[k] = lv[order[k]]; plan->pos_parts[k] = parts[order[k]];
+            total += segs[order[k]] * parts[order[k]];
         } else {
             plan->pos_level[k] = 0; plan->pos_parts[k] = 1;
         }
     }
     plan->pos_start[RFX_MAX_LEVELS] = total;
+    static const bool debug = getenv("RFX_DEBUG_SWEEP") != nullptr;
+    if (debug) {
+        fprintf(stderr, "[sweep] %lld points, %d rows, %d CUs, %d blocks:", (long long)n_est, K, cus, total);
+        for (int k = 0; k < n_lv; ++k) fprintf(stderr, " L%d x%d (%.0f us)", lv[order[k]], parts[order[k]], c_l[order[k]]);
+        fprintf(stderr, "\n");
+    }
     return total;
 }
 
@@ -520,20 +486,23 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
             // the whole 128-byte row in eight 16-byte loads issued together, then the sixteen plane stores
             float4 r4[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) r4[q] = reinterpret_cast<const float4*>(rowf)[q];
+            for (int q = 0; q < 8; ++q)
+                if ((plan.swept >> (2 * q)) & 3u) r4[q] = reinterpret_cast<const float4*>(rowf)[q];          // (uniform)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
-                planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
+                if ((plan.swept >> (2 * q)) & 1u) planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
+                if ((plan.swept >> (2 * q + 1)) & 1u) planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
             }
         } else {
             const float2* __restrict__ row = reinterpret_cast<const float2*>(rowf);
-            for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = row[l];
+            for (int l = 0; l < n_levels; ++l)
+                if ((plan.swept >> l) & 1u) planes[(int64_t)l * slots + s] = row[l];
         }
         const int64_t px = src.perm ? src.perm[p] : p;
         xs[s] = src.x01[px * 3]; xs[slots + s] = src.x01[px * 3 + 1]; xs[2 * slots + s] = src.x01[px * 3 + 2];
     } else {
-        for (int l = 0; l < n_levels; ++l) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
+        for (int l = 0; l < n_levels; ++l)
+            if ((plan.swept >> l) & 1u) planes[(int64_t)l * slots + s] = make_float2(0.f, 0.f);
         xs[s] = 0.5f; xs[slots + s] = 0.5f; xs[2 * slots + s] = 0.5f;
     }
 }
@@ -1339,6 +1308,8 @@ static int launch_grid_scatter(const rfx_grid_desc& g, const float* table, const
     const size_t scratch_floats = scatter_scratch_floats(n_all, g.n_levels);
     if (total > 0) {
         plan.chunks = 1;
+        plan.swept = 0;
+        for (int l = 0; l < g.n_levels; ++l) if (!binned[l]) plan.swept |= 1u << l;
         plan.K = (int)((n + n_b + SCATTER_THREADS - 1) / SCATTER_THREADS);
         plan.slots = (int64_t)plan.K * SCATTER_THREADS;
         static int cus_of[64] = {};          // per device

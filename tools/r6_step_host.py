@@ -12,7 +12,11 @@ from remixfusion_amd.pipeline import MappingPipeline
 
 cfg = synthetic_config("office0")
 nf = int(os.environ.get("FRAMES", 46))
+if os.environ.get("NO_MV_STREAM"):
+    cfg.setdefault("pipeline", {})["mv_stream"] = False
 pipe = MappingPipeline(cfg, n_frames=nf + 8)
+if os.environ.get("NO_V1"):          # what the loop costs without the volume's work (an upper bound for any V1 speed-up)
+    pipe.mv.integrate = lambda *a, **k: None
 frames = pipe.prefetch(list(range(nf)))
 pipe.start(frames[0])
 lib = _lib.load()

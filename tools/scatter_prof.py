@@ -6,7 +6,8 @@ import numpy as np, torch
 from remixfusion_amd import _lib as L
 from remixfusion_amd.config import synthetic_config
 from remixfusion_amd.pipeline import MappingPipeline
-cfg = synthetic_config("office0"); cfg["mapping"]["first_iters"] = 20
+name = sys.argv[1] if len(sys.argv) > 1 else "office0"
+cfg = synthetic_config(name); cfg["mapping"]["first_iters"] = 20
 pipe = MappingPipeline(cfg, n_frames=40)
 frames = pipe.prefetch(list(range(32)))
 pipe.start(frames[0])
@@ -37,7 +38,7 @@ start = (a[:nb, 0] - t0) / 100.0                        # 100 MHz wall clock -> 
 dur = (a[:nb, 1] - a[:nb, 0]) / 100.0
 end = start + dur
 print("blocks", nb, "launch span", float(end.max()), "us; sum of block times", float(dur.sum()), "us =", float(dur.sum() / 256), "per CU")
-for lo in range(0, nb, 32):
-    m = slice(lo, min(nb, lo + 32))
+for lo in range(0, nb, 16):
+    m = slice(lo, min(nb, lo + 16))
     print(f"blocks {lo:4d}..: duration mean {dur[m].mean():6.1f} max {dur[m].max():6.1f}; start mean {start[m].mean():6.1f} max {start[m].max():6.1f}")
 print("blocks running at t =", " ".join(f"{t}us:{int(((start <= t) & (end > t)).sum())}" for t in range(0, 130, 10)))
