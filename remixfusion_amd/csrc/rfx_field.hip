@@ -312,7 +312,7 @@ __device__ __forceinline__ ScatterShare scatter_share(const ScatterPlan& p) {
 // 256 CUs, the dear blocks of the small dense levels starting at 43 us of a 120 us launch -- tools/scatter_prof.py).
 // One block per CU (128 KB of LDS) and a block costs fixed(level) + points * per_point(level):
 //   fixed      zeroing and flushing the segment's accumulators: ~12 us for a full 8 192-entry segment
-//   per_point  a hashed level cut into >= 8 segments (membership test first, few corners land): 0.65 ns;
+//   per_point  a hashed level cut into >= 8 segments (membership test first, few corners land): 0.7 ns;
 //              the other levels (every corner lands, same-cell runs merged in registers, same-address atomics): 1.2-1.6 ns
 // (measured with -DSCATTER_PROF on office0's 201 k points).  A block takes a RANGE OF ROWS of the staged points (row i = point
 // t K + i of every thread t: any range has the sources' mix), `parts` ranges per segment of its level -- at office0 2 parts for the
@@ -324,7 +324,7 @@ static SweepCost sweep_cost(const rfx_grid_desc& g, int l, unsigned seg_entries,
     c.cut = g.hashed[l] && g.size[l] >= (f64 ? 8u : 16u) * seg_entries;
     const double fill = (double)std::min(g.size[l], seg_entries) / seg_entries;
     c.fixed = 2.0 + 10.0 * fill;
-    c.per_point = (c.cut ? 0.65e-3 : n_seg == 1 ? 1.6e-3 : 1.2e-3) * (f64 ? 1.0 : 3.0);      // (ds_add_f32: tools/micro/lds_atomic)
+    c.per_point = (c.cut ? 0.7e-3 : n_seg == 1 ? 1.6e-3 : 1.2e-3) * (f64 ? 1.0 : 3.0);      // (ds_add_f32: tools/micro/lds_atomic)
     return c;
 }
 
@@ -485,13 +485,23 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
         if (n_levels == RFX_MAX_LEVELS && (src.ld & 3) == 0 && (((uintptr_t)src.dfeat) & 15) == 0) {
             // the whole 128-byte row in eight 16-byte loads issued together, then the sixteen plane stores
             float4 r4[8];
+            if (plan.swept == 0xFFFFu) {           // every level swept (T <= 2^16): straight-line, all loads in flight at once
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if ((plan.swept >> (2 * q)) & 3u) r4[q] = reinterpret_cast<const float4*>(rowf)[q];          // (uniform)
+                for (int q = 0; q < 8; ++q) r4[q] = reinterpret_cast<const float4*>(rowf)[q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if ((plan.swept >> (2 * q)) & 1u) planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
-                if ((plan.swept >> (2 * q + 1)) & 1u) planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
+                for (int q = 0; q < 8; ++q) {
+                    planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
+                    planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if ((plan.swept >> (2 * q)) & 3u) r4[q] = reinterpret_cast<const float4*>(rowf)[q];          // (uniform)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((plan.swept >> (2 * q)) & 1u) planes[(int64_t)(2 * q) * slots + s] = make_float2(r4[q].x, r4[q].y);
+                    if ((plan.swept >> (2 * q + 1)) & 1u) planes[(int64_t)(2 * q + 1) * slots + s] = make_float2(r4[q].z, r4[q].w);
+                }
             }
         } else {
             const float2* __restrict__ row = reinterpret_cast<const float2*>(rowf);
@@ -612,11 +622,32 @@ __global__ __launch_bounds__(SCATTER_THREADS) void grid_scatter_lds_kernel(rfx_g
                     const unsigned z0 = c.g[2] * 805459861u, z1 = z0 + 805459861u;
                     unsigned i0[4] = {(c.g[0] ^ y0 ^ z0) & msk, (c.g[0] ^ y1 ^ z0) & msk, (c.g[0] ^ y0 ^ z1) & msk, (c.g[0] ^ y1 ^ z1) & msk};
                     const unsigned xx = (c.g[0] ^ (c.g[0] + 1u)) & msk;            // partner index = i0 ^ xx
+                    const float fx0 = 1.0f - c.f[0], fx1 = c.f[0];
+                    if (__ballot((xx & ~(SEG - 1u)) != 0u) == 0ull) {
+                        // No lane's pair can straddle a segment boundary (x + 1 stays below the segment bits: every point inside
+                        // the unit cube): one test per pair instead of two, and a round's adds need none at all.  Same contributions.
+                        unsigned m = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) m |= ((i0[k] - base) < cnt ? 1u : 0u) << k;
+                        if (gv.x == 0.f && gv.y == 0.f) m = 0;
+                        while (__ballot(m != 0u)) {                                // wave-uniform
+                            const int k = __ffs((int)m) - 1;
+                            const unsigned ia = (k & 1) ? ((k & 2) ? i0[3] : i0[1]) : ((k & 2) ? i0[2] : i0[0]);
+                            const float wy = (k & 1) ? c.f[1] : 1.0f - c.f[1], wz = (k & 2) ? c.f[2] : 1.0f - c.f[2];
+                            if (m) {
+                                const unsigned ra = ia - base, rb = (ia ^ xx) - base;
+                                const float wa = (fx0 * wy) * wz, wb = (fx1 * wy) * wz;
+                                atomicAdd(&acc[2 * ra], (ACC)(wa * gv.x)); atomicAdd(&acc[2 * ra + 1], (ACC)(wa * gv.y));
+                                atomicAdd(&acc[2 * rb], (ACC)(wb * gv.x)); atomicAdd(&acc[2 * rb + 1], (ACC)(wb * gv.y));
+                            }
+                            m &= m - 1u;
+                        }
+                        continue;
+                    }
                     unsigned m = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) m |= (((i0[k] - base) < cnt || ((i0[k] ^ xx) - base) < cnt) ? 1u : 0u) << k;
                     if (gv.x == 0.f && gv.y == 0.f) m = 0;
-                    const float fx0 = 1.0f - c.f[0], fx1 = c.f[0];
                     while (__ballot(m != 0u)) {                                    // wave-uniform
                         const int k = __ffs((int)m) - 1;
                         const unsigned ia = (k & 1) ? ((k & 2) ? i0[3] : i0[1]) : ((k & 2) ? i0[2] : i0[0]);
