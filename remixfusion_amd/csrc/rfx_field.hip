@@ -522,8 +522,14 @@ __global__ __launch_bounds__(256) void scatter_stage_kernel(ScatterSrc a, Scatte
 // with doubles the atomics stop being the bound, but every point is visited by twice as many blocks, so the index
 // arithmetic doubles.  Measured (tools/time_scatter.py, merged ray + TV points): T = 2^16 0.23 -> 0.15 ms with doubles,
 // T = 2^19 0.93 -> 1.21 ms, T = 2^21 1.5 -> 2.6 ms: doubles are used while no level is cut into 16 or more float segments.
-#ifdef SCATTER_PROF      // dev builds only (tools/scatter_prof.py): start / end clock of every block of the last sweep
+#ifdef SCATTER_PROF      // dev builds only (tools/scatter_prof.py, tools/bin_prof.py): start / end clock of every block of the last sweep / sort / reduce
 __device__ unsigned long long g_scatter_prof[2 * 8192];
+__device__ unsigned long long g_bin_prof[2][2 * 8192];
+struct ProfStamp {       // thread 0's entry and exit (whichever return it takes)
+    unsigned long long* p;
+    __device__ explicit ProfStamp(unsigned long long* q) : p(q) { if (threadIdx.x == 0 && p) p[0] = wall_clock64(); }
+    __device__ ~ProfStamp() { if (threadIdx.x == 0 && p) p[1] = wall_clock64(); }
+};
 #endif
 
 template <typename ACC, unsigned SEG>
@@ -861,9 +867,14 @@ struct BinLevels {
 #define BIN_DENSE_FACTOR 4.0
 #endif
 #ifndef BIN_CHUNK_RECORDS
-#define BIN_CHUNK_RECORDS 16384
+#define BIN_CHUNK_RECORDS 32768
 #endif
-constexpr unsigned BIN_CHUNK = BIN_CHUNK_RECORDS;      // (pair) records one reduce block is meant to add (sets `parts`)
+// (pair) records one reduce block is meant to add (sets `parts`).  32 768 since the second session of round 6 (16 384 before): at
+// T = 2^19 a hashed level's 64 segments get ~33 k records each from a BA iteration's 530 k points -- ONE block per segment then: a
+// third of the blocks' fixed cost (zero + write-back of 128 KB) gone, plain read-modify-write instead of float atomics, and the
+// map phase's no-zero-fill / no-read-back form (scatter_overwrite_from_level: needs parts == 1) reaches scene0000's levels too:
+// 736 -> 760 frames/s there, nothing at T = 2^21 whose segments (8 k records each) had one block already (tools/r6_chunk_ab.sh)
+constexpr unsigned BIN_CHUNK = BIN_CHUNK_RECORDS;
 
 template <bool DENSE>
 __device__ __forceinline__ void bin_sort_body(const BinLevels& B, int g, const ScatterSrc& a, const ScatterSrc& b, unsigned* h, unsigned* wsum) {
@@ -1065,6 +1076,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_sort_kernel(BinLevels B, Scat
     __shared__ unsigned wsum[BIN_THREADS / 64];
     const int g = blockIdx.y;
     if ((int)blockIdx.x >= B.n_blk[g]) return;                          // (the grid is as wide as the level with the most sort blocks)
+#ifdef SCATTER_PROF
+    const unsigned prof_id = blockIdx.y * gridDim.x + blockIdx.x;
+    ProfStamp prof_stamp(prof_id < 8192 ? &g_bin_prof[0][2 * prof_id] : nullptr);
+#endif
     if (B.lv[g].hashed) bin_sort_body<false>(B, g, a, b, h, wsum);      // block-uniform
     else bin_sort_dense(B, g, a, b, h, wsum);
 }
@@ -1095,6 +1110,9 @@ __device__ __forceinline__ void bin_add(double* acc, const BinRec& q) {
 // round trip per run), then the runs are read BIN_RUNS at a time, 128 records of each, before any of them is added (a block's time is a chain of
 // round trips: 16 waves, one block per CU).
 __global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, float* __restrict__ dtable) {
+#ifdef SCATTER_PROF
+    ProfStamp prof_stamp(blockIdx.x < 8192 ? &g_bin_prof[1][2 * blockIdx.x] : nullptr);
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];
     double* acc = reinterpret_cast<double*>(acc_raw);
     int g = 0;
@@ -2212,6 +2230,11 @@ int rfx_grid_encode_backward(const rfx_grid_desc* g, const float* table, const f
 #ifdef SCATTER_PROF
 extern "C" int rfx_debug_scatter_prof(unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scatter_prof), sizeof(unsigned long long) * (size_t)std::min(n, 2 * 8192)) == hipSuccess ? 0 : -2;
+}
+// which: 0 = bin_sort (block = blockIdx.y * gridDim.x + blockIdx.x), 1 = bin_reduce
+extern "C" int rfx_debug_bin_prof(int which, unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_prof), sizeof(unsigned long long) * (size_t)std::min(n, 2 * 8192),
+                               sizeof(unsigned long long) * 2 * 8192 * (size_t)(which ? 1 : 0)) == hipSuccess ? 0 : -2;
 }
 #endif
 
