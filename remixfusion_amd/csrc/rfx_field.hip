@@ -1228,9 +1228,16 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_reduce_kernel(BinLevels B, fl
     }
 }
 
+// a DENSE level is binned from 8 segments on: every corner of every point lands in its sweep blocks (2.7 ns per point and
+// segment at scene0000, the lattice's points piling onto the coarse cells, against 0.7 ns on a cut hashed level), so its
+// share of the sweep outgrows a binned level's cost earlier (scene0000's 10-segment level: merged scatter 559 -> 544 us; 5: the
+// same; 3: 570; cafeteria / apartment have no such level)
+#ifndef SCATTER_BIN_MIN_SEGMENTS_DENSE
+#define SCATTER_BIN_MIN_SEGMENTS_DENSE 8
+#endif
 static bool level_is_binned(const rfx_grid_desc& g, int l) {
     const unsigned segs = (g.size[l] + BIN_SEG - 1) / BIN_SEG;
-    return segs >= (unsigned)SCATTER_BIN_MIN_SEGMENTS && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
+    return segs >= (unsigned)(g.hashed[l] ? SCATTER_BIN_MIN_SEGMENTS : SCATTER_BIN_MIN_SEGMENTS_DENSE) && segs <= (unsigned)SCATTER_BIN_MAX_SEGMENTS;
 }
 
 static inline size_t bin_sort_blocks(int64_t n_all, bool hashed) {
