@@ -339,9 +339,9 @@ def field_rooflines(summ, cfg, merged_scatter=True):
         nbytes = pts * (12 + 128 + 1024)
         ach = nbytes / (ms * 1e-3) / 1e9
         f64 = cfg["grid"]["hash_size"] <= 17
-        binned = cfg["grid"]["hash_size"] >= 19         # levels of >= 12 segments of 8 192 entries exist (csrc/rfx_field.hip: level_is_binned)
+        binned = cfg["grid"]["hash_size"] >= 19         # levels of >= 12 (dense: 8) segments of 8 192 entries exist (csrc/rfx_field.hip: level_is_binned)
         out["field_backward_scatter"] = {
-            "kernel": (f"scatter_stage_kernel + grid_scatter_lds_kernel (levels below 12 segments) + bin_sort_kernel + bin_reduce_kernel (the binned levels) ({scat})"
+            "kernel": (f"scatter_stage_kernel + grid_scatter_lds_kernel (the levels of few segments) + bin_sort_kernel + bin_reduce_kernel (the binned levels) ({scat})"
                        if binned else f"scatter_stage_kernel + grid_scatter_lds_kernel ({scat})"),
             "bound": "hbm", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -352,8 +352,9 @@ def field_rooflines(summ, cfg, merged_scatter=True):
                      "segment back (bin_reduce): the records -- 64 B per point and level written and read once -- are the traffic, "
                      "moved at 2.3-3.4 TB/s (profiles/r6_notes.md)" if binned else
                      "LDS-privatised: corner sums accumulate in 128 KB of LDS per table segment (double accumulators over "
-                     "8 192 entries at T <= 2^17, float over 16 384 above), then one contiguous global atomic per "
-                     "non-zero entry; bound by LDS atomics / index arithmetic, not HBM"),
+                     "8 192 entries), then one contiguous global atomic per non-zero entry; a block = (segment, range of the "
+                     "staged rows), the parts per level chosen so that all blocks are resident at once, dearest first (round 6); "
+                     "bound by the walk's index arithmetic (every hashed level is walked once per segment), not HBM"),
             # algorithmic adds = points x 16 levels x 8 corners x 2 features, priced against the LDS atomic of the
             # accumulator type this table size uses (tools/micro/lds_atomic.hip: a full-wave ds_add_f64 retires in 19
             # clocks per CU, ds_add_f32 in 169; x 256 CUs x 2.4 GHz)

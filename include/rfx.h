@@ -232,7 +232,7 @@ int rfx_grid_encode_forward(const rfx_grid_desc* g, const float* table, const fl
  * workspace (optional, dev, >= rfx_grid_encode_backward_workspace_bytes): enables the LDS-privatised
  * scatter (per-segment accumulation in LDS, contiguous flush); NULL = direct atomics. */
 size_t rfx_grid_encode_backward_workspace_bytes(int64_t n, int n_levels);
-/* The size that lets the scatter keep ALL binned levels of grid `g` (levels of >= 12 segments of 8 192 entries) in flight at
+/* The size that lets the scatter keep ALL binned levels of grid `g` (levels of >= 12 segments of 8 192 entries; dense levels from 8) in flight at
  * once -- four launches per sweep instead of four per level; with the minimum above they go one level at a time.  Any size
  * in between is used for as many levels per group as fit.  Equals the minimum for grids without binned levels. (ABI 5) */
 size_t rfx_grid_encode_backward_workspace_bytes_for(const rfx_grid_desc* g, int64_t n);
