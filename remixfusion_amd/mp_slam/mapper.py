@@ -220,9 +220,10 @@ class Mapper:
         self.rba_optimizer.zero_grad()
         current_rays = self._current_rays(batch)
         with torch.no_grad():
-            last_kf_id = torch.full((1, 1), cur_frame_id // m["keyframe_every"], dtype=torch.int64, device=self.device)
+            k_last = cur_frame_id // m["keyframe_every"]
+            last_kf_id = self._camera_ids(k_last + 1)[k_last:]          # [[k_last]]: a view, no fill launch
             poses_all = poses
-            poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze().clone()
+            poses_all[-1, :, :] = self.model.rba(last_kf_id).squeeze()   # (the assignment is the copy)
         direct = self._direct_iterations()
         if direct is not None:          # same kernels and random draws, launched without an autograd graph
             for i in range(m["iters"]):
@@ -242,12 +243,12 @@ class Mapper:
     def global_pose(self, batch, cur_frame_id):
         """pose (RBA-MLP) update with the map frozen (reference :425-520)."""
         m = self.config["mapping"]
-        poses = self.est_c2w_data[0:cur_frame_id:m["keyframe_every"]].clone()
+        n_kf = len(range(0, cur_frame_id, m["keyframe_every"]))          # poses = est_c2w_data[0:cur_frame_id:keyframe_every]
         frame_ids_all = list(range(0, cur_frame_id + 1, m["keyframe_every"]))
         self.map_optimizer.zero_grad()
         self.rba_optimizer.zero_grad()
         current_rays = self._current_rays(batch)
-        all_index = torch.arange(0, poses.shape[0] + 1, device=self.device).unsqueeze(-1)
+        all_index = self._camera_ids(n_kf + 1)                          # arange(0, n_kf + 1)[:, None], cached
         direct = self._direct_iterations() if m["opt_pose"] else None
         if direct is not None:
             idx = all_index.reshape(-1).contiguous()
@@ -274,14 +275,24 @@ class Mapper:
                 self.rba_optimizer.zero_grad()
         self._write_back_poses(poses_all, frame_ids_all, cur_frame_id)
 
+    def _camera_ids(self, n):
+        """arange(0, n)[:, None] on the device: a view of one cached tensor (the reference builds it, and the `kfupid` list below,
+        with two or three tiny launches per mapper step)"""
+        c = getattr(self, "_cam_ids", None)
+        if c is None or c.shape[0] < n:
+            c = self._cam_ids = torch.arange(0, max(n, 64), device=self.device).unsqueeze(-1)
+        return c[:n]
+
     def _write_back_poses(self, poses_all, frame_ids_all, cur_frame_id):
         """refined keyframe poses -> est_c2w_data (reference :507-520)."""
         m = self.config["mapping"]
         if len(frame_ids_all) > 1 and m["opt_pose"]:
-            kfupid = torch.arange(len(frame_ids_all) - 1, device=self.device) * m["keyframe_every"]
+            n = len(frame_ids_all) - 1
+            ke = m["keyframe_every"]
             if m["optim_cur"]:
-                self.est_c2w_data[cur_frame_id] = poses_all[-1:].detach().clone()[0]
-            self.est_c2w_data[kfupid] = poses_all[:-1].detach().clone()
+                self.est_c2w_data[cur_frame_id] = poses_all[-1].detach()
+            # est_c2w_data[arange(n) * keyframe_every] = poses_all[:-1]: the index list is a stride -- one strided copy
+            self.est_c2w_data[0:(n - 1) * ke + 1:ke] = poses_all[:-1].detach()
 
     def _direct_iterations(self):
         """graph-free issue of the BA iterations (mp_slam/direct.py) when the configuration allows it."""
