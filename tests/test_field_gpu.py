@@ -278,6 +278,39 @@ def test_grid_encode_backward_standalone(name, n):
     _grad_close(xg.grad, xo.grad, xq.grad, "dx", k=8.0)
 
 
+@pytest.mark.parametrize("name,n", [("office0", 6000), ("scene0000", 5000)])
+def test_grid_encode_backward_far_outside_the_cube(name, n):
+    """points up to twelve cube lengths outside, and some as far out as it takes for the cell's x + 1 to reach the segment bits
+    of the fine hashed levels, so that the two corners of an x-pair can fall into different table segments -- the sweep's per-corner fallback (the wave-uniform fast path
+    tests one corner per pair; round 6) and the binned sort's one-corner records; dense levels wrap modulo their size.  Few rows
+    per thread as well (n / 1 024 = 5-6: fewer than some levels' parts)."""
+    cfg, m = _model(name, gbv_fill=False)
+    fp = _oracle_params(cfg, m)
+    x = _points(n, seed=12, lo=-1.0, hi=12.0)
+    x[: n // 2] = _points(n // 2, seed=13, lo=0.0, hi=1.0)      # half of them inside: the waves mix both kinds
+    # ... and, for every level fine enough, forty points whose cell is x = 8 191 exactly: x + 1 = 8 192 is the first segment bit
+    desc = m.embed_res_fn.desc
+    k = n // 2
+    for l in range(int(desc.n_levels)):
+        sc = float(desc.scale[l])
+        xs = (8191.3 - 0.5) / sc
+        if int(desc.hashed[l]) and xs < 80.0:          # (25-70 cube lengths out at office0 sizes: only a fallback ever sees them)
+            x[k:k + 40, 0] = xs
+            k += 40
+    assert k > n // 2 + 80, "no level fine enough to straddle: the test would not reach the fallback"
+    x = x[torch.randperm(n, generator=torch.Generator().manual_seed(14))].contiguous()
+    g = torch.Generator().manual_seed(15)
+    dy = torch.randn((n, 32), generator=g)
+    fp.hash_table.requires_grad_(True)
+    FO.grid_encode(x.clone(), fp.hash_table, fp.hash_meta).backward(dy)
+    t64 = fp.hash_table.detach().double().requires_grad_(True)
+    FO.grid_encode(x.clone(), t64, fp.hash_meta).backward(dy.double())
+    xg = x.cuda().requires_grad_(True)
+    m.embed_res_fn.params.grad = None
+    m.embed_res_fn(xg).backward(dy.cuda())
+    _grad_close(m.embed_res_fn.params.grad, fp.hash_table.grad, t64.grad, "dtable", _level_groups(fp.hash_meta))
+
+
 @pytest.mark.parametrize("name", ["scene0000", "cafeteria"])
 def test_binned_scatter_is_the_same_one_level_or_all_levels_at_a_time(name):
     """T >= 2^19: the binned levels go through their four kernels in groups as large as the workspace allows --
