@@ -257,6 +257,35 @@ def test_field_backward_matches_autograd_of_oracle(clamp, n):
     assert m.GBV.params.grad is None
 
 
+def test_field_backward_with_few_rows_that_carry_a_gradient():
+    """40 001 points of which 600 have a non-zero d_raw: the backward selects those rows on the device (n_sel), so the table
+    scatter's sweep -- planned on the host for ~0.65 n rows, 40 staged rows per thread -- finds ONE staged row: most of its
+    (segment, part) blocks get no rows at all and must leave their segment untouched.  Against autograd through the oracle."""
+    n = 40001
+    cfg, m = _model(hash_scale=0.5)
+    fp = _oracle_params(cfg, m)
+    x = _points(n, seed=21, lo=0.02, hi=0.98)
+    g = torch.Generator().manual_seed(22)
+    draw = torch.zeros((n, 4))
+    rows = torch.randperm(n, generator=g)[:600]
+    draw[rows] = torch.randn((600, 4), generator=g)
+    for t in (fp.hash_table, fp.W1, fp.W2, fp.W3, fp.W4):
+        t.requires_grad_(True)
+    FO.query_color_sdf(fp, x.clone(), False).backward(draw)
+    m.clamp = False
+    for p in m.parameters():
+        p.grad = None
+    m.query_color_sdf(x.cuda()).backward(draw.cuda())
+    fq = _f64_params(fp)
+    FO.query_color_sdf(fq, x.clone(), False).backward(draw.double())
+    w1, w2, w3, w4 = m.decoder_res.fused_weights()
+    for got, r32, r64, nm in ((w1.grad, fp.W1.grad, fq.W1.grad, "dW1"), (w2.grad, fp.W2.grad, fq.W2.grad, "dW2"),
+                              (w3.grad, fp.W3.grad, fq.W3.grad, "dW3"), (w4.grad, fp.W4.grad, fq.W4.grad, "dW4")):
+        _grad_close(got, r32, r64, nm)
+    _grad_close(m.embed_res_fn.params.grad, fp.hash_table.grad, fq.hash_table.grad, "d_hash", _level_groups(fp.hash_meta))
+    assert float((m.embed_res_fn.params.grad != 0).float().sum()) > 600
+
+
 @pytest.mark.parametrize("name,n", [("office0", 2000), ("office0", 12000), ("scene0000", 12000), ("cafeteria", 9000)])
 def test_grid_encode_backward_standalone(name, n):
     """n < 4096: direct atomics; n >= 4096: LDS-privatised scatter (T = 2^16: <= 4 segments / level, 2^19: 32, 2^21: 128)."""
