@@ -272,9 +272,26 @@ __global__ __launch_bounds__(256) void rba_wgrad_kernel(const float* __restrict_
     if (!out) return;
     const int i = e / n_in, jj = e - i * n_in;
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float gp = grads[(size_t)k * RBA_GRAD_LD + g_off + i];
-        acc = bias ? acc + gp : fmaf(gp, acts[(size_t)k * RBA_ACT_LD + a_off + jj], acc);
+    // The sum runs over the cameras in order (deterministic), one L2 round trip per camera when the loads are issued one by
+    // one: 57 us at 190 keyframes (4.8 at 5) -- a long stream's pose iteration grew by a fifth.  Sixteen cameras' loads are
+    // issued together, then added in the same order: the same sums, 57 -> ~8 us at 190.
+    constexpr int UB = 16;
+    const float* __restrict__ gq = grads + g_off + i;
+    const float* __restrict__ aq = acts + a_off + jj;
+    int k = 0;
+    for (; k + UB <= K; k += UB) {
+        float gv[UB], av[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            gv[u] = gq[(size_t)(k + u) * RBA_GRAD_LD];
+            av[u] = bias ? 1.0f : aq[(size_t)(k + u) * RBA_ACT_LD];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = bias ? acc + gv[u] : fmaf(gv[u], av[u], acc);
+    }
+    for (; k < K; ++k) {
+        const float gp = gq[(size_t)k * RBA_GRAD_LD];
+        acc = bias ? acc + gp : fmaf(gp, aq[(size_t)k * RBA_ACT_LD], acc);
     }
     out[e] = acc;
 }
