@@ -5,7 +5,7 @@
 // K (keyframes) is small -- tens to a few hundred -- so the work is latency, not throughput:
 //   P1 rba_forward_kernel   block = camera, thread = hidden unit; activations kept for the backward
 //   P2 rba_backward_kernel  block = camera: dL/dpose -> dL/d(axis-angle, t) -> pre-activation grads
-//   P3 rba_wgrad_kernel     thread = parameter element, loops over the cameras (deterministic sums)
+//   P3 rba_wgrad_kernel     block = 8 rows of a layer, thread = column, cameras in order (deterministic sums)
 #include "rfx_common.h"
 
 namespace rfx {
@@ -251,49 +251,76 @@ __global__ __launch_bounds__(RBA_H) void rba_backward_kernel(RbaW W, const float
     g[j] = v;                                        // dP1
 }
 
-// parameter gradients, overwritten: element e of the concatenation [w0 | b0 | w1 | b1 | w2 | b2 | w3 | b3]
+// parameter gradients, overwritten:  dW_l[i][j] = sum_k dP_l[k][i] * in_l[k][j],  db_l[i] = sum_k dP_l[k][i],  k over the cameras IN
+// ORDER (deterministic, and the same sums whatever the tiling).
+// Rounds 2-6 ran one thread per parameter element with a loop over the cameras: two loads per camera and element, 133 k threads --
+// 4.8 us at 5 keyframes, 57 us at 190, 110+ at 380: a long stream's pose iteration grew by half (profiles/r6_notes.md 7.5).
+// Now a block owns WG_TI rows i of one layer and all its columns j (thread = column): per camera ONE coalesced load of the layer's
+// input row (WG_UB cameras' loads in flight, the next batch's issued before this one is added) and the WG_TI pre-activation
+// gradients from an LDS panel the block fetched WG_KC cameras at a time -- a fraction of the loads, a round trip per 32 cameras.
+// Rows of the panel beyond K are zero: fmaf(0, a, acc) == acc, so no tail handling, and the sums are the element-per-thread
+// loop's bit for bit.
+constexpr int WG_TI = 4, WG_KC = 128, WG_UB = 32;
+constexpr int WG_TILES_H = RBA_H / WG_TI;                       // row tiles of a 256-row layer
+constexpr int WG_TILES_OUT = (RBA_OUT + WG_TI - 1) / WG_TI;     // ... of the 6-row output layer
+constexpr int WG_BLOCKS = 3 * WG_TILES_H + WG_TILES_OUT;        // w0, w1, w2, then w3
+static_assert(WG_TI == 4 && RBA_H % WG_TI == 0 && WG_KC % WG_UB == 0 && WG_KC * WG_TI % 256 == 0, "rba_wgrad tiling (a panel row is one float4)");
+
 __global__ __launch_bounds__(256) void rba_wgrad_kernel(const float* __restrict__ acts, const float* __restrict__ grads, int K,
                                                         RbaG G) {
-    constexpr int N0 = RBA_H * RBA_IN, N1 = RBA_H * RBA_H, N3 = RBA_OUT * RBA_H;
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    int g_off, a_off, ld_in, n_in;       // column of the pre-activation grad block, of the input activation block
-    float* out;
-    bool bias = false;
-    if (e < N0) { g_off = 0; a_off = 0; n_in = RBA_IN; out = G.w0; }
-    else if ((e -= N0) < RBA_H) { g_off = 0; a_off = 0; n_in = 1; out = G.b0; bias = true; }
-    else if ((e -= RBA_H) < N1) { g_off = RBA_H; a_off = 8; n_in = RBA_H; out = G.w1; }
-    else if ((e -= N1) < RBA_H) { g_off = RBA_H; a_off = 0; n_in = 1; out = G.b1; bias = true; }
-    else if ((e -= RBA_H) < N1) { g_off = 2 * RBA_H; a_off = 8 + RBA_H; n_in = RBA_H; out = G.w2; }
-    else if ((e -= N1) < RBA_H) { g_off = 2 * RBA_H; a_off = 0; n_in = 1; out = G.b2; bias = true; }
-    else if ((e -= RBA_H) < N3) { g_off = 3 * RBA_H; a_off = 8 + 2 * RBA_H; n_in = RBA_H; out = G.w3; }
-    else if ((e -= N3) < RBA_OUT) { g_off = 3 * RBA_H; a_off = 0; n_in = 1; out = G.b3; bias = true; }
-    else return;
-    (void)ld_in;
-    if (!out) return;
-    const int i = e / n_in, jj = e - i * n_in;
-    float acc = 0.f;
-    // The sum runs over the cameras in order (deterministic), one L2 round trip per camera when the loads are issued one by
-    // one: 57 us at 190 keyframes (4.8 at 5) -- a long stream's pose iteration grew by a fifth.  Sixteen cameras' loads are
-    // issued together, then added in the same order: the same sums, 57 -> ~8 us at 190.
-    constexpr int UB = 16;
-    const float* __restrict__ gq = grads + g_off + i;
-    const float* __restrict__ aq = acts + a_off + jj;
-    int k = 0;
-    for (; k + UB <= K; k += UB) {
-        float gv[UB], av[UB];
+    __shared__ __attribute__((aligned(16))) float gs[WG_KC][WG_TI];
+    const int layer = min((int)blockIdx.x / WG_TILES_H, 3), tile = (int)blockIdx.x - layer * WG_TILES_H;      // (w3's tiles: 0, 1)
+    const int rows = layer == 3 ? RBA_OUT : RBA_H;
+    const int n_in = layer == 0 ? RBA_IN : RBA_H;
+    const int g_off = layer * RBA_H;                              // dP1 | dP2 | dP3 | dout
+    const int a_off = layer == 0 ? 0 : 8 + (layer - 1) * RBA_H;   // inp[8] | H1 | H2 | H3
+    float* __restrict__ out_w = layer == 0 ? G.w0 : layer == 1 ? G.w1 : layer == 2 ? G.w2 : G.w3;
+    float* __restrict__ out_b = layer == 0 ? G.b0 : layer == 1 ? G.b1 : layer == 2 ? G.b2 : G.b3;
+    const int i0 = tile * WG_TI, t = threadIdx.x;
+    const bool active = t < n_in;
+    const float* __restrict__ aq = acts + a_off + (active ? t : 0);
+    float acc[WG_TI], bacc[WG_TI];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            gv[u] = gq[(size_t)(k + u) * RBA_GRAD_LD];
-            av[u] = bias ? 1.0f : aq[(size_t)(k + u) * RBA_ACT_LD];
+    for (int r = 0; r < WG_TI; ++r) { acc[r] = 0.f; bacc[r] = 0.f; }
+    for (int kc = 0; kc < K; kc += WG_KC) {
+        const int nk = min(WG_KC, K - kc);
+#pragma unroll
+        for (int q = 0; q < WG_KC * WG_TI / 256; ++q) {
+            const int idx = t + q * 256, k = idx / WG_TI, r = idx % WG_TI;
+            const bool ok = k < nk && i0 + r < rows;
+            const float g = grads[(size_t)(kc + min(k, nk - 1)) * RBA_GRAD_LD + g_off + min(i0 + r, rows - 1)];      // (unconditional load)
+            gs[k][r] = ok ? g : 0.f;
         }
+        __syncthreads();
+        float av[WG_UB], an[WG_UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) acc = bias ? acc + gv[u] : fmaf(gv[u], av[u], acc);
+        for (int u = 0; u < WG_UB; ++u) av[u] = aq[(size_t)min(kc + u, K - 1) * RBA_ACT_LD];
+        for (int k0 = 0; k0 < nk; k0 += WG_UB) {
+            const bool more = k0 + WG_UB < nk;                    // block-uniform
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < WG_UB; ++u) an[u] = aq[(size_t)min(kc + k0 + WG_UB + u, K - 1) * RBA_ACT_LD];
+            }
+#pragma unroll
+            for (int u = 0; u < WG_UB; ++u) {
+                const float4 g = *reinterpret_cast<const float4*>(&gs[k0 + u][0]);
+                const float gr[WG_TI] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int r = 0; r < WG_TI; ++r) { acc[r] = fmaf(gr[r], av[u], acc[r]); bacc[r] += gr[r]; }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < WG_UB; ++u) av[u] = an[u];
+            }
+        }
+        __syncthreads();
     }
-    for (; k < K; ++k) {
-        const float gp = gq[(size_t)k * RBA_GRAD_LD];
-        acc = bias ? acc + gp : fmaf(gp, aq[(size_t)k * RBA_ACT_LD], acc);
+#pragma unroll
+    for (int r = 0; r < WG_TI; ++r) {
+        if (i0 + r >= rows) break;
+        if (active && out_w) out_w[(size_t)(i0 + r) * n_in + t] = acc[r];
+        if (t == 0 && out_b) out_b[i0 + r] = bacc[r];
     }
-    out[e] = acc;
 }
 
 // ---- the tail of a pose iteration in ONE launch: d rays -> d poses -> pose-MLP backward ------------------------------------
@@ -441,8 +468,7 @@ int pose_chain_backward(const float* dx01, const float* z_vals, const float* d_c
                        workspace, dposes16);
     RFX_LAUNCH_CHECK();
     RbaG G{gr->w0, gr->b0, gr->w1, gr->b1, gr->w2, gr->b2, gr->w3, gr->b3};
-    const int total = RBA_H * RBA_IN + RBA_H + 2 * (RBA_H * RBA_H + RBA_H) + RBA_OUT * RBA_H + RBA_OUT;
-    hipLaunchKernelGGL(rba_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), acts, workspace, K, G);
+    hipLaunchKernelGGL(rba_wgrad_kernel, dim3(WG_BLOCKS), dim3(256), 0, as_stream(stream), acts, workspace, K, G);
     RFX_LAUNCH_CHECK();
     *done = 1;
     return RFX_OK;
@@ -498,8 +524,7 @@ int rfx_rba_backward(const rfx_rba_params* p, const float* acts, int64_t K, cons
                        workspace);
     RFX_LAUNCH_CHECK();
     RbaG G{g->w0, g->b0, g->w1, g->b1, g->w2, g->b2, g->w3, g->b3};
-    const int total = RBA_H * RBA_IN + RBA_H + 2 * (RBA_H * RBA_H + RBA_H) + RBA_OUT * RBA_H + RBA_OUT;
-    hipLaunchKernelGGL(rba_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), acts, workspace, (int)K, G);
+    hipLaunchKernelGGL(rba_wgrad_kernel, dim3(WG_BLOCKS), dim3(256), 0, as_stream(stream), acts, workspace, (int)K, G);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
