@@ -10,7 +10,7 @@ from remixfusion_amd import _lib
 from remixfusion_amd.config import synthetic_config
 from remixfusion_amd.pipeline import MappingPipeline
 
-cfg = synthetic_config("office0")
+cfg = synthetic_config(os.environ.get("CONFIG", "office0"))
 nf = int(os.environ.get("FRAMES", 46))
 if os.environ.get("NO_MV_STREAM"):
     cfg.setdefault("pipeline", {})["mv_stream"] = False
