@@ -155,6 +155,23 @@ class DirectIterations:
         self._count += 1
         return self.stagewise_every > 0 and self._count % self.stagewise_every == 0
 
+    def prepare(self):
+        """allocate and fill in, ahead of the first iteration, what the first iteration of each phase would on its way: the
+        buffers at their capacity, both phases' descriptors, the pose MLP's gradient buffers, the optimizers' state
+        (Mapper._prepare_steps: the first mapper step of a stream then costs the host what every later one does)."""
+        enc = self.model.embed_res_fn
+        dev = enc.params.device
+        if dev.type != "cuda":
+            return
+        B = self._buffers(1, 1, dev)                      # capacity: most rays an iteration can have, all cameras
+        for clamp in (False, True):
+            self._descriptor(B, clamp, dev)
+        self.model._loss_weights(dev)
+        self._rba_grad_buffers()
+        for opt in (self.mp.map_optimizer, self.mp.rba_optimizer):
+            if hasattr(opt, "prepare"):
+                opt.prepare()
+
     @staticmethod
     def supported(mapper) -> bool:
         m, tr = mapper.config["mapping"], mapper.config["training"]
@@ -400,6 +417,14 @@ class DirectIterations:
         self._drop_grads()
         return lc
 
+    def _rba_grad_buffers(self):
+        params = self._rba_params
+        if self._rba_grads is None or self._rba_grads[0] != params[0].data_ptr():
+            grads = [torch.empty_like(w) for w in params]      # overwritten by every rfx_rba_backward
+            self._rba_grads = (params[0].data_ptr(), grads, _lib.RbaParams(*[w.data_ptr() for w in params], 256),
+                               _lib.RbaGrads(*[g.data_ptr() for g in grads]))
+        return self._rba_grads
+
     def _drop_grads(self):
         """map_optimizer.zero_grad() + rba_optimizer.zero_grad() (set_to_none) for the parameters these iterations touch"""
         self.model.embed_res_fn.params.grad = None
@@ -421,11 +446,7 @@ class DirectIterations:
         R = self._buffers(self._n_rays(), K, dev)     # owns the RBA buffers in both modes
         p = R.p
         params = self._rba_params
-        if self._rba_grads is None or self._rba_grads[0] != params[0].data_ptr():
-            grads = [torch.empty_like(w) for w in params]      # overwritten by every rfx_rba_backward
-            self._rba_grads = (params[0].data_ptr(), grads, _lib.RbaParams(*[w.data_ptr() for w in params], 256),
-                               _lib.RbaGrads(*[g.data_ptr() for g in grads]))
-        _, grads, prm, gdesc = self._rba_grads
+        _, grads, prm, gdesc = self._rba_grad_buffers()
         check(lib.rfx_rba_forward(C.byref(prm), rba.init_r.data_ptr(), rba.init_t.data_ptr(), idx.data_ptr(), K, rba.num_cams,
                                   float(rba.scale), p.poses, p.acts, st), "rfx_rba_forward")
         if self._stagewise_now():

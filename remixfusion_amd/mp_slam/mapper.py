@@ -172,7 +172,22 @@ class Mapper:
             self.map_optimizer.step()
         self.keyframe.add_keyframe(batch, filter_depth=self.config["mapping"]["filter_depth"])
         self.mapping_first_frame[0] = 1
+        self._prepare_steps()
         return ret, loss
+
+    def _prepare_steps(self):
+        """what the FIRST mapper step would otherwise set up on its way (0.5-0.8 ms of host time with nothing queued on the GPU
+        yet -- the step's kernels wait for it): the no-op `model.to(device)` of the loop's first pass (reference :884-890), the
+        direct iterations' buffers, descriptors and optimizer state.  Nothing here changes a result."""
+        if self.first_BA:
+            self.model = self.model.to(self.device)
+            self.first_BA = False
+        try:
+            direct = self._direct_iterations()
+        except Exception:      # noqa: BLE001 -- e.g. a scene shard that is attached later: the first step sets it up as before
+            direct = None
+        if direct is not None and hasattr(direct, "prepare"):
+            direct.prepare()
 
     def _sample_rays(self, current_rays):
         m = self.config["mapping"]

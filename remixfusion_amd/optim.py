@@ -51,6 +51,25 @@ class Adam(torch.optim.Adam):
                     return False
         return True
 
+    def prepare(self):
+        """create the state of every parameter now (zeros, step 0: what the first step() would create on its way) -- a stream's
+        first mapper step then issues its optimizer steps as fast as every later one.  Parameters the native step cannot take
+        (CPU tensors, other dtypes) are left to torch's own lazy initialisation."""
+        for g in self.param_groups:
+            if g.get("amsgrad") or g.get("capturable") or g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
+                continue
+            for p in g["params"]:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.requires_grad):
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                stp = st["step"]
+                if not stp.is_cuda and stp.dtype == torch.float32 and p not in self._views:
+                    self._views[p] = (stp, stp.numpy())
+
     def step(self, closure=None):
         if self._hooked():
             return torch.optim.Optimizer.profile_hook_step(type(self)._step_impl)(self, closure)

@@ -14,6 +14,13 @@ cfg = synthetic_config(os.environ.get("CONFIG", "office0"))
 nf = int(os.environ.get("FRAMES", 46))
 if os.environ.get("NO_MV_STREAM"):
     cfg.setdefault("pipeline", {})["mv_stream"] = False
+if os.environ.get("WARM"):            # bench.py's process warm-up: a throwaway pipeline of the same configuration first
+    import copy, gc
+    w = copy.deepcopy(cfg); w["mapping"]["first_iters"] = 4
+    wp = MappingPipeline(w, n_frames=20, seed=1000)
+    wf = wp.prefetch(list(range(12))); wp.start(wf[0])
+    for i in range(1, 12): wp.step(i, wf[i])
+    torch.cuda.synchronize(); del wp, wf; gc.collect()
 pipe = MappingPipeline(cfg, n_frames=nf + 8)
 if os.environ.get("NO_V1"):          # what the loop costs without the volume's work (an upper bound for any V1 speed-up)
     pipe.mv.integrate = lambda *a, **k: None
@@ -63,6 +70,7 @@ def wrap(fn):
         t0 = time.perf_counter()
         r = fn(*a)
         cur["its"].append(time.perf_counter() - t0)
+        if os.environ.get("ITS"): cur.setdefault("its_list", []).append(round(1e6 * (time.perf_counter() - t0)))
         cur["e_last"] = ev(); hip.hipEventRecord(cur["e_last"], st); cur["t_last"] = time.perf_counter()
         return r
     return f
@@ -91,4 +99,4 @@ print("step: host preamble / iterations(sum, max) / tail us | gpu preamble / ite
 for k, s in enumerate(log):
     nxt = el(s["e_out"], log[k + 1]["e_in"]) if k + 1 < len(log) else float("nan")
     print(f"  {k:2d}: host {1e6 * (s['t_first'] - s['t_in']):7.0f} / {1e6 * sum(s['its']):7.0f} {1e6 * max(s['its']):5.0f} / {1e6 * (s['t_out'] - s['t_last']):6.0f}"
-          f" | gpu {el(s['e_in'], s['e_first']):7.0f} / {el(s['e_first'], s['e_last']):7.0f} / {el(s['e_last'], s['e_out']):6.0f} | {nxt:7.0f}")
+          f" | gpu {el(s['e_in'], s['e_first']):7.0f} / {el(s['e_first'], s['e_last']):7.0f} / {el(s['e_last'], s['e_out']):6.0f} | {nxt:7.0f}" + (f"  its {s.get('its_list')}" if os.environ.get("ITS") else ""))
