@@ -33,3 +33,12 @@ for f in (6, 11):
     t0 = time.perf_counter(); pipe.step(f, frames[f]); print(f"frame {f}: host {1e3 * (time.perf_counter() - t0):.3f} ms")
     for i in range(f + 1, f + 5): pipe.step(i, frames[i])
     torch.cuda.synchronize()
+mp2 = pipe.mapper
+for label, fn in (("map_optimizer.zero_grad()", lambda: mp2.map_optimizer.zero_grad()), ("rba_optimizer.zero_grad()", lambda: mp2.rba_optimizer.zero_grad()),
+                  ("dataset[30]", lambda: mp2.dataset[30]), ("_current_rays", lambda: mp2._current_rays({k: (v[None, ...] if isinstance(v, torch.Tensor) else torch.tensor([v])) for k, v in mp2.dataset[30].items()})),
+                  ("est clone", lambda: mp2.est_c2w_data[0:31:5].clone()), ("rba(last)", lambda: mp2.model.rba(mp2._camera_ids(7)[6:])),
+                  ("integrate_kf", lambda: mp2.integrate_kf({k: (v[None, ...] if isinstance(v, torch.Tensor) else torch.tensor([v])) for k, v in mp2.dataset[30].items()}, mp2.est_c2w_data[30]))):
+    for _ in range(3): fn()
+    t0 = time.perf_counter()
+    for _ in range(20): fn()
+    print(f"{label}: {1e6 * (time.perf_counter() - t0) / 20:.1f} us per call")
